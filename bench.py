@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on N MI355X GPUs of one node: graphs/sec + gather-aggregate HBM GB/s.
+
+A "step" is one batched forward (graph prep + conv stack + pooling + MLP head) over one batch of
+synthetic molecule-shaped graphs that is already resident in HBM.  Default workload = BASELINE.json
+configs[1]: 2-layer GCN d=128, QM9-shaped graphs, batch 4096 per GPU.  One process per GPU
+(torch.distributed / RCCL); graphs are independent, so ranks shard batches with no data-path
+collective and only the throughput counters are reduced (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
+  roofline      -- the GCN gather-aggregate kernel at the full feature width: algorithmic bytes
+                    / measured launch duration (HIP events on the launch stream,
+                   rotating through distinct buffers > 256 MiB so the Infinity Cache cannot serve
+                   the reads) against 8 TB/s.
+  cpu_baseline  -- the reference's own C++ kernel library (oracle/_ref, compiled in place from
+                   /root/reference; falls back to the C oracle port when it is absent) running the
+                   same model on a bounded sample of the same graphs on ONE host core, rank 0 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md chip table (spec); 6290 measured float4 copy
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    # BASELINE.json configs[1..4]
+    "c2": dict(desc="2-layer GCN d=128, QM9-shaped synthetic graphs, batch=4096 per GPU", conv="gcn", shape="qm9",
+               hidden=128, layers=2, pools=("add", "mean", "max"), batch=4096),
+    "c3": dict(desc="3-layer GIN d=128 + sum-pool, ogbg-molhiv-shaped graphs, batch=4096 per GPU", conv="gin",
+               shape="molhiv", hidden=128, layers=3, pools=("add",), batch=4096),
+    "c4": dict(desc="3-layer PNA d=128, QM9-shaped graphs, batch=8192 per GPU", conv="pna", shape="qm9",
+               hidden=128, layers=3, pools=("add", "mean", "max"), batch=8192),
+    "c5": dict(desc="2-layer GraphSAGE d=256, ogbg-molhiv-shaped graphs, batch=8192 per GPU (65536 over 8)",
+               conv="sage", shape="molhiv", hidden=256, layers=2, pools=("add", "mean", "max"), batch=8192),
+}
+
+
+def build_model(w, seed=0):
+    import torch
+    import gnnbuilder_amd as gnnb
+    from gnnbuilder_amd import synthetic
+
+    torch.manual_seed(seed)
+    convs = {"gcn": gnnb.GCNConv_GNNB, "gin": gnnb.GINConv_GNNB, "sage": gnnb.SAGEConv_GNNB, "pna": gnnb.PNAConv_GNNB}
+    shp = synthetic.SHAPES[w["shape"]]
+    return gnnb.GNNModel(shp["f_in"], None, w["hidden"], w["layers"], w["hidden"], convs[w["conv"]], torch.nn.ReLU,
+                         True, gnnb.GlobalPooling(list(w["pools"])),
+                         gnnb.MLP(len(w["pools"]) * w["hidden"], shp["out"], 64, 2), None).eval()
+
+
+def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200):
+    """GCN gather-aggregate at `width`, timed with HIP events on the launch stream.  Returns both
+    the HBM regime (inputs/outputs rotate over > 256 MiB of distinct buffers) and the regime the
+    kernel sees inside the pipeline (same buffers every launch: Infinity-Cache resident)."""
+    import torch
+    from gnnbuilder_amd import runtime
+
+    x, coo, nptr, eptr = batch_dev
+    N, E, B = int(x.shape[0]), int(coo.shape[0]), int(nptr.numel()) - 1
+    cm.graph_prep(coo, nptr, eptr, N)
+    # read every input row once + write every output row once + CSR + graph ptr
+    alg_bytes = 4 * width * N + 4 * width * N + 4 * (N + 1) + 4 * E + 4 * (B + 1)
+    per_pair = 2 * 4 * width * N
+    nbuf = max(2, int(np.ceil(320 * 2**20 / per_pair)) + 1)
+    ins = [torch.rand(N, width, device=dev) * 2 - 1 for _ in range(nbuf)]
+    outs = [torch.empty(N, width, device=dev) for _ in range(nbuf)]
+    timer = runtime.HipTimer()
+    res = {}
+    for regime, rotate in (("hbm", True), ("l3_resident", False)):
+        for i in range(10):
+            cm.aggregate("gcn", ins[i % nbuf if rotate else 0], out=outs[i % nbuf if rotate else 0])
+        torch.cuda.synchronize()
+        timer.start()
+        for i in range(iters):
+            k = i % nbuf if rotate else 0
+            cm.aggregate("gcn", ins[k], out=outs[k])
+        timer.stop()
+        us = timer.elapsed_ms() * 1e3 / iters
+        res[regime] = dict(us=us, gbps=alg_bytes / (us * 1e-6) / 1e9)
+    del ins, outs
+    return alg_bytes, res
+
+
+def measure_update_mfma(w, N, dev, iters=100):
+    """The dense update of the full-width layer (X[N,d] . W[d,d]^T + b, ReLU) on fp32 MFMA."""
+    import torch
+    from gnnbuilder_amd import runtime
+
+    d = w["hidden"]
+    a = torch.rand(N, d, device=dev) - 0.5
+    wt = (torch.rand(d, d, device=dev) - 0.5) / d ** 0.5
+    b = torch.rand(d, device=dev)
+    y = torch.empty(N, d, device=dev)
+    timer = runtime.HipTimer()
+    for _ in range(5):
+        runtime.linear([(a, None)], wt, b, act="relu", out=y)
+    torch.cuda.synchronize()
+    timer.start()
+    for _ in range(iters):
+        runtime.linear([(a, None)], wt, b, act="relu", out=y)
+    timer.stop()
+    us = timer.elapsed_ms() * 1e3 / iters
+    flops = 2.0 * N * d * d
+    return dict(us=us, tflops=flops / (us * 1e-6) / 1e12, frac=flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+
+
+def cpu_baseline(model, batch, budget_s=12.0):
+    """Reference CPU path on ONE core over a bounded sample of the same graphs."""
+    from oracle import oracle as O
+
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})  # as build_base_benchmarks.py:188-189
+    except Exception:
+        pass
+    spec, params = model.spec(), [p.numpy() for p in model.canonical_params()]
+    kind = "reference" if O.have_ref() else "port"
+    chunk, done, t_total = 128, 0, 0.0
+    B = batch.num_graphs
+    while t_total < budget_s and done < B:
+        g1 = min(done + chunk, B)
+        sub = batch.slice(done, g1)
+        t0 = time.perf_counter()
+        if kind == "reference":
+            try:
+                O.ref_forward_batched(spec, params, sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
+            except ValueError:
+                kind = "port"
+                continue
+        else:
+            O.forward_batched(spec, params, sub.x, sub.coo, sub.node_ptr, sub.edge_ptr, std="pyg")
+        t_total += time.perf_counter() - t0
+        done = g1
+    what = ("reference C++ kernel library (gnn_builder_lib.h, float, g++ -O2) via oracle/_ref"
+            if kind == "reference" else "C oracle port (oracle/gnnb_oracle.c, gcc -O2)")
+    return {"value": done / t_total, "unit": "graphs/s", "cores": 1, "kind": kind,
+            "sample": f"first {done} graphs of the step's batch, per-graph loop, {t_total:.1f} s; {what}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches rotated per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from gnnbuilder_amd import runtime, synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`",
+                  file=sys.stderr)
+            sys.exit(2)
+    runtime.load_library(require_gpu=True)  # no fallback: fail loudly without the HIP path
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w = WORKLOADS[args.workload]
+    model = build_model(w)
+    # rank-distinct synthetic batches (weak scaling: every GPU gets its own `batch` graphs per step)
+    batches = [synthetic.make_batch(w["shape"], w["batch"], seed=1000 * rank + i) for i in range(args.batches)]
+    maxn = max(b.num_nodes for b in batches)
+    maxe = max(b.num_edges for b in batches)
+    cm = runtime.CompiledModel.from_model(model, w["batch"], maxn, maxe)
+    dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr)) for b in batches]
+    outs = [torch.empty(w["batch"], cm.out_dim, device=dev) for _ in batches]
+
+    def step(i):
+        k = i % len(dev_batches)
+        cm.forward(*dev_batches[k], out=outs[k])
+
+    for i in range(args.warmup):
+        step(i)
+    cm.check()  # device-side batch validation (synchronises)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    graphs_done = float(args.steps * w["batch"])
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # RCCL over xGMI: 8 bytes, latency only
+        elapsed = float(t.item())
+        c = torch.tensor([graphs_done], device=dev, dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        graphs_done = float(c.item())
+
+    # the prep-excluded rate (topology tables re-used; only features change)
+    x0, coo0, np0, ep0 = dev_batches[0]
+    cm.graph_prep(coo0, np0, ep0, int(x0.shape[0]))
+    for _ in range(5):
+        cm.forward_prepared(x0, out=outs[0])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    nprep = max(args.steps // 2, 10)
+    for _ in range(nprep):
+        cm.forward_prepared(x0, out=outs[0])
+    torch.cuda.synchronize()
+    ms_noprep = (time.perf_counter() - t1) / nprep * 1e3
+
+    result = {
+        "metric": "graphs/sec whole-node (batched QM9, GCN d=128)" if args.workload == "c2"
+        else f"graphs/sec whole-node ({args.workload})",
+        "value": graphs_done / elapsed,
+        "unit": "graphs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": w["desc"], "graphs_per_step_per_gpu": w["batch"],
+                   "nodes_per_batch": int(np.mean([b.num_nodes for b in batches])),
+                   "edges_per_batch": int(np.mean([b.num_edges for b in batches])),
+                   "parallelism": f"graph-sharded x{world}, no data-path collective",
+                   "csr_build_in_timed_region": True},
+        "ms_per_step_prepared_topology": ms_noprep,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        alg_bytes, agg = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev)
+        result["roofline"] = {
+            "kernel": "k_aggregate<GCN> (gather-aggregate, width %d)" % w["hidden"],
+            "bound": "hbm", "achieved": agg["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": agg["hbm"]["us"],
+            "regime": "inputs/outputs rotate over >256 MiB of distinct buffers (HBM-served)",
+            "l3_resident": agg["l3_resident"],
+        }
+        result["roofline_update"] = dict(kernel="k_linear (fp32 MFMA 32x32x2), full-width layer update",
+                                         bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                         **measure_update_mfma(w, batches[0].num_nodes, dev))
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(model, batches[0])
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

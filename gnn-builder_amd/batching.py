@@ -1,0 +1,125 @@
+"""Packing many small graphs into one batched COO/ptr layout, and sharding batches across GPUs.
+
+The reference processes one graph per ``<name>_top`` call (model_tb.cpp.jinja:189-201).  The
+MI355X path packs thousands of independent graphs so one kernel launch covers them all:
+
+    x        [N_tot, F]   fp32, graphs concatenated
+    coo      [E_tot, 2]   int32 (src, dst) with batch-global node ids, edges grouped by graph
+    node_ptr [B+1]        int32
+    edge_ptr [B+1]        int32
+
+This is host logic (numpy): it runs on CPU and is covered by the ``-m "not gpu"`` tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+@dataclass
+class GraphBatch:
+    x: np.ndarray
+    coo: np.ndarray
+    node_ptr: np.ndarray
+    edge_ptr: np.ndarray
+
+    @property
+    def num_graphs(self) -> int:
+        return int(self.node_ptr.shape[0]) - 1
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.node_ptr[-1])
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.edge_ptr[-1])
+
+    def graph(self, g: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(x, coo with graph-local ids) of graph g -- what ``<name>_top`` takes."""
+        n0, n1 = int(self.node_ptr[g]), int(self.node_ptr[g + 1])
+        e0, e1 = int(self.edge_ptr[g]), int(self.edge_ptr[g + 1])
+        return self.x[n0:n1], self.coo[e0:e1] - n0
+
+    def slice(self, g0: int, g1: int) -> "GraphBatch":
+        n0, n1 = int(self.node_ptr[g0]), int(self.node_ptr[g1])
+        e0, e1 = int(self.edge_ptr[g0]), int(self.edge_ptr[g1])
+        return GraphBatch(
+            x=np.ascontiguousarray(self.x[n0:n1]),
+            coo=np.ascontiguousarray(self.coo[e0:e1] - n0),
+            node_ptr=(self.node_ptr[g0:g1 + 1] - n0).astype(np.int32),
+            edge_ptr=(self.edge_ptr[g0:g1 + 1] - e0).astype(np.int32),
+        )
+
+    def validate(self) -> None:
+        B = self.num_graphs
+        if self.node_ptr[0] != 0 or self.edge_ptr[0] != 0:
+            raise ValueError("ptr arrays must start at 0")
+        if np.any(np.diff(self.node_ptr) < 0) or np.any(np.diff(self.edge_ptr) < 0):
+            raise ValueError("ptr arrays must be non-decreasing")
+        if self.x.shape[0] != self.num_nodes or self.coo.shape[0] != self.num_edges:
+            raise ValueError("x / coo sizes disagree with the ptr arrays")
+        if self.num_edges:
+            g_of_edge = np.repeat(np.arange(B), np.diff(self.edge_ptr))
+            lo, hi = self.node_ptr[g_of_edge], self.node_ptr[g_of_edge + 1]
+            if np.any(self.coo < lo[:, None]) or np.any(self.coo >= hi[:, None]):
+                raise ValueError("an edge leaves its graph")
+
+
+def pack_graphs(graphs: Sequence[Tuple[np.ndarray, np.ndarray]]) -> GraphBatch:
+    """``graphs``: sequence of (x [n, F], edges) where edges is either ``[e, 2]`` (src, dst) rows
+    -- the tb_data ``*_coo.bin`` layout, reference code_gen.py:262 -- or a PyG-style
+    ``edge_index`` ``[2, e]``; ids are graph-local."""
+    xs, coos, nptr, eptr = [], [], [0], [0]
+    feat = None
+    for x, ei in graphs:
+        x = np.asarray(x, dtype=np.float32)
+        if x.ndim != 2:
+            raise ValueError("node features must be [n, F]")
+        feat = x.shape[1] if feat is None else feat
+        if x.shape[1] != feat:
+            raise ValueError("all graphs must share the feature width")
+        ei = np.asarray(ei)
+        if ei.size == 0:
+            ei = np.zeros((0, 2), dtype=np.int32)
+        elif ei.ndim == 2 and ei.shape[0] == 2 and ei.shape[1] != 2:
+            ei = ei.T
+        elif ei.ndim != 2 or ei.shape[1] != 2:
+            raise ValueError("edges must be [e, 2] or [2, e]")
+        ei = ei.astype(np.int32)
+        if ei.size and (ei.min() < 0 or ei.max() >= x.shape[0]):
+            raise ValueError("edge endpoint outside its graph")
+        xs.append(x)
+        coos.append(ei + nptr[-1])
+        nptr.append(nptr[-1] + x.shape[0])
+        eptr.append(eptr[-1] + ei.shape[0])
+    if feat is None:
+        raise ValueError("empty batch")
+    return GraphBatch(
+        x=np.ascontiguousarray(np.concatenate(xs, axis=0)) if xs else np.zeros((0, feat), np.float32),
+        coo=np.ascontiguousarray(np.concatenate(coos, axis=0)).reshape(-1, 2).astype(np.int32),
+        node_ptr=np.asarray(nptr, dtype=np.int32),
+        edge_ptr=np.asarray(eptr, dtype=np.int32),
+    )
+
+
+def shard_bounds(node_ptr: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous graph ranges per rank, cut on the cumulative NODE count so every GPU gets
+    ~N_tot/world_size nodes; graphs are never split."""
+    B = int(node_ptr.shape[0]) - 1
+    total = int(node_ptr[-1])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        g = int(np.searchsorted(node_ptr, target, side="left"))
+        g = min(max(g, cuts[-1]), B)
+        cuts.append(g)
+    cuts.append(B)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
+def shard_batch(batch: GraphBatch, world_size: int, rank: int) -> GraphBatch:
+    g0, g1 = shard_bounds(batch.node_ptr, world_size)[rank]
+    return batch.slice(g0, g1)

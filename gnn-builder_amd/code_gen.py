@@ -1,0 +1,303 @@
+"""``Project`` -- the compiler driver, counterpart of the reference's ``gnnbuilder/code_gen.py``.
+
+Same constructor, method names and return keys as the reference ``Project`` (code_gen.py:62-489),
+so existing driver scripts (``demos/demo.py:102-129``,
+``experiments/build_gnnbuilder_benchmarks.py:202-223``) run unchanged.  What changes is the
+emission target: instead of rendering Vitis-HLS C++ over ``gnn_builder_lib.h`` it renders
+
+* ``model.h`` / ``model.cpp`` -- a thin C-ABI host shim exporting the reference's
+  ``extern "C" <name>_top(...)`` plus a batched entry, bound to ``libgnnb_hip.so`` (hand-written HIP
+  kernels for gfx950, ``csrc/``);
+* ``model_tb.cpp`` -- the testbench harness with the reference's ``tb_data`` contract;
+* ``makefile_testbench`` -- a ``hipcc --offload-arch=gfx950`` build;
+* ``model_desc.json`` -- the architecture and parameter manifest.
+
+FPGA-only controls (``vitis_hls_path``, ``fpx``, ``clock_speed``, ``fpga_part``, the Vitis
+synthesis / co-simulation methods) are accepted for signature compatibility and otherwise unused.
+"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+from functools import cached_property
+from pathlib import Path
+from typing import Optional
+
+import jinja2
+import numpy as np
+import torch
+
+from .models import GNNModel
+from .utils import layer_param_name_combiner, serialize_tensor, write_file
+
+CURRENT_DIR = Path(__file__).resolve().parent
+REPO_INCLUDE_DIR = CURRENT_DIR.parent / "include"
+
+template_env = jinja2.Environment(
+    loader=jinja2.FileSystemLoader(searchpath=str(CURRENT_DIR / "templates")),
+    trim_blocks=True,
+    lstrip_blocks=True,
+)
+
+
+class FPX:
+    """Fixed-point spec of the reference (code_gen.py:39-52).  Kept so scripts that pass one keep
+    working; the MI355X backend computes in fp32 only."""
+
+    def __init__(self, W: int = 32, I: int = 16, Q: str = "AP_TRN", O: str = "AP_WRAP"):
+        self.W, self.I, self.Q, self.O = W, I, Q, O
+        if I > 33:
+            raise Exception("I must be <= 33")
+        if W - I > 32:
+            raise Exception("W-I must be <= 32")
+
+    def __str__(self):
+        return f"ap_fixed<{self.W},{self.I},{self.Q},{self.O}>"
+
+
+SUPPORTED_FPGA_PARTS = ["xcu50-fsvh2104-2-e", "xcu280-fsvh2892-2L-e"]
+SUPPORTED_GPU_ARCHS = ["gfx950"]
+
+
+class Project:
+    def __init__(
+        self,
+        name: str,
+        model: GNNModel,
+        pyg_output_encoding: str,
+        vitis_hls_path: Optional[Path] = None,
+        build_dir: Path = Path("./build"),
+        dataset=None,
+        max_nodes: int = 500,
+        max_edges: int = 500,
+        num_nodes_guess: Optional[int] = None,
+        num_edges_guess: Optional[int] = None,
+        degree_guess: Optional[int] = None,
+        float_or_fixed: str = "float",
+        fpx: FPX = FPX(W=32, I=16),
+        clock_speed: float = 3.33,
+        fpga_part: str = "xcu50-fsvh2104-2-e",
+        n_jobs: int = 1,
+        cosim_wave_debug: bool = False,
+        arch: str = "gfx950",
+    ):
+        self.model = model
+        self.dataset = dataset
+        self.name = name
+        self.max_nodes = max_nodes
+        self.max_edges = max_edges
+        self.num_nodes_guess = self.max_nodes if num_nodes_guess is None else num_nodes_guess
+        self.num_edges_guess = self.max_edges if num_edges_guess is None else num_edges_guess
+        self.degree_guess = self.max_nodes if degree_guess is None else degree_guess
+
+        self.pyg_output_encoding = pyg_output_encoding
+        valid_output_encodings = ["regression", "classification_integer", "classification_onehot"]
+        if self.pyg_output_encoding not in valid_output_encodings:
+            raise ValueError(f"pyg_output_encoding must be one of {valid_output_encodings}")
+
+        self.vitis_hls_path = vitis_hls_path
+        self.build_dir = Path(build_dir)
+
+        self.float_or_fixed = float_or_fixed
+        self.fpx = fpx
+        if float_or_fixed not in ["float", "fixed"]:
+            raise ValueError("float_or_fixed must be one of ['float', 'fixed']")
+        if float_or_fixed == "fixed":
+            raise NotImplementedError(
+                "the MI355X backend computes in fp32; ap_fixed emulation is not built "
+                "(SURVEY.md 8(f) rank 4)")
+        self.clock_speed = clock_speed
+        if self.clock_speed <= 0:
+            raise ValueError("clock_speed must be > 0")
+        self.fpga_part = fpga_part
+        if self.fpga_part not in SUPPORTED_FPGA_PARTS:
+            raise ValueError(f"fpga_part must be one of {SUPPORTED_FPGA_PARTS}")
+        self.n_jobs = n_jobs
+        if self.n_jobs <= 0:
+            raise ValueError("n_jobs must be > 0")
+        self.cosim_wave_debug = cosim_wave_debug
+        self.arch = arch
+        if self.arch not in SUPPORTED_GPU_ARCHS:
+            raise ValueError(f"arch must be one of {SUPPORTED_GPU_ARCHS}")
+        if not str(name).isidentifier():
+            raise ValueError("name must be a valid C identifier (it prefixes the exported symbols)")
+
+    def validate_project(self):
+        if self.name is None:
+            raise Exception("No name is set.")
+        if self.dataset is None:
+            raise Exception("No dataset is set.")
+        if self.model is None:
+            raise Exception("No model is set.")
+
+    @cached_property
+    def model_dir(self) -> Path:
+        return self.build_dir / self.name
+
+    # ------------------------------------------------------------------ template context
+    @cached_property
+    def template_dict(self) -> dict:
+        from .runtime import ACT, CONV, POOL
+
+        spec = self.model.spec()
+        names = self.model.layer_parameter_names_flat
+        shapes = self.model.layer_parameter_shapes_flat
+        params = []
+        for n, s in zip(names, shapes):
+            ctype = "float *" if len(s) == 1 else "float (*)" + "".join(f"[{d}]" for d in s[1:])
+            params.append({"name": n, "shape": s, "shape_len": len(s), "size": int(np.prod(s)), "ctype": ctype})
+        pools = [POOL[p] for p in spec["pools"]] + [0, 0, 0]
+        desc = {
+            "conv_type": CONV[spec["conv"]], "num_layers": spec["num_layers"], "in_dim": spec["in_dim"],
+            "hidden_dim": spec["hidden_dim"], "out_dim": spec["out_dim"], "activation": ACT[spec["activation"]],
+            "skip": int(spec["skip"]), "num_pools": len(spec["pools"]), "pools": pools[:3],
+            "mlp_num_linear": spec["mlp_hidden_layers"] + 1, "mlp_hidden": spec["mlp_hidden"],
+            "mlp_out": spec["mlp_out"], "mlp_activation": ACT[spec["mlp_activation"]],
+            "gin_eps": repr(float(spec["gin_eps"])), "pna_delta": repr(float(spec["pna_delta"])),
+        }
+        return {
+            "name": self.name,
+            "NAME": self.name.upper(),
+            "model_top_name": self.name,
+            "max_nodes": self.max_nodes,
+            "max_edges": self.max_edges,
+            "in_dim": self.model.input_node_features_dim,
+            "out_dim": self.model.output_features_dim,
+            "params": params,
+            "model_parameters": params,
+            "canon": self.model.canonical_param_names(),
+            "desc": desc,
+            "spec": spec,
+            "include_dir": str(REPO_INCLUDE_DIR),
+            "lib_dir": str(CURRENT_DIR),
+            "arch": self.arch,
+        }
+
+    def _render(self, template: str, out_name: str) -> None:
+        os.makedirs(self.model_dir, exist_ok=True)
+        write_file(self.model_dir / out_name, template_env.get_template(template).render(self.template_dict))
+
+    # ------------------------------------------------------------------ emission (reference code_gen.py:201-337)
+    def gen_hw_model(self):
+        """Emit the host shim (``model.h`` / ``model.cpp``) and the model manifest."""
+        self._render("model.h.jinja", "model.h")
+        self._render("model.cpp.jinja", "model.cpp")
+        td = self.template_dict
+        manifest = {"name": self.name, "arch": self.arch, "spec": td["spec"],
+                    "max_nodes": self.max_nodes, "max_edges": self.max_edges,
+                    "parameters": [{"name": p["name"], "shape": p["shape"]} for p in td["params"]],
+                    "canonical_order": td["canon"]}
+        write_file(self.model_dir / "model_desc.json", json.dumps(manifest, indent=2))
+
+    def gen_testbench(self, gen_testbench_data=True):
+        self._render("model_tb.cpp.jinja", "model_tb.cpp")
+        if gen_testbench_data:
+            self.gen_testbench_data()
+
+    def gen_testbench_data(self):
+        """Write ``tb_data/`` in the reference's on-disk format (code_gen.py:227-305, SURVEY
+        Appendix B): raw little-endian fp32 / int32, no headers."""
+        self.validate_project()
+        tb = self.model_dir / "tb_data"
+        os.makedirs(tb / "model_parameters", exist_ok=True)
+        os.makedirs(tb / "graphs", exist_ok=True)
+        for layer in self.model.layers:
+            for pname, tensor in self.model.layer_parameters[layer]:
+                serialize_tensor(tensor, tb / "model_parameters" / f"{layer_param_name_combiner(layer, pname)}.bin")
+
+        indices = list(self.dataset.indices())
+        with open(tb / "dataset_info.txt", "w") as f:
+            f.write(f"num_graphs {len(indices)}\n")
+            for idx in indices:
+                f.write(f"{idx}\n")
+
+        was_training = self.model.training
+        self.model.eval()
+        with torch.no_grad():
+            for idx in indices:
+                graph = self.dataset[idx]
+                edge_index = torch.as_tensor(graph.edge_index)
+                x = torch.as_tensor(graph.x)
+                base = tb / "graphs" / f"graph_{idx}"
+                serialize_tensor(torch.tensor([int(graph.num_nodes), int(graph.num_edges)]),
+                                 Path(f"{base}_info.bin"), np_type=np.int32)
+                serialize_tensor(edge_index.T.contiguous(), Path(f"{base}_coo.bin"), np_type=np.int32)
+                serialize_tensor(x, Path(f"{base}_node_features.bin"))
+                y = torch.as_tensor(graph.y)
+                task = None
+                if self.pyg_output_encoding == "regression":
+                    task = y.float().view(-1)
+                elif self.pyg_output_encoding == "classification_integer":
+                    task = torch.zeros(int(self.dataset.num_classes))
+                    task[int(y.long().view(-1)[0])] = 1.0
+                elif self.pyg_output_encoding == "classification_onehot":
+                    task = y.float().view(-1)
+                    assert task.shape[0] == int(self.dataset.num_classes)
+                if task is not None:
+                    serialize_tensor(task, Path(f"{base}_task_golden_output.bin"))
+                golden = self.model(x.float(), edge_index.long()).detach().view(-1)
+                serialize_tensor(golden, Path(f"{base}_model_golden_output.bin"))
+        self.model.train(was_training)
+
+    def gen_makefile(self):
+        self._render("makefile_testbench.jinja", "makefile_testbench")
+
+    # ------------------------------------------------------------------ build + run (reference code_gen.py:339-395)
+    def build_and_run_testbench(self):
+        """``make -f makefile_testbench result`` with hipcc, run ``./result`` on the GPU, parse
+        ``tb_data/model_output_mae.txt`` / ``model_runtime.txt``.  Returns the reference's keys
+        (``model_output_mae``, ``model_runtime`` seconds per graph) plus the batched figures."""
+        for fp in ("model_tb.cpp", "model.h", "model.cpp", "makefile_testbench"):
+            if not (self.model_dir / fp).exists():
+                raise Exception(
+                    f"{self.name} - {self.model_dir / fp} does not exist. Make sure you call the"
+                    " gen_<...> functions to generate the model and testbench source code.")
+        from .runtime import LIB_PATH, build_library
+
+        if not LIB_PATH.exists():
+            build_library()
+        proc = subprocess.run(["make", "-f", "makefile_testbench", "result"], cwd=self.model_dir,
+                              capture_output=True)
+        if proc.returncode != 0:
+            print(proc.stdout.decode("utf-8"))
+            print(proc.stderr.decode("utf-8"))
+            raise Exception(f"{self.name} - Testbench build failed.")
+        proc = subprocess.run(["./result"], cwd=self.model_dir, capture_output=True)
+        if proc.returncode != 0:
+            print(proc.stdout.decode("utf-8"))
+            print(proc.stderr.decode("utf-8"))
+            raise Exception(f"{self.name} - Testbench execution failed (return code {proc.returncode}).")
+
+        def _read(key):
+            fp = self.model_dir / "tb_data" / f"{key}.txt"
+            return float(fp.read_text().strip().split()[1])
+
+        return {
+            "model_output_mae": _read("model_output_mae"),
+            "model_runtime": _read("model_runtime"),
+            "model_output_mae_batched": _read("model_output_mae_batched"),
+            "model_runtime_batched": _read("model_runtime_batched"),
+        }
+
+    # ------------------------------------------------------------------ FPGA-only surface
+    def _fpga_only(self, what: str):
+        raise NotImplementedError(
+            f"{what} drives Xilinx Vitis tools (reference code_gen.py:316-337,397-489); the MI355X "
+            "backend has no FPGA flow.  Use gen_hw_model / gen_testbench / gen_makefile / "
+            "build_and_run_testbench.")
+
+    def gen_vitis_hls_tcl_script(self):
+        self._fpga_only("gen_vitis_hls_tcl_script")
+
+    def gen_vitis_hls_cosim_tcl_script(self):
+        self._fpga_only("gen_vitis_hls_cosim_tcl_script")
+
+    def run_vitis_hls_synthesis(self, verbose=False):
+        self._fpga_only("run_vitis_hls_synthesis")
+
+    def gen_makefile_vitis(self):
+        self._fpga_only("gen_makefile_vitis")
+
+    def build_hw_kernel(self):
+        self._fpga_only("build_hw_kernel")

@@ -1,0 +1,57 @@
+// gnnb_internal.h -- launcher prototypes shared by the kernel and runtime translation units
+// of libgnnb_hip.so (gfx950 only).  Public ABI: include/gnnb_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gnnb_hip.h"
+
+namespace gnnb {
+
+// Tables produced by graph prep for one batch (all device pointers, owned by a workspace).
+struct BatchTables {
+    int32_t *row_ptr;    // [N+1] CSR by destination, batch-global
+    int32_t *col;        // [E]   source node (batch-global id) of every in-edge, stable COO order
+    float *amp;          // [N]   PNA amplification  log(max(d,1)+1)/delta
+    float *att;          // [N]   PNA attenuation    delta/log(max(d,1)+1)
+    int32_t *tile_first; // [T+1] first node of node-tile t; tiles are cut at graph boundaries
+    int32_t *err;        // [1]   != 0 when the batch was malformed
+    const int32_t *node_ptr; // [B+1] caller's graph_node_ptr (device)
+    int32_t num_graphs, num_nodes, num_edges;
+    int32_t tile_rows;   // target rows per tile
+    int32_t num_tiles;
+};
+
+struct Options {
+    int tile_rows;    // node-tile granularity of the gather-aggregate kernel
+    int agg_lds_kb;   // LDS budget per aggregate workgroup
+    int agg_tiles_per_wg;
+    int agg_overshoot; // LDS rows reserved for the graph that straddles a tile's end
+};
+Options &options();
+
+hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
+                             BatchTables &t, float pna_delta, hipStream_t s);
+
+hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
+                            float *out, int width, float eps, hipStream_t s);
+
+struct GemmArgs {
+    const float *a[4];
+    const float *rs[4];
+    int32_t lda[4];
+    int32_t k[4];
+    int32_t koff[4];   // column offset of segment s inside W
+    int32_t cpre[5];   // prefix sums of ceil(k/32)
+    int32_t avec[4];   // segment may use 16-byte loads for A
+    int32_t wvec[4];   // ... for W
+    int32_t nseg;
+};
+hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
+                         const float *skip, float *y, int M, int N, int act, hipStream_t s);
+
+hipError_t launch_global_pool(const float *x, const int32_t *node_ptr, int num_graphs, int d,
+                              const int32_t *pools, int num_pools, float *out, hipStream_t s);
+
+} // namespace gnnb

@@ -1,0 +1,742 @@
+// gnnb_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels of the GNNBuilder hot path.
+//
+//   k_graph_prep   COO -> CSR-by-destination + degree scalers + node tiles   (HBM / latency bound)
+//   k_aggregate    gather -> segmented reduce per destination row            (HBM bound: THE roofline kernel)
+//   k_linear       multi-segment X.W^T + bias + skip + activation on fp32 MFMA (matrix-core bound)
+//   k_global_pool  per-graph add / mean / max readout                        (HBM bound)
+//
+// Wavefront = 64 lanes everywhere.  Reference semantics are cited per kernel
+// (paths relative to the reference repository root).
+#include "gnnb_internal.h"
+
+namespace gnnb {
+
+static constexpr int WG = 256; // 4 wavefronts
+
+// =====================================================================================
+// graph prep
+// =====================================================================================
+// Reference: compute_degree_tables + compute_neighbor_tables
+// (gnnbuilder/gnn_builder_lib/gnn_builder_lib.h:1051-1083, :1086-1124): in-degree, exclusive
+// prefix sum, stable counting sort of sources by destination.  The reference runs this
+// serially per graph; here ONE WAVEFRONT owns one graph of the batch: lane = destination
+// node, the graph's (few dozen) edges sit in LDS and are scanned by broadcast reads, so the
+// sort is stable by construction and needs no atomics.  Edges of a graph are contiguous
+// (edge_ptr), so the batch-global CSR segment of graph g starts at edge_ptr[g].
+static constexpr int PREP_EDGE_CAP = 512; // edges cached in LDS per wavefront
+
+__global__ __launch_bounds__(WG) void k_graph_prep(
+    const int2 *__restrict__ coo, const int32_t *__restrict__ node_ptr,
+    const int32_t *__restrict__ edge_ptr, int B, int N, int E, int32_t *__restrict__ row_ptr,
+    int32_t *__restrict__ col, float *__restrict__ amp, float *__restrict__ att, float delta,
+    int32_t *__restrict__ tile_first, int tile_rows, int num_tiles, int32_t *__restrict__ err)
+{
+    __shared__ int2 s_edges[WG / 64][PREP_EDGE_CAP];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * (WG / 64) + wave;
+    if (g > B)
+        return;
+
+    // ---- node tiles: tile_first[t] = min{ node_ptr[g'] : node_ptr[g'] >= t*tile_rows }
+    {
+        // clamped so that a malformed node_ptr (flagged below) cannot write out of range
+        const int p = (g == B) ? N : min(max(node_ptr[g], 0), N);
+        const int t_lo = (g == 0) ? 0 : max(min(max(node_ptr[g - 1], 0), N) / tile_rows + 1, 0);
+        const int t_hi = (g == B) ? num_tiles : min(p / tile_rows, num_tiles);
+        for (int t = t_lo + lane; t <= t_hi; t += 64)
+            tile_first[t] = p;
+    }
+    if (g == B) {
+        if (lane == 0) {
+            row_ptr[N] = E;
+            if (node_ptr[B] != N || edge_ptr[B] != E || node_ptr[0] != 0 || edge_ptr[0] != 0)
+                atomicOr(err, 1);
+        }
+        return;
+    }
+
+    const int n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
+    if (n0 > n1 || e0 > e1 || n1 > N || e1 > E || n0 < 0 || e0 < 0) {
+        if (lane == 0)
+            atomicOr(err, 2);
+        return;
+    }
+    const int ne = e1 - e0;
+    const bool cached = ne <= PREP_EDGE_CAP;
+    int2 *se = s_edges[wave];
+    bool bad = false;
+    if (cached) {
+        for (int i = lane; i < ne; i += 64) {
+            int2 ed = coo[e0 + i];
+            // an edge that leaves its graph is an error; clamp so later gathers stay in range
+            if (ed.x < n0 || ed.x >= n1 || ed.y < n0 || ed.y >= n1) {
+                bad = true;
+                ed.x = n0;
+                ed.y = -1;
+            }
+            se[i] = ed;
+        }
+    }
+    // (wave-private LDS region: the wave's own writes are visible to it after the waitcnt
+    //  the compiler inserts; no workgroup barrier needed)
+    __builtin_amdgcn_wave_barrier();
+
+    int base = e0;
+    for (int c0 = n0; c0 < n1; c0 += 64) {
+        const int v = c0 + lane;
+        const bool active = v < n1;
+        int cnt = 0;
+        if (cached) {
+            for (int i = 0; i < ne; i++)
+                cnt += (se[i].y == v) ? 1 : 0;
+        } else {
+            for (int i = 0; i < ne; i++) {
+                int2 ed = coo[e0 + i];
+                if (ed.x < n0 || ed.x >= n1 || ed.y < n0 || ed.y >= n1)
+                    bad = true;
+                else
+                    cnt += (ed.y == v) ? 1 : 0;
+            }
+        }
+        if (!active)
+            cnt = 0;
+        // wave-wide inclusive scan of the in-degrees
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += t;
+        }
+        const int start = base + incl - cnt;
+        if (active) {
+            row_ptr[v] = start;
+            const int dcl = cnt < 1 ? 1 : cnt; // gnn_builder_lib.h:1972-1982
+            const float logd = logf((float)(dcl + 1));
+            amp[v] = logd / delta;
+            att[v] = delta / logd;
+        }
+        // stable fill: edges are visited in COO order
+        int pos = start;
+        if (cached) {
+            for (int i = 0; i < ne; i++) {
+                int2 ed = se[i];
+                if (ed.y == v)
+                    col[pos++] = ed.x;
+            }
+        } else {
+            for (int i = 0; i < ne; i++) {
+                int2 ed = coo[e0 + i];
+                if (ed.y == v && ed.x >= n0 && ed.x < n1)
+                    col[pos++] = ed.x;
+            }
+        }
+        base += __shfl(incl, 63, 64);
+    }
+    if (bad)
+        atomicOr(err, 4);
+}
+
+hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
+                             BatchTables &t, float pna_delta, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(t.err, 0, sizeof(int32_t), s);
+    if (e != hipSuccess)
+        return e;
+    const int waves = t.num_graphs + 1;
+    const int grid = (waves + (WG / 64) - 1) / (WG / 64);
+    hipLaunchKernelGGL(k_graph_prep, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
+                       edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.amp,
+                       t.att, pna_delta, t.tile_first, t.tile_rows, t.num_tiles, t.err);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// gather-aggregate
+// =====================================================================================
+// One workgroup owns a run of node tiles, i.e. a few WHOLE graphs (tiles are cut at graph
+// boundaries), so every neighbour row a destination needs lies inside the workgroup's own
+// node range.  The node rows are streamed from HBM exactly once, fully coalesced (16 B per
+// lane), into LDS; the CSR slice (row_ptr, col) of the tile is staged next to them.  Each
+// destination row is then reduced by a lane group (width/4 lanes, float4 per lane) reading
+// its neighbours from LDS in CSR order -- no atomics, one owner per output row -- and the
+// result is written back with 16-B coalesced stores.  Algorithmic HBM traffic per launch:
+// 4*w*N read + 4*w*N*k_out write + 4*(N+1) + 4*E + 4*(T+1).
+//
+// A tile that does not fit the LDS budget (a graph far larger than tile_rows) takes the
+// same code path with the neighbour rows read straight from global memory (L2).
+//
+// Semantics per mode:
+//   GCN  gcn_conv_agg   gnn_builder_lib.h:1213-1289   sum_j x_j/sqrt((1+d_i)(1+d_j)) + x_i/sqrt((1+d_i)^2)
+//   SUM  gin_conv_agg   gnn_builder_lib.h:1389-1437 + :1525-1535   sum_j x_j + x_i (1+eps)
+//   MEAN sage_conv_agg  gnn_builder_lib.h:2161-2209   (sum_j x_j)/d, 0 when d = 0
+//   PNA  pna_conv_agg   gnn_builder_lib.h:1750-1834 with h_ij = q_i + p_j (the per-edge
+//        W_pre [x_i || x_j] + b split into two per-node products) and PyG's std:
+//        sqrt(max(E[h^2]-E[h]^2, 1e-5)) zeroed where <= sqrt(1e-5)  (SURVEY finding 5).
+// Neighbours are summed in CSR (= stable COO) order, the self term last, as the reference does.
+
+template <int VEC>
+struct Vf;
+template <>
+struct Vf<4> {
+    float4 v;
+    __device__ static Vf load(const float *p) { Vf r; r.v = *reinterpret_cast<const float4 *>(p); return r; }
+    __device__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = v; }
+    __device__ static Vf splat(float s) { Vf r; r.v = make_float4(s, s, s, s); return r; }
+};
+template <>
+struct Vf<1> {
+    float v;
+    __device__ static Vf load(const float *p) { Vf r; r.v = *p; return r; }
+    __device__ void store(float *p) const { *p = v; }
+    __device__ static Vf splat(float s) { Vf r; r.v = s; return r; }
+};
+#define VF_BINOP(NAME, EXPR)                                                         \
+    __device__ inline Vf<4> NAME(const Vf<4> &a, const Vf<4> &b)                     \
+    {                                                                                \
+        Vf<4> r;                                                                     \
+        { const float x = a.v.x, y = b.v.x; r.v.x = (EXPR); }                        \
+        { const float x = a.v.y, y = b.v.y; r.v.y = (EXPR); }                        \
+        { const float x = a.v.z, y = b.v.z; r.v.z = (EXPR); }                        \
+        { const float x = a.v.w, y = b.v.w; r.v.w = (EXPR); }                        \
+        return r;                                                                    \
+    }                                                                                \
+    __device__ inline Vf<1> NAME(const Vf<1> &a, const Vf<1> &b)                     \
+    {                                                                                \
+        Vf<1> r;                                                                     \
+        const float x = a.v, y = b.v;                                                \
+        r.v = (EXPR);                                                                \
+        return r;                                                                    \
+    }
+VF_BINOP(vadd, x + y)
+VF_BINOP(vmul, x *y)
+VF_BINOP(vmax, fmaxf(x, y))
+VF_BINOP(vmin, fminf(x, y))
+VF_BINOP(vdiv, x / y)
+VF_BINOP(vsub, x - y)
+#undef VF_BINOP
+// PyG StdAggregation: var = E[h^2] - E[h]^2 ; std = sqrt(clamp(var, 1e-5)) ; 0 where <= sqrt(1e-5)
+__device__ inline float pyg_std1(float mean2, float mean)
+{
+    float var = mean2 - mean * mean;
+    var = var < 1e-5f ? 1e-5f : var;
+    const float sd = sqrtf(var);
+    return sd <= sqrtf(1e-5f) ? 0.0f : sd;
+}
+__device__ inline Vf<4> pyg_std(const Vf<4> &m2, const Vf<4> &m)
+{
+    Vf<4> r;
+    r.v = make_float4(pyg_std1(m2.v.x, m.v.x), pyg_std1(m2.v.y, m.v.y), pyg_std1(m2.v.z, m.v.z),
+                      pyg_std1(m2.v.w, m.v.w));
+    return r;
+}
+__device__ inline Vf<1> pyg_std(const Vf<1> &m2, const Vf<1> &m)
+{
+    Vf<1> r;
+    r.v = pyg_std1(m2.v, m.v);
+    return r;
+}
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(WG) void k_aggregate(
+    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
+    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ tile_first, int num_tiles, int tiles_per_wg, int w, int glog2,
+    int rows_cap, int edge_cap, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sx = reinterpret_cast<float *>(smem);
+    // rows_cap*w*4 is kept a multiple of 16 by the launcher
+    int32_t *srp = reinterpret_cast<int32_t *>(sx + (size_t)rows_cap * w);
+    int32_t *scol = srp + ((rows_cap + 1 + 3) & ~3);
+
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t1 = min(t0 + tiles_per_wg, num_tiles);
+    const int nb = tile_first[t0];
+    const int ne = tile_first[t1];
+    const int rows = ne - nb;
+    if (rows <= 0)
+        return;
+    const int eb = row_ptr[nb];
+    const int nedges = row_ptr[ne] - eb;
+    const bool staged = rows <= rows_cap;   // workgroup-uniform
+    const bool ecached = nedges <= edge_cap; // workgroup-uniform
+
+    if (staged) {
+        // one pass over the tile's node rows: the only HBM read of x this launch makes
+        const size_t base = (size_t)nb * w;
+        const int total = rows * w;
+        if (VEC == 4) {
+            const float4 *src = reinterpret_cast<const float4 *>(x + base);
+            float4 *dst = reinterpret_cast<float4 *>(sx);
+            const int nv = total >> 2;
+            int i = tid;
+            // 4 independent 16-B loads in flight per lane
+            for (; i + 3 * WG < nv; i += 4 * WG) {
+                float4 a = src[i], b = src[i + WG], c = src[i + 2 * WG], d = src[i + 3 * WG];
+                dst[i] = a;
+                dst[i + WG] = b;
+                dst[i + 2 * WG] = c;
+                dst[i + 3 * WG] = d;
+            }
+            for (; i < nv; i += WG)
+                dst[i] = src[i];
+        } else {
+            for (int i = tid; i < total; i += WG)
+                sx[i] = x[base + i];
+        }
+        for (int i = tid; i <= rows; i += WG)
+            srp[i] = row_ptr[nb + i];
+    }
+    if (ecached)
+        for (int i = tid; i < nedges; i += WG)
+            scol[i] = col[eb + i];
+    __syncthreads();
+
+    const int nvec = w / VEC;
+    const int G = 1 << glog2;
+    const int groups = WG >> glog2;
+    const int grp = tid >> glog2;
+    const int gl = tid & (G - 1);
+    typedef Vf<VEC> V;
+
+    for (int r = grp; r < rows; r += groups) {
+        const int node = nb + r;
+        const int rp0 = staged ? srp[r] : row_ptr[node];
+        const int rp1 = staged ? srp[r + 1] : row_ptr[node + 1];
+        const int deg = rp1 - rp0;
+        for (int f = gl; f < nvec; f += G) {
+            const int fo = f * VEC;
+            const V xi = staged ? V::load(sx + (size_t)r * w + fo) : V::load(x + (size_t)node * w + fo);
+            V acc = V::splat(0.0f);
+            V vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f), q = V::splat(0.0f);
+            if (MODE == GNNB_AGG_PNA)
+                q = V::load(selfq + (size_t)node * w + fo);
+            const float di = 1.0f + (float)deg;
+            for (int k = rp0; k < rp1; k++) {
+                const int j = ecached ? scol[k - eb] : col[k];
+                const int jr = j - nb;
+                const V xj = staged ? V::load(sx + (size_t)jr * w + fo) : V::load(x + (size_t)j * w + fo);
+                if (MODE == GNNB_AGG_GCN) {
+                    const int dj_i = staged ? (srp[jr + 1] - srp[jr]) : (row_ptr[j + 1] - row_ptr[j]);
+                    const float dj = 1.0f + (float)dj_i;
+                    const float sc = 1.0f / sqrtf(di * dj);
+                    acc = vadd(acc, vmul(xj, V::splat(sc)));
+                } else if (MODE == GNNB_AGG_PNA) {
+                    const V h = vadd(q, xj);
+                    if (k == rp0) {
+                        vmx = h;
+                        vmn = h;
+                    } else {
+                        vmx = vmax(vmx, h);
+                        vmn = vmin(vmn, h);
+                    }
+                    acc = vadd(acc, h);
+                    s2 = vadd(s2, vmul(h, h));
+                } else {
+                    acc = vadd(acc, xj);
+                }
+            }
+            if (MODE == GNNB_AGG_GCN) {
+                const float sself = 1.0f / sqrtf(di * di);
+                acc = vadd(acc, vmul(xi, V::splat(sself)));
+                acc.store(out + (size_t)node * w + fo);
+            } else if (MODE == GNNB_AGG_SUM) {
+                acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
+                acc.store(out + (size_t)node * w + fo);
+            } else if (MODE == GNNB_AGG_MEAN) {
+                if (deg > 0)
+                    acc = vdiv(acc, V::splat((float)deg));
+                acc.store(out + (size_t)node * w + fo);
+            } else {
+                V mean = V::splat(0.0f), sd = V::splat(0.0f);
+                if (deg > 0) {
+                    const V dn = V::splat((float)deg);
+                    mean = vdiv(acc, dn);
+                    sd = pyg_std(vdiv(s2, dn), mean);
+                }
+                float *o = out + (size_t)node * 4 * w + fo;
+                vmx.store(o);
+                vmn.store(o + w);
+                mean.store(o + 2 * (size_t)w);
+                sd.store(o + 3 * (size_t)w);
+            }
+        }
+    }
+}
+
+template <int MODE, int VEC>
+static hipError_t launch_aggregate_t(const BatchTables &t, const float *x, const float *selfq,
+                                     float *out, int w, float eps, hipStream_t s)
+{
+    const Options &o = options();
+    const int nvec = w / VEC;
+    int glog2 = 2;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    const int tpw = o.agg_tiles_per_wg < 1 ? 1 : o.agg_tiles_per_wg;
+    // LDS budget -> staged rows; keep the float region a multiple of 16 bytes
+    size_t budget = (size_t)o.agg_lds_kb * 1024;
+    int rows_cap = (int)(budget / ((size_t)w * 4 + 24));
+    // a tile holds tile_rows nodes plus the tail of the graph that straddles its end
+    const int want = t.tile_rows * tpw + o.agg_overshoot;
+    if (rows_cap > want)
+        rows_cap = want;
+    rows_cap &= ~3;
+    if (rows_cap < 4)
+        rows_cap = 4;
+    const int edge_cap = rows_cap * 4;
+    const size_t lds = (size_t)rows_cap * w * 4 + (size_t)((rows_cap + 1 + 3) & ~3) * 4 + (size_t)edge_cap * 4;
+    auto kern = k_aggregate<MODE, VEC>;
+    static size_t lds_allowed = 64 * 1024; // per instantiation
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        lds_allowed = lds;
+    }
+    const int grid = (t.num_tiles + tpw - 1) / tpw;
+    if (grid <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), lds, s, x, selfq, out, t.row_ptr, t.col,
+                       t.tile_first, t.num_tiles, tpw, w, glog2, rows_cap, edge_cap, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
+                            float *out, int width, float eps, hipStream_t s)
+{
+    const bool v4 = (width % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0) &&
+                    (selfq == nullptr || ((uintptr_t)selfq & 15) == 0);
+#define GNNB_AGG_CASE(K)                                                                         \
+    case K:                                                                                      \
+        return v4 ? launch_aggregate_t<K, 4>(t, x, selfq, out, width, eps, s)                    \
+                  : launch_aggregate_t<K, 1>(t, x, selfq, out, width, eps, s);
+    switch (kind) {
+        GNNB_AGG_CASE(GNNB_AGG_GCN)
+        GNNB_AGG_CASE(GNNB_AGG_SUM)
+        GNNB_AGG_CASE(GNNB_AGG_MEAN)
+        GNNB_AGG_CASE(GNNB_AGG_PNA)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef GNNB_AGG_CASE
+}
+
+// =====================================================================================
+// dense update: multi-segment  Y = act( sum_s (rs_s . A_s) W_s^T + bias + skip )
+// =====================================================================================
+// Reference: `linear` applied to one node vector at a time (gnn_builder_lib.h:808-905) inside
+// every conv (gcn :1379, gin :1538-1544, sage, pna :2146-2147) and the MLP head
+// (templates/model.cpp.jinja:454-530).  Here all M rows of the batch go through one GEMM on
+// the fp32 matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation; gfx950
+// has no xf32).  Both operands are K-contiguous ("NT" GEMM: activations [M,K] row-major,
+// weights [N,K] row-major = torch Linear layout), so A and W tiles are staged identically:
+// 16-B global loads -> registers -> LDS rows padded to 36 floats (conflict-free
+// ds_read_b128).  One ds_read_b128 per operand feeds four MFMA k-steps: lane (i, h) holds
+// k = kb+4h..kb+4h+3, and MFMA step s contracts k in {kb+s, kb+4+s} -- a permutation of the
+// k order shared by A and W, which the sum does not care about.
+// Segments let SAGE ([mean | x] . [Wl | Wr]^T) and PNA ([x | A | amp.A | att.A] . Wpost^T, 13F
+// wide) run as ONE GEMM without materialising the concatenation in HBM: the per-row scaler is
+// applied while the A tile is staged.
+static constexpr int BM = 128;
+static constexpr int BK = 32;
+static constexpr int LDS_LD = BK + 4; // padded row, floats
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ inline float act_apply(float v, int act)
+{
+    switch (act) {
+    case GNNB_ACT_RELU:
+        return v > 0.0f ? v : 0.0f; // gnn_builder_lib.h:363-375
+    case GNNB_ACT_GELU:
+        return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); // nn.GELU (erf), lib:378-385
+    case GNNB_ACT_SIGMOID:
+        return 1.0f / (1.0f + expf(-v)); // lib:420-425
+    case GNNB_ACT_TANH:
+        return tanhf(v); // lib:436-448
+    default:
+        return v;
+    }
+}
+
+__device__ inline float4 load4_guard(const float *p, int remaining, bool vec)
+{
+    // `remaining` = number of valid floats at p (<= 0: none)
+    if (remaining <= 0)
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec && remaining >= 4)
+        return *reinterpret_cast<const float4 *>(p);
+    float4 r;
+    r.x = p[0];
+    r.y = remaining > 1 ? p[1] : 0.f;
+    r.z = remaining > 2 ? p[2] : 0.f;
+    r.w = remaining > 3 ? p[3] : 0.f;
+    return r;
+}
+
+template <int NT> // workgroup tile = 128 x (64*NT); wave tile = 64 x (32*NT)
+__global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restrict__ W, int ldw,
+                                               const float *__restrict__ bias,
+                                               const float *__restrict__ skip,
+                                               float *__restrict__ Y, int M, int N, int act)
+{
+    constexpr int BN = 64 * NT;
+    constexpr int BROWS = BN / 32; // W-tile staging passes per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *As = reinterpret_cast<float *>(smem);         // [2][BM*LDS_LD]
+    float *Bs = As + 2 * BM * LDS_LD;                    // [2][BN*LDS_LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const int c4 = tid & 7;  // which float4 of the 32-wide k chunk
+    const int r0 = tid >> 3; // 0..31
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                acc[mi][ni][i] = 0.0f;
+
+    float4 ra[4], rb[BROWS];
+    const int total = g.cpre[g.nseg];
+
+    auto load_chunk = [&](int c) {
+        // segment lookup with static indexing only (keeps the kernarg struct out of scratch)
+        const float *ap = g.a[0];
+        const float *rs = g.rs[0];
+        int lda = g.lda[0], ks = g.k[0], koff = g.koff[0], cbase = 0, av = g.avec[0], wv = g.wvec[0];
+#pragma unroll
+        for (int s = 1; s < 4; s++) {
+            if (s < g.nseg && c >= g.cpre[s]) {
+                ap = g.a[s];
+                rs = g.rs[s];
+                lda = g.lda[s];
+                ks = g.k[s];
+                koff = g.koff[s];
+                cbase = g.cpre[s];
+                av = g.avec[s];
+                wv = g.wvec[s];
+            }
+        }
+        const int kk = (c - cbase) * BK + c4 * 4;
+        const int rem = ks - kk;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int row = m0 + r0 + 32 * p;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M) {
+                v = load4_guard(ap + (size_t)row * lda + kk, rem, av != 0);
+                if (rs != nullptr) {
+                    const float sc = rs[row];
+                    v.x *= sc;
+                    v.y *= sc;
+                    v.z *= sc;
+                    v.w *= sc;
+                }
+            }
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < BROWS; p++) {
+            const int n = n0 + r0 + 32 * p;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < N)
+                v = load4_guard(W + (size_t)n * ldw + koff + kk, rem, wv != 0);
+            rb[p] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float *a = As + buf * BM * LDS_LD;
+        float *b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            *reinterpret_cast<float4 *>(a + (r0 + 32 * p) * LDS_LD + c4 * 4) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BROWS; p++)
+            *reinterpret_cast<float4 *>(b + (r0 + 32 * p) * LDS_LD + c4 * 4) = rb[p];
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    for (int c = 0; c < total; c++) {
+        const int buf = c & 1;
+        if (c + 1 < total)
+            load_chunk(c + 1); // global loads stay in flight under the MFMAs below
+        const float *a = As + buf * BM * LDS_LD + (wm * 64 + li) * LDS_LD + 4 * lh;
+        const float *b = Bs + buf * BN * LDS_LD + (wn * 32 * NT + li) * LDS_LD + 4 * lh;
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 8) {
+            float4 fa[2], fb[NT];
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+                fa[mi] = *reinterpret_cast<const float4 *>(a + mi * 32 * LDS_LD + kb);
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++)
+                fb[ni] = *reinterpret_cast<const float4 *>(b + ni * 32 * LDS_LD + kb);
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NT; ni++) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].x, fb[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].y, fb[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].z, fb[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+        if (c + 1 < total)
+            store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++) {
+            const int colg = n0 + wn * 32 * NT + ni * 32 + li;
+            if (colg >= N)
+                continue;
+            const float bv = bias ? bias[colg] : 0.0f;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int rowg = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (rowg < M) {
+                    float v = acc[mi][ni][reg] + bv;
+                    if (skip)
+                        v += skip[(size_t)rowg * N + colg];
+                    Y[(size_t)rowg * N + colg] = act_apply(v, act);
+                }
+            }
+        }
+}
+
+hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
+                         const float *skip, float *y, int M, int N, int act, hipStream_t s)
+{
+    if (M <= 0 || N <= 0)
+        return hipSuccess;
+    const int gm = (M + BM - 1) / BM;
+    if (N > 64) {
+        constexpr int NT = 2;
+        const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * 64 * NT * LDS_LD) * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear<NT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess)
+                return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_linear<NT>, dim3(gm, (N + 127) / 128), dim3(WG), lds, s, g, w, ldw,
+                           bias, skip, y, M, N, act);
+    } else {
+        constexpr int NT = 1;
+        const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * 64 * NT * LDS_LD) * 4;
+        hipLaunchKernelGGL(k_linear<NT>, dim3(gm, 1), dim3(WG), lds, s, g, w, ldw, bias, skip, y, M,
+                           N, act);
+    }
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// global pooling
+// =====================================================================================
+// Reference: global_add_pool / global_mean_pool / global_max_pool
+// (gnn_builder_lib.h:2709-2739, :2741-2771, :2773-2803) concatenated in `aggrs` order
+// (templates/model.cpp.jinja:440-448; gnnbuilder/models.py:348-352).  One lane group
+// (d/4 lanes, float4 each) owns one graph and walks its node rows in order, so the sum
+// order equals the reference's; all requested reductions come from a single read of x.
+template <int VEC>
+__global__ __launch_bounds__(WG) void k_global_pool(const float *__restrict__ x,
+                                                    const int32_t *__restrict__ node_ptr, int B,
+                                                    int d, int glog2, int p0, int p1, int p2,
+                                                    int np, float *__restrict__ out)
+{
+    typedef Vf<VEC> V;
+    const int G = 1 << glog2;
+    const int grp = threadIdx.x >> glog2;
+    const int gl = threadIdx.x & (G - 1);
+    const int g = blockIdx.x * (WG >> glog2) + grp;
+    if (g >= B)
+        return;
+    const int n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int nvec = d / VEC;
+    const int pools[3] = {p0, p1, p2};
+    for (int f = gl; f < nvec; f += G) {
+        const int fo = f * VEC;
+        V sum = V::splat(0.0f), mx = V::splat(0.0f);
+        int i = n0;
+        if (i < n1) {
+            const V v = V::load(x + (size_t)i * d + fo);
+            sum = v;
+            mx = v;
+            i++;
+        }
+        for (; i + 3 < n1; i += 4) {
+            const V a = V::load(x + (size_t)i * d + fo);
+            const V b = V::load(x + (size_t)(i + 1) * d + fo);
+            const V c = V::load(x + (size_t)(i + 2) * d + fo);
+            const V e = V::load(x + (size_t)(i + 3) * d + fo);
+            sum = vadd(vadd(vadd(vadd(sum, a), b), c), e);
+            mx = vmax(vmax(mx, a), vmax(b, vmax(c, e)));
+        }
+        for (; i < n1; i++) {
+            const V v = V::load(x + (size_t)i * d + fo);
+            sum = vadd(sum, v);
+            mx = vmax(mx, v);
+        }
+        const int n = n1 - n0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (k >= np)
+                break;
+            V r = sum;
+            if (pools[k] == GNNB_POOL_MEAN)
+                r = n > 0 ? vdiv(sum, V::splat((float)n)) : V::splat(0.0f);
+            else if (pools[k] == GNNB_POOL_MAX)
+                r = mx;
+            r.store(out + (size_t)g * np * d + (size_t)k * d + fo);
+        }
+    }
+}
+
+hipError_t launch_global_pool(const float *x, const int32_t *node_ptr, int num_graphs, int d,
+                              const int32_t *pools, int num_pools, float *out, hipStream_t s)
+{
+    if (num_graphs <= 0)
+        return hipSuccess;
+    const bool v4 = (d % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    const int nvec = v4 ? d / 4 : d;
+    int glog2 = 2;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    const int per_wg = WG >> glog2;
+    const int grid = (num_graphs + per_wg - 1) / per_wg;
+    const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
+    if (v4)
+        hipLaunchKernelGGL(k_global_pool<4>, dim3(grid), dim3(WG), 0, s, x, node_ptr, num_graphs, d,
+                           glog2, p0, p1, p2, num_pools, out);
+    else
+        hipLaunchKernelGGL(k_global_pool<1>, dim3(grid), dim3(WG), 0, s, x, node_ptr, num_graphs, d,
+                           glog2, p0, p1, p2, num_pools, out);
+    return hipGetLastError();
+}
+
+} // namespace gnnb

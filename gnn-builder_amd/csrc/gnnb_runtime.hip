@@ -1,0 +1,756 @@
+// gnnb_runtime.hip -- host side of libgnnb_hip.so: model / workspace handles, the batched
+// forward that sequences the kernels of gnnb_kernels.hip on one HIP stream, and the C ABI
+// declared in include/gnnb_hip.h.
+//
+// Sequencing follows the reference's generated top (gnnbuilder/templates/model.cpp.jinja):
+//   load_parameters once (:724-730)            -> gnnb_model_create (device-resident weights)
+//   compute_degree/neighbor_tables (:737-758)  -> k_graph_prep, once per batch, shared by all layers
+//   compute_gnn_head (:151-359)                -> per layer: k_aggregate + k_linear (+skip +act fused)
+//   compute_global_graph_pooling (:413-449)    -> k_global_pool
+//   compute_mlp_head (:454-530)                -> k_linear chain
+// There is no CPU fallback: every entry point fails with GNNB_ERR_NO_DEVICE / GNNB_ERR_HIP when
+// the GPU path cannot run.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gnnb_internal.h"
+
+namespace gnnb {
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define GNNB_HIP_TRY(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(GNNB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                        __FILE__, __LINE__);                                                      \
+    } while (0)
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+Options &options()
+{
+    static Options o = {env_int("GNNB_TILE_ROWS", 32), env_int("GNNB_AGG_LDS_KB", 48),
+                        env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32)};
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------
+struct LayerDims {
+    int fin, fout;
+};
+
+static int conv_slots(int conv)
+{
+    switch (conv) {
+    case GNNB_CONV_GCN: return 2;
+    case GNNB_CONV_GIN: return 4;
+    case GNNB_CONV_SAGE: return 3;
+    case GNNB_CONV_PNA: return 6;
+    default: return -1;
+    }
+}
+
+// gnnbuilder/models.py:519-549
+static LayerDims layer_dims(const gnnb_model_desc &d, int l)
+{
+    if (d.num_layers == 1)
+        return {d.in_dim, d.out_dim};
+    if (l == 0)
+        return {d.in_dim, d.hidden_dim};
+    if (l == d.num_layers - 1)
+        return {d.hidden_dim, d.out_dim};
+    return {d.hidden_dim, d.hidden_dim};
+}
+
+static int gnn_out_width(const gnnb_model_desc &d) { return d.num_layers == 0 ? d.in_dim : d.out_dim; }
+
+// gnnbuilder/models.py:398-415
+static void mlp_dims(const gnnb_model_desc &d, int i, int *din, int *dout)
+{
+    const int pooled = d.num_pools * gnn_out_width(d);
+    *din = (i == 0) ? pooled : d.mlp_hidden;
+    *dout = (i == d.mlp_num_linear - 1) ? d.mlp_out : d.mlp_hidden;
+}
+
+static int validate_desc(const gnnb_model_desc *d)
+{
+    if (!d)
+        return fail(GNNB_ERR_INVALID, "null model description");
+    if (conv_slots(d->conv_type) < 0)
+        return fail(GNNB_ERR_INVALID, "unsupported conv_type %d", d->conv_type);
+    if (d->num_layers < 0 || d->num_layers > GNNB_MAX_LAYERS)
+        return fail(GNNB_ERR_INVALID, "num_layers %d out of range", d->num_layers);
+    if (d->in_dim < 1 || d->out_dim < 1 || (d->num_layers > 1 && d->hidden_dim < 1))
+        return fail(GNNB_ERR_INVALID, "feature dims must be positive");
+    if (d->num_layers == 0 && d->in_dim != d->out_dim) // models.py:512-518
+        return fail(GNNB_ERR_INVALID, "gnn_num_layers=0 needs gnn_output_dim == graph_input_feature_dim");
+    if (d->activation < 0 || d->activation > GNNB_ACT_TANH || d->mlp_activation < 0 ||
+        d->mlp_activation > GNNB_ACT_TANH)
+        return fail(GNNB_ERR_INVALID, "unsupported activation"); // models.py:362
+    if (d->num_pools < 1 || d->num_pools > 3)
+        return fail(GNNB_ERR_INVALID, "num_pools must be 1..3"); // models.py:332-333
+    for (int i = 0; i < d->num_pools; i++)
+        if (d->pools[i] < 0 || d->pools[i] > GNNB_POOL_MAX)
+            return fail(GNNB_ERR_INVALID, "unsupported pooling %d", d->pools[i]);
+    if (d->mlp_num_linear < 1 || d->mlp_num_linear > GNNB_MAX_LAYERS || d->mlp_out < 1 ||
+        (d->mlp_num_linear > 1 && d->mlp_hidden < 1))
+        return fail(GNNB_ERR_INVALID, "bad MLP head shape");
+    if (d->conv_type == GNNB_CONV_PNA && !(d->pna_delta > 0.0f))
+        return fail(GNNB_ERR_INVALID, "pna_delta must be > 0");
+    return GNNB_OK;
+}
+
+} // namespace gnnb
+
+using namespace gnnb;
+
+struct gnnb_model {
+    gnnb_model_desc desc;
+    float *blob = nullptr; // all weights, device
+    size_t blob_floats = 0;
+    // per conv layer device pointers (canonical slots; SAGE slot 0 is the fused [Wl|Wr])
+    std::vector<std::vector<const float *>> conv;
+    std::vector<const float *> head_w, head_b;
+    int device = 0;
+};
+
+struct gnnb_workspace {
+    gnnb_model_desc desc;
+    int max_graphs = 0, max_nodes = 0, max_edges = 0;
+    char *blob = nullptr;
+    size_t bytes = 0;
+    BatchTables t{};
+    float *act[2] = {nullptr, nullptr}; // ping-pong node embeddings [max_nodes, maxw]
+    float *agg = nullptr;               // aggregate output [max_nodes, aggw]
+    float *tmp0 = nullptr, *tmp1 = nullptr; // GIN hidden / PNA p,q
+    float *pooled = nullptr;            // [max_graphs, np*d]
+    float *mlp[2] = {nullptr, nullptr}; // [max_graphs, max(mlp_hidden, mlp_out)]
+    bool prepared = false;
+    int device = 0;
+};
+
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int gnnb_version(void) { return GNNB_VERSION; }
+
+const char *gnnb_last_error(void) { return g_last_error.c_str(); }
+
+int gnnb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int gnnb_stream_sync(void *stream)
+{
+    GNNB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GNNB_OK;
+}
+
+int gnnb_set_option(const char *name, int value)
+{
+    Options &o = options();
+    if (!name)
+        return fail(GNNB_ERR_INVALID, "null option name");
+    if (!strcmp(name, "tile_rows") && value >= 4)
+        o.tile_rows = value;
+    else if (!strcmp(name, "agg_lds_kb") && value >= 4 && value <= 160)
+        o.agg_lds_kb = value;
+    else if (!strcmp(name, "agg_tiles_per_wg") && value >= 1)
+        o.agg_tiles_per_wg = value;
+    else if (!strcmp(name, "agg_overshoot") && value >= 0)
+        o.agg_overshoot = value;
+    else
+        return fail(GNNB_ERR_INVALID, "unknown option or bad value: %s=%d", name, value);
+    return GNNB_OK;
+}
+
+int gnnb_model_num_params(const gnnb_model_desc *desc)
+{
+    int rc = validate_desc(desc);
+    if (rc != GNNB_OK)
+        return rc;
+    return conv_slots(desc->conv_type) * desc->num_layers + 2 * desc->mlp_num_linear;
+}
+
+int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_params, int num_params,
+                      gnnb_model **out_model)
+{
+    if (!out_model)
+        return fail(GNNB_ERR_INVALID, "null out_model");
+    *out_model = nullptr;
+    int expect = gnnb_model_num_params(desc);
+    if (expect < 0)
+        return expect;
+    if (num_params != expect || !host_params)
+        return fail(GNNB_ERR_INVALID, "expected %d parameter tensors, got %d", expect, num_params);
+    for (int i = 0; i < num_params; i++)
+        if (!host_params[i])
+            return fail(GNNB_ERR_INVALID, "parameter %d is NULL", i);
+    if (gnnb_device_count() <= 0)
+        return fail(GNNB_ERR_NO_DEVICE, "no HIP device visible: the MI355X path cannot run");
+
+    const gnnb_model_desc &d = *desc;
+    // host staging image: every tensor padded to a 16-byte boundary
+    std::vector<float> img;
+    auto push = [&](const float *src, size_t n) -> size_t {
+        size_t off = img.size();
+        img.insert(img.end(), src, src + n);
+        while (img.size() % 4)
+            img.push_back(0.0f);
+        return off;
+    };
+    std::vector<std::vector<size_t>> conv_off(d.num_layers);
+    std::vector<size_t> hw, hb;
+    const int slots = conv_slots(d.conv_type);
+    int pi = 0;
+    for (int l = 0; l < d.num_layers; l++) {
+        const LayerDims ld = layer_dims(d, l);
+        const size_t fi = ld.fin, fo = ld.fout;
+        const float *const *p = host_params + pi;
+        switch (d.conv_type) {
+        case GNNB_CONV_GCN:
+            conv_off[l] = {push(p[0], fo * fi), push(p[1], fo)};
+            break;
+        case GNNB_CONV_GIN: // hidden = out_channels (models.py:90)
+            conv_off[l] = {push(p[0], fo * fi), push(p[1], fo), push(p[2], fo * fo), push(p[3], fo)};
+            break;
+        case GNNB_CONV_SAGE: {
+            // fuse lin_l and lin_r into one [out, 2*in] matrix: [Wl | Wr]
+            std::vector<float> cat(fo * 2 * fi);
+            for (size_t o = 0; o < fo; o++) {
+                memcpy(&cat[o * 2 * fi], p[0] + o * fi, fi * sizeof(float));
+                memcpy(&cat[o * 2 * fi + fi], p[2] + o * fi, fi * sizeof(float));
+            }
+            conv_off[l] = {push(cat.data(), cat.size()), push(p[1], fo)};
+            break;
+        }
+        case GNNB_CONV_PNA:
+            conv_off[l] = {push(p[0], fi * 2 * fi), push(p[1], fi), push(p[2], fo * 13 * fi),
+                           push(p[3], fo),          push(p[4], fo * fo), push(p[5], fo)};
+            break;
+        }
+        pi += slots;
+    }
+    for (int i = 0; i < d.mlp_num_linear; i++) {
+        int din, dout;
+        mlp_dims(d, i, &din, &dout);
+        hw.push_back(push(host_params[pi], (size_t)din * dout));
+        hb.push_back(push(host_params[pi + 1], (size_t)dout));
+        pi += 2;
+    }
+
+    gnnb_model *m = new gnnb_model();
+    m->desc = d;
+    (void)hipGetDevice(&m->device);
+    m->blob_floats = img.size();
+    hipError_t e = hipMalloc((void **)&m->blob, std::max<size_t>(img.size(), 4) * sizeof(float));
+    if (e == hipSuccess && !img.empty())
+        e = hipMemcpy(m->blob, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (m->blob)
+            (void)hipFree(m->blob);
+        delete m;
+        return fail(GNNB_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
+    }
+    m->conv.resize(d.num_layers);
+    for (int l = 0; l < d.num_layers; l++)
+        for (size_t off : conv_off[l])
+            m->conv[l].push_back(m->blob + off);
+    for (int i = 0; i < d.mlp_num_linear; i++) {
+        m->head_w.push_back(m->blob + hw[i]);
+        m->head_b.push_back(m->blob + hb[i]);
+    }
+    *out_model = m;
+    return GNNB_OK;
+}
+
+void gnnb_model_destroy(gnnb_model *model)
+{
+    if (!model)
+        return;
+    if (model->blob)
+        (void)hipFree(model->blob);
+    delete model;
+}
+
+int gnnb_model_get_desc(const gnnb_model *model, gnnb_model_desc *out_desc)
+{
+    if (!model || !out_desc)
+        return fail(GNNB_ERR_INVALID, "null argument");
+    *out_desc = model->desc;
+    return GNNB_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes, int max_edges,
+                          gnnb_workspace **out_ws)
+{
+    if (!out_ws)
+        return fail(GNNB_ERR_INVALID, "null out_ws");
+    *out_ws = nullptr;
+    if (!model)
+        return fail(GNNB_ERR_INVALID, "null model");
+    if (max_graphs < 1 || max_nodes < 1 || max_edges < 0)
+        return fail(GNNB_ERR_INVALID, "workspace capacities must be positive");
+    const gnnb_model_desc &d = model->desc;
+
+    int maxw = d.in_dim, aggw = 4, tmpw = 4;
+    for (int l = 0; l < d.num_layers; l++) {
+        const LayerDims ld = layer_dims(d, l);
+        maxw = std::max(maxw, std::max(ld.fin, ld.fout));
+        aggw = std::max(aggw, d.conv_type == GNNB_CONV_PNA ? 4 * ld.fin : ld.fin);
+    }
+    tmpw = std::max(tmpw, maxw);
+    const int pooledw = d.num_pools * gnn_out_width(d);
+    const int mlpw = std::max(d.mlp_hidden, d.mlp_out);
+    const int min_tile_rows = 4;
+    const size_t max_tiles = (size_t)max_nodes / min_tile_rows + 2;
+
+    gnnb_workspace *ws = new gnnb_workspace();
+    ws->desc = d;
+    ws->max_graphs = max_graphs;
+    ws->max_nodes = max_nodes;
+    ws->max_edges = max_edges;
+    (void)hipGetDevice(&ws->device);
+
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t N = max_nodes, E = std::max(max_edges, 1), B = max_graphs;
+    const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_amp = carve(N * 4),
+                 o_att = carve(N * 4), o_tile = carve((max_tiles + 1) * 4), o_err = carve(4),
+                 o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
+                 o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
+                 o_pool = carve(B * pooledw * 4), o_m0 = carve(B * mlpw * 4),
+                 o_m1 = carve(B * mlpw * 4);
+    ws->bytes = off;
+    hipError_t e = hipMalloc((void **)&ws->blob, ws->bytes);
+    if (e != hipSuccess) {
+        delete ws;
+        return fail(GNNB_ERR_HIP, "workspace allocation of %zu bytes failed: %s", off,
+                    hipGetErrorString(e));
+    }
+    char *b = ws->blob;
+    ws->t.row_ptr = (int32_t *)(b + o_rp);
+    ws->t.col = (int32_t *)(b + o_col);
+    ws->t.amp = (float *)(b + o_amp);
+    ws->t.att = (float *)(b + o_att);
+    ws->t.tile_first = (int32_t *)(b + o_tile);
+    ws->t.err = (int32_t *)(b + o_err);
+    ws->act[0] = (float *)(b + o_a0);
+    ws->act[1] = (float *)(b + o_a1);
+    ws->agg = (float *)(b + o_agg);
+    ws->tmp0 = (float *)(b + o_t0);
+    ws->tmp1 = (float *)(b + o_t1);
+    ws->pooled = (float *)(b + o_pool);
+    ws->mlp[0] = (float *)(b + o_m0);
+    ws->mlp[1] = (float *)(b + o_m1);
+    *out_ws = ws;
+    return GNNB_OK;
+}
+
+void gnnb_workspace_destroy(gnnb_workspace *ws)
+{
+    if (!ws)
+        return;
+    if (ws->blob)
+        (void)hipFree(ws->blob);
+    delete ws;
+}
+
+size_t gnnb_workspace_bytes(const gnnb_workspace *ws) { return ws ? ws->bytes : 0; }
+
+// ---------------------------------------------------------------------------------------
+int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *node_ptr_dev,
+                    const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges,
+                    float pna_delta, void *stream)
+{
+    if (!ws || !node_ptr_dev || !edge_ptr_dev || (num_edges > 0 && !coo_dev))
+        return fail(GNNB_ERR_INVALID, "null argument to gnnb_graph_prep");
+    if (num_graphs < 0 || num_nodes < 0 || num_edges < 0)
+        return fail(GNNB_ERR_INVALID, "negative batch size");
+    if (num_graphs > ws->max_graphs || num_nodes > ws->max_nodes || num_edges > ws->max_edges)
+        return fail(GNNB_ERR_CAPACITY,
+                    "batch (%d graphs, %d nodes, %d edges) exceeds workspace (%d, %d, %d)",
+                    num_graphs, num_nodes, num_edges, ws->max_graphs, ws->max_nodes, ws->max_edges);
+    BatchTables &t = ws->t;
+    t.node_ptr = node_ptr_dev;
+    t.num_graphs = num_graphs;
+    t.num_nodes = num_nodes;
+    t.num_edges = num_edges;
+    t.tile_rows = std::max(options().tile_rows, 4);
+    t.num_tiles = (num_nodes + t.tile_rows - 1) / t.tile_rows;
+    if (!(pna_delta > 0.0f))
+        pna_delta = 1.0f;
+    GNNB_HIP_TRY(launch_graph_prep(coo_dev, node_ptr_dev, edge_ptr_dev, t, pna_delta,
+                                   (hipStream_t)stream));
+    ws->prepared = true;
+    return GNNB_OK;
+}
+
+int gnnb_workspace_check(gnnb_workspace *ws, void *stream)
+{
+    if (!ws || !ws->prepared)
+        return fail(GNNB_ERR_INVALID, "workspace has no prepared batch");
+    int32_t err = 0;
+    GNNB_HIP_TRY(hipMemcpyAsync(&err, ws->t.err, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GNNB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (err != 0)
+        return fail(GNNB_ERR_GRAPH, "malformed batch (flags 0x%x): ptr arrays not monotone/complete, "
+                                    "or an edge leaves its graph", err);
+    return GNNB_OK;
+}
+
+int gnnb_graph_tables_to_host(gnnb_workspace *ws, int32_t *row_ptr, int32_t *col, int32_t *in_deg,
+                              void *stream)
+{
+    if (!ws || !ws->prepared)
+        return fail(GNNB_ERR_INVALID, "workspace has no prepared batch");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = ws->t.num_nodes, E = ws->t.num_edges;
+    std::vector<int32_t> rp((size_t)N + 1);
+    GNNB_HIP_TRY(hipMemcpyAsync(rp.data(), ws->t.row_ptr, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (col && E > 0)
+        GNNB_HIP_TRY(hipMemcpyAsync(col, ws->t.col, (size_t)E * 4, hipMemcpyDeviceToHost, s));
+    GNNB_HIP_TRY(hipStreamSynchronize(s));
+    if (row_ptr)
+        memcpy(row_ptr, rp.data(), ((size_t)N + 1) * 4);
+    if (in_deg)
+        for (int i = 0; i < N; i++)
+            in_deg[i] = rp[i + 1] - rp[i];
+    return GNNB_OK;
+}
+
+int gnnb_aggregate(gnnb_workspace *ws, int agg_kind, const float *x_dev, const float *self_dev,
+                   float *out_dev, int width, float eps, void *stream)
+{
+    if (!ws || !ws->prepared)
+        return fail(GNNB_ERR_INVALID, "gnnb_aggregate needs a prepared batch (gnnb_graph_prep)");
+    if (!x_dev || !out_dev || width < 1)
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_aggregate");
+    if (agg_kind < GNNB_AGG_GCN || agg_kind > GNNB_AGG_PNA)
+        return fail(GNNB_ERR_INVALID, "unknown aggregate kind %d", agg_kind);
+    if (agg_kind == GNNB_AGG_PNA && !self_dev)
+        return fail(GNNB_ERR_INVALID, "PNA aggregate needs the per-destination term");
+    if (ws->t.num_nodes == 0)
+        return GNNB_OK;
+    GNNB_HIP_TRY(launch_aggregate(ws->t, agg_kind, x_dev, self_dev, out_dev, width, eps,
+                                  (hipStream_t)stream));
+    return GNNB_OK;
+}
+
+static int build_gemm(GemmArgs &g, const gnnb_gemm_seg *segs, int num_segs, const float *w, int ldw)
+{
+    if (num_segs < 1 || num_segs > 4 || !segs)
+        return fail(GNNB_ERR_INVALID, "gnnb_linear takes 1..4 segments");
+    memset(&g, 0, sizeof(g));
+    g.nseg = num_segs;
+    int koff = 0;
+    g.cpre[0] = 0;
+    for (int s = 0; s < 4; s++) {
+        if (s < num_segs) {
+            if (!segs[s].a_dev || segs[s].k < 1 || segs[s].lda < segs[s].k)
+                return fail(GNNB_ERR_INVALID, "bad GEMM segment %d", s);
+            g.a[s] = segs[s].a_dev;
+            g.rs[s] = segs[s].rowscale_dev;
+            g.lda[s] = segs[s].lda;
+            g.k[s] = segs[s].k;
+            g.koff[s] = koff;
+            g.avec[s] = (segs[s].k % 4 == 0) && (segs[s].lda % 4 == 0) && (((uintptr_t)segs[s].a_dev & 15) == 0);
+            g.wvec[s] = (segs[s].k % 4 == 0) && (ldw % 4 == 0) && (koff % 4 == 0) && (((uintptr_t)w & 15) == 0);
+            g.cpre[s + 1] = g.cpre[s] + (segs[s].k + 31) / 32;
+            koff += segs[s].k;
+        } else {
+            g.cpre[s + 1] = g.cpre[s];
+        }
+    }
+    if (koff > ldw)
+        return fail(GNNB_ERR_INVALID, "segments span %d columns but ldw = %d", koff, ldw);
+    return GNNB_OK;
+}
+
+int gnnb_linear(const gnnb_gemm_seg *segs, int num_segs, const float *w_dev, int ldw,
+                const float *bias_dev, const float *skip_dev, float *y_dev, int M, int N, int act,
+                void *stream)
+{
+    if (!w_dev || !y_dev || M < 0 || N < 1)
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_linear");
+    if (act < 0 || act > GNNB_ACT_NONE)
+        return fail(GNNB_ERR_INVALID, "unknown activation %d", act);
+    GemmArgs g;
+    int rc = build_gemm(g, segs, num_segs, w_dev, ldw);
+    if (rc != GNNB_OK)
+        return rc;
+    GNNB_HIP_TRY(launch_linear(g, w_dev, ldw, bias_dev, skip_dev, y_dev, M, N, act, (hipStream_t)stream));
+    return GNNB_OK;
+}
+
+int gnnb_global_pool(gnnb_workspace *ws, const float *x_dev, int d, const int32_t *pools,
+                     int num_pools, float *out_dev, void *stream)
+{
+    if (!ws || !ws->prepared)
+        return fail(GNNB_ERR_INVALID, "gnnb_global_pool needs a prepared batch");
+    if (!x_dev || !out_dev || !pools || d < 1 || num_pools < 1 || num_pools > 3)
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_global_pool");
+    for (int i = 0; i < num_pools; i++)
+        if (pools[i] < 0 || pools[i] > GNNB_POOL_MAX)
+            return fail(GNNB_ERR_INVALID, "unsupported pooling %d", pools[i]);
+    GNNB_HIP_TRY(launch_global_pool(x_dev, ws->t.node_ptr, ws->t.num_graphs, d, pools, num_pools,
+                                    out_dev, (hipStream_t)stream));
+    return GNNB_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+static int linear1(const float *a, int lda, int k, const float *w, int ldw, const float *bias,
+                   const float *skip, float *y, int M, int N, int act, void *stream)
+{
+    gnnb_gemm_seg seg = {a, nullptr, lda, k};
+    return gnnb_linear(&seg, 1, w, ldw, bias, skip, y, M, N, act, stream);
+}
+
+int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev,
+                          float *out_dev, void *stream)
+{
+    if (!model || !ws || !x_dev || !out_dev)
+        return fail(GNNB_ERR_INVALID, "null argument to gnnb_forward");
+    if (!ws->prepared)
+        return fail(GNNB_ERR_INVALID, "workspace has no prepared batch");
+    if (memcmp(&model->desc, &ws->desc, sizeof(gnnb_model_desc)) != 0)
+        return fail(GNNB_ERR_INVALID, "workspace was created for a different model");
+    const gnnb_model_desc &d = model->desc;
+    const int N = ws->t.num_nodes, B = ws->t.num_graphs;
+    int rc;
+
+    const float *cur = x_dev;
+    int which = 0;
+    for (int l = 0; l < d.num_layers; l++) {
+        const LayerDims ld = layer_dims(d, l);
+        const int fi = ld.fin, fo = ld.fout;
+        const std::vector<const float *> &p = model->conv[l];
+        // skip connection on middle layers only (models.py:562-564); fused into the GEMM epilogue
+        const float *skip = (d.skip && l != 0 && l != d.num_layers - 1) ? cur : nullptr;
+        float *nxt = ws->act[which];
+        if ((const float *)nxt == cur) { // never write the buffer being read
+            which ^= 1;
+            nxt = ws->act[which];
+        }
+        switch (d.conv_type) {
+        case GNNB_CONV_GCN:
+            // aggregate at the input width, then transform (the reference's order, lib:1346-1379)
+            if ((rc = gnnb_aggregate(ws, GNNB_AGG_GCN, cur, nullptr, ws->agg, fi, 0.f, stream)))
+                return rc;
+            if ((rc = linear1(ws->agg, fi, fi, p[0], fi, p[1], skip, nxt, N, fo, d.activation, stream)))
+                return rc;
+            break;
+        case GNNB_CONV_GIN:
+            if ((rc = gnnb_aggregate(ws, GNNB_AGG_SUM, cur, nullptr, ws->agg, fi, d.gin_eps, stream)))
+                return rc;
+            if ((rc = linear1(ws->agg, fi, fi, p[0], fi, p[1], nullptr, ws->tmp0, N, fo, GNNB_ACT_RELU, stream)))
+                return rc;
+            if ((rc = linear1(ws->tmp0, fo, fo, p[2], fo, p[3], skip, nxt, N, fo, d.activation, stream)))
+                return rc;
+            break;
+        case GNNB_CONV_SAGE: {
+            if ((rc = gnnb_aggregate(ws, GNNB_AGG_MEAN, cur, nullptr, ws->agg, fi, 0.f, stream)))
+                return rc;
+            gnnb_gemm_seg segs[2] = {{ws->agg, nullptr, fi, fi}, {cur, nullptr, fi, fi}};
+            if ((rc = gnnb_linear(segs, 2, p[0], 2 * fi, p[1], skip, nxt, N, fo, d.activation, stream)))
+                return rc;
+            break;
+        }
+        case GNNB_CONV_PNA: {
+            // h_ij = Wpre [x_i || x_j] + b  ==  (Wpre[:, :F] x_i + b) + Wpre[:, F:] x_j
+            float *q = ws->tmp0, *pp = ws->tmp1;
+            if ((rc = linear1(cur, fi, fi, p[0], 2 * fi, p[1], nullptr, q, N, fi, GNNB_ACT_NONE, stream)))
+                return rc;
+            if ((rc = linear1(cur, fi, fi, p[0] + fi, 2 * fi, nullptr, nullptr, pp, N, fi, GNNB_ACT_NONE, stream)))
+                return rc;
+            if ((rc = gnnb_aggregate(ws, GNNB_AGG_PNA, pp, q, ws->agg, fi, 0.f, stream)))
+                return rc;
+            // [x | A | amp.A | att.A] . Wpost^T without materialising the 13F concat
+            gnnb_gemm_seg segs[4] = {{cur, nullptr, fi, fi},
+                                     {ws->agg, nullptr, 4 * fi, 4 * fi},
+                                     {ws->agg, ws->t.amp, 4 * fi, 4 * fi},
+                                     {ws->agg, ws->t.att, 4 * fi, 4 * fi}};
+            float *hid = ws->tmp0; // q is dead after the aggregate
+            if ((rc = gnnb_linear(segs, 4, p[2], 13 * fi, p[3], nullptr, hid, N, fo, GNNB_ACT_NONE, stream)))
+                return rc;
+            if ((rc = linear1(hid, fo, fo, p[4], fo, p[5], skip, nxt, N, fo, d.activation, stream)))
+                return rc;
+            break;
+        }
+        }
+        cur = nxt;
+        which ^= 1;
+    }
+
+    const int gw = gnn_out_width(d);
+    if ((rc = gnnb_global_pool(ws, cur, gw, d.pools, d.num_pools, ws->pooled, stream)))
+        return rc;
+
+    const float *h = ws->pooled;
+    for (int i = 0; i < d.mlp_num_linear; i++) {
+        int din, dout;
+        mlp_dims(d, i, &din, &dout);
+        const bool last = (i == d.mlp_num_linear - 1);
+        float *y = last ? out_dev : ws->mlp[i & 1];
+        if ((rc = linear1(h, din, din, model->head_w[i], din, model->head_b[i], nullptr, y, B, dout,
+                          last ? GNNB_ACT_NONE : d.mlp_activation, stream)))
+            return rc;
+        h = y;
+    }
+    return GNNB_OK;
+}
+
+int gnnb_forward_batched(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev,
+                         const int32_t *coo_dev, const int32_t *node_ptr_dev,
+                         const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges,
+                         float *out_dev, void *stream)
+{
+    if (!model || !ws)
+        return fail(GNNB_ERR_INVALID, "null argument to gnnb_forward_batched");
+    int rc = gnnb_graph_prep(ws, coo_dev, node_ptr_dev, edge_ptr_dev, num_graphs, num_nodes,
+                             num_edges, model->desc.pna_delta, stream);
+    if (rc != GNNB_OK)
+        return rc;
+    return gnnb_forward_prepared(model, ws, x_dev, out_dev, stream);
+}
+
+int gnnb_forward_batched_host(const gnnb_model *model, gnnb_workspace *ws, const float *x,
+                              const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
+                              int num_graphs, int num_nodes, int num_edges, float *out)
+{
+    if (!model || !ws || !x || !node_ptr || !edge_ptr || !out || (num_edges > 0 && !coo))
+        return fail(GNNB_ERR_INVALID, "null argument to gnnb_forward_batched_host");
+    if (num_graphs > ws->max_graphs || num_nodes > ws->max_nodes || num_edges > ws->max_edges)
+        return fail(GNNB_ERR_CAPACITY,
+                    "batch (%d graphs, %d nodes, %d edges) exceeds workspace (%d, %d, %d)",
+                    num_graphs, num_nodes, num_edges, ws->max_graphs, ws->max_nodes, ws->max_edges);
+    const gnnb_model_desc &d = model->desc;
+    const size_t bx = (size_t)num_nodes * d.in_dim * 4, bc = (size_t)num_edges * 8,
+                 bp = ((size_t)num_graphs + 1) * 4, bo = (size_t)num_graphs * d.mlp_out * 4;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    char *dev = nullptr;
+    GNNB_HIP_TRY(hipMalloc((void **)&dev, up(bx) + up(bc) + 2 * up(bp) + up(bo) + 256));
+    float *dx = (float *)dev;
+    int32_t *dc = (int32_t *)(dev + up(bx));
+    int32_t *dn = (int32_t *)((char *)dc + up(bc));
+    int32_t *de = (int32_t *)((char *)dn + up(bp));
+    float *dout = (float *)((char *)de + up(bp));
+    int rc = GNNB_OK;
+    hipError_t e = hipSuccess;
+    if (bx)
+        e = hipMemcpy(dx, x, bx, hipMemcpyHostToDevice);
+    if (e == hipSuccess && bc)
+        e = hipMemcpy(dc, coo, bc, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(dn, node_ptr, bp, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(de, edge_ptr, bp, hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+        rc = fail(GNNB_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e));
+    if (rc == GNNB_OK)
+        rc = gnnb_forward_batched(model, ws, dx, dc, dn, de, num_graphs, num_nodes, num_edges, dout, nullptr);
+    if (rc == GNNB_OK)
+        rc = gnnb_workspace_check(ws, nullptr);
+    if (rc == GNNB_OK && bo) {
+        e = hipMemcpy(out, dout, bo, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = fail(GNNB_ERR_HIP, "D2H copy failed: %s", hipGetErrorString(e));
+    }
+    (void)hipDeviceSynchronize();
+    ws->t.node_ptr = nullptr; // the temporary ptr array dies with this call
+    ws->prepared = false;
+    (void)hipFree(dev);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+int gnnb_event_create(void **out_event)
+{
+    if (!out_event)
+        return fail(GNNB_ERR_INVALID, "null out_event");
+    hipEvent_t ev;
+    GNNB_HIP_TRY(hipEventCreate(&ev));
+    *out_event = (void *)ev;
+    return GNNB_OK;
+}
+
+int gnnb_event_record(void *event, void *stream)
+{
+    GNNB_HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return GNNB_OK;
+}
+
+int gnnb_event_elapsed_ms(void *start, void *stop, float *out_ms)
+{
+    if (!out_ms)
+        return fail(GNNB_ERR_INVALID, "null out_ms");
+    GNNB_HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    GNNB_HIP_TRY(hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return GNNB_OK;
+}
+
+void gnnb_event_destroy(void *event)
+{
+    if (event)
+        (void)hipEventDestroy((hipEvent_t)event);
+}
+
+int gnnb_malloc(void **out_dev, size_t bytes)
+{
+    if (!out_dev)
+        return fail(GNNB_ERR_INVALID, "null out_dev");
+    GNNB_HIP_TRY(hipMalloc(out_dev, bytes ? bytes : 4));
+    return GNNB_OK;
+}
+
+void gnnb_free(void *dev)
+{
+    if (dev)
+        (void)hipFree(dev);
+}
+
+int gnnb_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream)
+{
+    GNNB_HIP_TRY(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return GNNB_OK;
+}
+
+int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream)
+{
+    GNNB_HIP_TRY(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GNNB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GNNB_OK;
+}
+
+} // extern "C"

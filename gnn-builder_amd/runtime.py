@@ -1,0 +1,353 @@
+"""Python binding of the C ABI in ``include/gnnb_hip.h`` (``libgnnb_hip.so``).
+
+This is the accelerated product path.  It has NO fallback: if the HIP library is not built, or no
+MI355X is visible, every entry point raises ``GnnbUnavailable`` -- it never routes to PyTorch or
+to the CPU oracle.
+
+PyTorch is used here only as plumbing: device tensors give us HBM allocations and the current
+HIP stream; the kernels themselves are the hand-written ones in ``csrc/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libgnnb_hip.so"
+CSRC_DIR = PKG_DIR / "csrc"
+
+CONV = {"gcn": 0, "gin": 1, "sage": 2, "pna": 3}
+ACT = {"relu": 0, "gelu": 1, "sigmoid": 2, "tanh": 3, "none": 4}
+POOL = {"add": 0, "mean": 1, "max": 2}
+AGG = {"gcn": 0, "sum": 1, "mean": 2, "pna": 3}
+
+GNNB_OK = 0
+
+
+class GnnbError(RuntimeError):
+    pass
+
+
+class GnnbUnavailable(GnnbError):
+    """The HIP extension or the GPU is missing: the product path cannot run (no fallback)."""
+
+
+class ModelDesc(C.Structure):
+    # field-for-field gnnb_model_desc (include/gnnb_hip.h)
+    _fields_ = [
+        ("conv_type", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("in_dim", C.c_int32),
+        ("hidden_dim", C.c_int32),
+        ("out_dim", C.c_int32),
+        ("activation", C.c_int32),
+        ("skip", C.c_int32),
+        ("num_pools", C.c_int32),
+        ("pools", C.c_int32 * 3),
+        ("mlp_num_linear", C.c_int32),
+        ("mlp_hidden", C.c_int32),
+        ("mlp_out", C.c_int32),
+        ("mlp_activation", C.c_int32),
+        ("gin_eps", C.c_float),
+        ("pna_delta", C.c_float),
+    ]
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [("a_dev", C.c_void_p), ("rowscale_dev", C.c_void_p), ("lda", C.c_int32), ("k", C.c_int32)]
+
+
+# every symbol include/gnnb_hip.h declares (tests check the .so exports each one)
+EXPORTED_SYMBOLS = [
+    "gnnb_version", "gnnb_last_error", "gnnb_device_count", "gnnb_stream_sync",
+    "gnnb_model_num_params", "gnnb_model_create", "gnnb_model_destroy", "gnnb_model_get_desc",
+    "gnnb_workspace_create", "gnnb_workspace_destroy", "gnnb_workspace_bytes",
+    "gnnb_forward_batched", "gnnb_forward_prepared", "gnnb_forward_batched_host", "gnnb_workspace_check",
+    "gnnb_graph_prep", "gnnb_graph_tables_to_host", "gnnb_aggregate", "gnnb_linear", "gnnb_global_pool",
+    "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
+    "gnnb_malloc", "gnnb_free", "gnnb_memcpy_h2d", "gnnb_memcpy_d2h", "gnnb_set_option",
+]
+
+
+def build_library(force: bool = False) -> Path:
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force and LIB_PATH.exists():
+        LIB_PATH.unlink()
+    proc = subprocess.run(["make", "-C", str(CSRC_DIR)], capture_output=True, text=True)
+    if proc.returncode != 0 or not LIB_PATH.exists():
+        raise GnnbError(f"hipcc build of libgnnb_hip.so failed:\n{proc.stdout}\n{proc.stderr}")
+    return LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(require_gpu: bool = True) -> C.CDLL:
+    """dlopen libgnnb_hip.so.  torch is imported first on purpose: its bundled libamdhip64 has the
+    same SONAME as the one the library was linked against, so both share ONE HIP runtime and
+    device pointers / streams can cross the boundary."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise GnnbUnavailable(
+                f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C gnn-builder_amd/csrc`.  There is no CPU fallback.")
+        import torch  # noqa: F401  (HIP runtime first, see docstring)
+        lib = C.CDLL(str(LIB_PATH))
+        lib.gnnb_last_error.restype = C.c_char_p
+        lib.gnnb_workspace_bytes.restype = C.c_size_t
+        lib.gnnb_workspace_bytes.argtypes = [C.c_void_p]
+        lib.gnnb_model_destroy.argtypes = [C.c_void_p]
+        lib.gnnb_model_destroy.restype = None
+        lib.gnnb_workspace_destroy.argtypes = [C.c_void_p]
+        lib.gnnb_workspace_destroy.restype = None
+        lib.gnnb_event_destroy.argtypes = [C.c_void_p]
+        lib.gnnb_event_destroy.restype = None
+        lib.gnnb_free.argtypes = [C.c_void_p]
+        lib.gnnb_free.restype = None
+        lib.gnnb_forward_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.gnnb_forward_prepared.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.gnnb_graph_prep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_int, C.c_float, C.c_void_p]
+        lib.gnnb_aggregate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_float, C.c_void_p]
+        lib.gnnb_linear.argtypes = [C.POINTER(GemmSeg), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.gnnb_global_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int,
+                                         C.c_void_p, C.c_void_p]
+        lib.gnnb_graph_tables_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.gnnb_workspace_check.argtypes = [C.c_void_p, C.c_void_p]
+        lib.gnnb_event_record.argtypes = [C.c_void_p, C.c_void_p]
+        lib.gnnb_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        lib.gnnb_stream_sync.argtypes = [C.c_void_p]
+        lib.gnnb_set_option.argtypes = [C.c_char_p, C.c_int]
+        _lib = lib
+    if require_gpu and _lib.gnnb_device_count() <= 0:
+        raise GnnbUnavailable("libgnnb_hip.so loaded but no MI355X (HIP device) is visible; "
+                              "the product path has no CPU fallback")
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != GNNB_OK:
+        msg = load_library(require_gpu=False).gnnb_last_error()
+        raise GnnbError(f"libgnnb_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def set_option(name: str, value: int) -> None:
+    _check(load_library(require_gpu=False).gnnb_set_option(name.encode(), int(value)))
+
+
+def make_desc(spec: dict) -> ModelDesc:
+    d = ModelDesc()
+    d.conv_type = CONV[spec["conv"]]
+    d.num_layers = spec["num_layers"]
+    d.in_dim = spec["in_dim"]
+    d.hidden_dim = spec["hidden_dim"]
+    d.out_dim = spec["out_dim"]
+    d.activation = ACT[spec["activation"]]
+    d.skip = int(bool(spec["skip"]))
+    d.num_pools = len(spec["pools"])
+    for i, p in enumerate(spec["pools"]):
+        d.pools[i] = POOL[p]
+    d.mlp_num_linear = spec["mlp_hidden_layers"] + 1
+    d.mlp_hidden = spec["mlp_hidden"]
+    d.mlp_out = spec["mlp_out"]
+    d.mlp_activation = ACT[spec["mlp_activation"]]
+    d.gin_eps = spec.get("gin_eps", 0.0)
+    d.pna_delta = spec.get("pna_delta", 1.0)
+    return d
+
+
+def _stream_ptr(stream=None) -> int:
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return int(s.cuda_stream)
+
+
+def _dptr(t) -> int:
+    return int(t.data_ptr())
+
+
+class CompiledModel:
+    """Device-resident model: weights uploaded once (the reference's copy_parameters_flag=1 call),
+    plus one workspace sized for the largest batch it will see."""
+
+    def __init__(self, spec: dict, params: Sequence, max_graphs: int, max_nodes: int, max_edges: int):
+        self.lib = load_library(require_gpu=True)
+        self.spec = dict(spec)
+        self.desc = make_desc(spec)
+        host = [np.ascontiguousarray(np.asarray(p.detach().cpu().numpy() if hasattr(p, "detach") else p,
+                                                dtype=np.float32)) for p in params]
+        n_expect = self.lib.gnnb_model_num_params(C.byref(self.desc))
+        if n_expect < 0:
+            _check(n_expect)
+        if len(host) != n_expect:
+            raise GnnbError(f"model needs {n_expect} parameter tensors, got {len(host)}")
+        arr = (C.c_void_p * len(host))(*[h.ctypes.data for h in host])
+        self._model = C.c_void_p()
+        _check(self.lib.gnnb_model_create(C.byref(self.desc), arr, len(host), C.byref(self._model)))
+        self._ws = C.c_void_p()
+        rc = self.lib.gnnb_workspace_create(self._model, int(max_graphs), int(max_nodes), int(max_edges),
+                                            C.byref(self._ws))
+        if rc != GNNB_OK:
+            self.lib.gnnb_model_destroy(self._model)
+            self._model = C.c_void_p()
+            _check(rc)
+        self.max_graphs, self.max_nodes, self.max_edges = int(max_graphs), int(max_nodes), int(max_edges)
+
+    @classmethod
+    def from_model(cls, model, max_graphs: int, max_nodes: int, max_edges: int) -> "CompiledModel":
+        """``model``: a ``gnnbuilder_amd.models.GNNModel``."""
+        return cls(model.spec(), model.canonical_params(), max_graphs, max_nodes, max_edges)
+
+    @property
+    def out_dim(self) -> int:
+        return int(self.desc.mlp_out)
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.gnnb_workspace_bytes(self._ws))
+
+    def close(self) -> None:
+        if getattr(self, "_ws", None):
+            self.lib.gnnb_workspace_destroy(self._ws)
+            self._ws = C.c_void_p()
+        if getattr(self, "_model", None):
+            self.lib.gnnb_model_destroy(self._model)
+            self._model = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ whole forward
+    def forward(self, x, coo, node_ptr, edge_ptr, out=None, stream=None):
+        """All arguments are torch CUDA tensors (fp32 / int32, contiguous); returns ``out``
+        [B, mlp_out].  Asynchronous on the current torch stream."""
+        import torch
+        B = int(node_ptr.numel()) - 1
+        N, E = int(x.shape[0]), int(coo.shape[0])
+        if out is None:
+            out = torch.empty((B, self.out_dim), dtype=torch.float32, device=x.device)
+        _check(self.lib.gnnb_forward_batched(self._model, self._ws, _dptr(x), _dptr(coo), _dptr(node_ptr),
+                                             _dptr(edge_ptr), B, N, E, _dptr(out), _stream_ptr(stream)))
+        return out
+
+    def graph_prep(self, coo, node_ptr, edge_ptr, num_nodes: int, stream=None) -> None:
+        B = int(node_ptr.numel()) - 1
+        self._keep = (coo, node_ptr, edge_ptr)
+        _check(self.lib.gnnb_graph_prep(self._ws, _dptr(coo), _dptr(node_ptr), _dptr(edge_ptr), B,
+                                        int(num_nodes), int(coo.shape[0]), float(self.desc.pna_delta),
+                                        _stream_ptr(stream)))
+        self._N, self._E, self._B = int(num_nodes), int(coo.shape[0]), B
+
+    def forward_prepared(self, x, out=None, stream=None):
+        import torch
+        if out is None:
+            out = torch.empty((self._B, self.out_dim), dtype=torch.float32, device=x.device)
+        _check(self.lib.gnnb_forward_prepared(self._model, self._ws, _dptr(x), _dptr(out), _stream_ptr(stream)))
+        return out
+
+    def check(self, stream=None) -> None:
+        _check(self.lib.gnnb_workspace_check(self._ws, _stream_ptr(stream)))
+
+    def forward_host(self, x: np.ndarray, coo: np.ndarray, node_ptr: np.ndarray, edge_ptr: np.ndarray) -> np.ndarray:
+        """Host-buffer entry (numpy in, numpy out; synchronous)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        coo = np.ascontiguousarray(coo, dtype=np.int32).reshape(-1, 2)
+        node_ptr = np.ascontiguousarray(node_ptr, dtype=np.int32)
+        edge_ptr = np.ascontiguousarray(edge_ptr, dtype=np.int32)
+        B = node_ptr.shape[0] - 1
+        out = np.zeros((B, self.out_dim), np.float32)
+        _check(self.lib.gnnb_forward_batched_host(
+            self._model, self._ws, x.ctypes.data_as(C.c_void_p), coo.ctypes.data_as(C.c_void_p),
+            node_ptr.ctypes.data_as(C.c_void_p), edge_ptr.ctypes.data_as(C.c_void_p), B, x.shape[0],
+            coo.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ------------------------------------------------------------------ stage-level entry points
+    def tables_to_host(self, stream=None):
+        row_ptr = np.zeros(self._N + 1, np.int32)
+        col = np.zeros(max(self._E, 1), np.int32)
+        in_deg = np.zeros(max(self._N, 1), np.int32)
+        _check(self.lib.gnnb_graph_tables_to_host(self._ws, row_ptr.ctypes.data_as(C.c_void_p),
+                                                  col.ctypes.data_as(C.c_void_p),
+                                                  in_deg.ctypes.data_as(C.c_void_p), _stream_ptr(stream)))
+        return row_ptr, col[:self._E], in_deg[:self._N]
+
+    def aggregate(self, kind: str, x, self_term=None, eps: float = 0.0, out=None, stream=None):
+        import torch
+        w = int(x.shape[1])
+        if out is None:
+            out = torch.empty((x.shape[0], 4 * w if kind == "pna" else w), dtype=torch.float32, device=x.device)
+        _check(self.lib.gnnb_aggregate(self._ws, AGG[kind], _dptr(x),
+                                       _dptr(self_term) if self_term is not None else None, _dptr(out), w,
+                                       float(eps), _stream_ptr(stream)))
+        return out
+
+    def global_pool(self, x, pools: Sequence[str], out=None, stream=None):
+        import torch
+        d = int(x.shape[1])
+        if out is None:
+            out = torch.empty((self._B, len(pools) * d), dtype=torch.float32, device=x.device)
+        arr = (C.c_int32 * len(pools))(*[POOL[p] for p in pools])
+        _check(self.lib.gnnb_global_pool(self._ws, _dptr(x), d, arr, len(pools), _dptr(out), _stream_ptr(stream)))
+        return out
+
+
+def linear(segments, weight, bias=None, skip=None, act: str = "none", out=None, stream=None):
+    """``segments``: list of (A [M, K_s] CUDA tensor, rowscale [M] or None).  weight [N, sum K_s]."""
+    import torch
+    lib = load_library(require_gpu=True)
+    M = int(segments[0][0].shape[0])
+    N = int(weight.shape[0])
+    segs = (GemmSeg * len(segments))()
+    for i, (a, rs) in enumerate(segments):
+        segs[i].a_dev = _dptr(a)
+        segs[i].rowscale_dev = _dptr(rs) if rs is not None else None
+        segs[i].lda = int(a.stride(0))
+        segs[i].k = int(a.shape[1])
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=weight.device)
+    _check(lib.gnnb_linear(segs, len(segments), _dptr(weight), int(weight.stride(0)),
+                           _dptr(bias) if bias is not None else None,
+                           _dptr(skip) if skip is not None else None, _dptr(out), M, N, ACT[act],
+                           _stream_ptr(stream)))
+    return out
+
+
+class HipTimer:
+    """hipEvent pair on an explicit stream (bench.py times kernels on the stream they run on)."""
+
+    def __init__(self):
+        self.lib = load_library(require_gpu=True)
+        self.a, self.b = C.c_void_p(), C.c_void_p()
+        _check(self.lib.gnnb_event_create(C.byref(self.a)))
+        _check(self.lib.gnnb_event_create(C.byref(self.b)))
+
+    def start(self, stream=None):
+        _check(self.lib.gnnb_event_record(self.a, _stream_ptr(stream)))
+
+    def stop(self, stream=None):
+        _check(self.lib.gnnb_event_record(self.b, _stream_ptr(stream)))
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float()
+        _check(self.lib.gnnb_event_elapsed_ms(self.a, self.b, C.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            self.lib.gnnb_event_destroy(self.a)
+            self.lib.gnnb_event_destroy(self.b)
+        except Exception:
+            pass

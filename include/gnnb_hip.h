@@ -1,0 +1,202 @@
+/*
+ * gnnb_hip.h -- C ABI of the MI355X (gfx950) GNNBuilder runtime, libgnnb_hip.so.
+ *
+ * This is the drop-in boundary for the reference's one data-parallel hot path:
+ * what `gnnbuilder.code_gen.Project` used to emit as Vitis-HLS C++ behind
+ *     extern "C" void <name>_top(x, edge_list, out, n, e, copy_params, W...)
+ * (gnnbuilder/templates/model.h.jinja:67-79, model.cpp.jinja:686-766) is served
+ * here by hand-written HIP kernels behind plain-C entry points: plain pointers
+ * and sizes, no torch / C++ types.  `Project.gen_hw_model()` of this package emits
+ * a thin `<name>_top` shim over these calls.
+ *
+ * Semantics = the PyTorch forward of gnnbuilder.models.GNNModel
+ * (gnnbuilder/models.py:551-575), applied independently to every graph of a batch.
+ * All arithmetic fp32, all indices int32.
+ *
+ * Conventions
+ *   - "_dev" pointers are device (HBM) pointers on the current HIP device;
+ *     everything else is host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ *     are asynchronous on that stream unless stated otherwise.
+ *   - Every function returns GNNB_OK or a negative gnnb_status; the text of the
+ *     last failure on the calling thread is available from gnnb_last_error().
+ *   - A model handle is immutable after creation and may be shared by workspaces;
+ *     a workspace serves one in-flight call at a time (the reference's statics made
+ *     the whole kernel non-re-entrant: model.cpp.jinja:5-22).
+ */
+#ifndef GNNB_HIP_H
+#define GNNB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNB_VERSION 100
+
+typedef enum gnnb_status {
+    GNNB_OK = 0,
+    GNNB_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    GNNB_ERR_CAPACITY = -2,  /* batch exceeds the workspace (reference: silent overflow) */
+    GNNB_ERR_HIP = -3,       /* a HIP runtime call failed */
+    GNNB_ERR_NO_DEVICE = -4, /* no gfx950 device visible */
+    GNNB_ERR_GRAPH = -5      /* malformed batch: an edge leaves its graph, ptr not monotone */
+} gnnb_status;
+
+/* gnnbuilder/models.py:453-459 (SUPPORTED_GNN_CONVS; GAT has no native path in the
+ * reference either: gnn_builder_lib.h:2343) */
+typedef enum gnnb_conv { GNNB_CONV_GCN = 0, GNNB_CONV_GIN = 1, GNNB_CONV_SAGE = 2, GNNB_CONV_PNA = 3 } gnnb_conv;
+/* gnnbuilder/models.py:362 (SUPPORTED_ACTIVATIONS); GELU is the exact erf form */
+typedef enum gnnb_act { GNNB_ACT_RELU = 0, GNNB_ACT_GELU = 1, GNNB_ACT_SIGMOID = 2, GNNB_ACT_TANH = 3, GNNB_ACT_NONE = 4 } gnnb_act;
+/* gnnbuilder/models.py:317-321 (SUPPORTED_GLOBAL_POOLING_AGGRS) */
+typedef enum gnnb_pool { GNNB_POOL_ADD = 0, GNNB_POOL_MEAN = 1, GNNB_POOL_MAX = 2 } gnnb_pool;
+
+/* What GNNModel.__init__ fixes (gnnbuilder/models.py:463-549). */
+typedef struct gnnb_model_desc {
+    int32_t conv_type;      /* gnnb_conv */
+    int32_t num_layers;     /* gnn_num_layers, 0..GNNB_MAX_LAYERS */
+    int32_t in_dim;         /* graph_input_feature_dim */
+    int32_t hidden_dim;     /* gnn_hidden_dim */
+    int32_t out_dim;        /* gnn_output_dim */
+    int32_t activation;     /* gnn_activation (gnnb_act), applied after EVERY conv */
+    int32_t skip;           /* gnn_skip_connection: middle layers only (models.py:562-564) */
+    int32_t num_pools;      /* 1..3 */
+    int32_t pools[3];       /* GlobalPooling.aggrs in order (gnnb_pool) */
+    int32_t mlp_num_linear; /* MLP.hidden_layers + 1 */
+    int32_t mlp_hidden;     /* MLP.hidden_dim */
+    int32_t mlp_out;        /* MLP.out_dim = model output width */
+    int32_t mlp_activation; /* MLP.activation (gnnb_act), between head linears only */
+    float gin_eps;          /* GINConv_GNNB.eps (models.py:76) */
+    float pna_delta;        /* PNAConv_GNNB.delta used verbatim as avg_deg_log (models.py:236) */
+} gnnb_model_desc;
+
+#define GNNB_MAX_LAYERS 16
+
+typedef struct gnnb_model gnnb_model;
+typedef struct gnnb_workspace gnnb_workspace;
+
+/* ------------------------------------------------------------------ library / device */
+int gnnb_version(void);
+const char *gnnb_last_error(void);
+/* number of gfx950 devices visible; <= 0 means the product path cannot run */
+int gnnb_device_count(void);
+/* synchronise a stream (hipStreamSynchronize) */
+int gnnb_stream_sync(void *stream);
+
+/* ------------------------------------------------------------------ model
+ * Number of weight tensors the description consumes, in canonical order:
+ *   per conv layer  GCN  {W[out,in], b[out]}
+ *                   GIN  {W0[out,in], b0[out], W1[out,out], b1[out]}        (hidden = out, models.py:90)
+ *                   SAGE {Wl[out,in], bl[out], Wr[out,in]}
+ *                   PNA  {Wpre[in,2in], bpre[in], Wpost[out,13in], bpost[out], Wlin[out,out], blin[out]}
+ *   then per head linear {W[out,in], b[out]}.
+ * All row-major [out][in] fp32 = torch.nn.Linear.weight (gnn_builder_lib.h:40-45). */
+int gnnb_model_num_params(const gnnb_model_desc *desc);
+/* Copies the weights to the device once (the reference's copy_parameters_flag=1 call,
+ * model.cpp.jinja:724-730).  host_params[i] points at tensor i (host memory). */
+int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_params, int num_params,
+                      gnnb_model **out_model);
+void gnnb_model_destroy(gnnb_model *model);
+int gnnb_model_get_desc(const gnnb_model *model, gnnb_model_desc *out_desc);
+
+/* ------------------------------------------------------------------ workspace
+ * Device scratch for batches of at most max_graphs graphs / max_nodes nodes /
+ * max_edges edges in total (replaces MAX_NODES/MAX_EDGES static arrays,
+ * model.cpp.jinja:5-22, but checked: GNNB_ERR_CAPACITY instead of overflow). */
+int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes, int max_edges,
+                          gnnb_workspace **out_ws);
+void gnnb_workspace_destroy(gnnb_workspace *ws);
+size_t gnnb_workspace_bytes(const gnnb_workspace *ws);
+
+/* ------------------------------------------------------------------ batched forward
+ * x_dev        [num_nodes, in_dim] fp32 row-major, graphs concatenated
+ * coo_dev      [num_edges, 2] int32 (src, dst) with BATCH-GLOBAL node ids (edge_index.T as
+ *              code_gen.py:262 writes it, plus the graph's node offset); message flows src->dst
+ * node_ptr_dev [num_graphs+1] int32, node range of graph g = [node_ptr[g], node_ptr[g+1])
+ * edge_ptr_dev [num_graphs+1] int32, edge rows of graph g (edges are grouped by graph,
+ *              original order kept inside a graph)
+ * out_dev      [num_graphs, mlp_out] fp32
+ * Runs graph prep (degree / CSR-by-destination tables, gnn_builder_lib.h:1051-1124), the
+ * conv stack, pooling and the MLP head on `stream`. */
+int gnnb_forward_batched(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev,
+                         const int32_t *coo_dev, const int32_t *node_ptr_dev,
+                         const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges,
+                         float *out_dev, void *stream);
+/* Same with the tables of a previous gnnb_graph_prep() on this workspace re-used
+ * (the topology of the batch is unchanged; only features differ). */
+int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev,
+                          float *out_dev, void *stream);
+/* Host-buffer convenience: H2D copies, forward, D2H copy, synchronises. */
+int gnnb_forward_batched_host(const gnnb_model *model, gnnb_workspace *ws, const float *x,
+                              const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
+                              int num_graphs, int num_nodes, int num_edges, float *out);
+/* Device-side validation result of the last prep on this workspace (synchronises the
+ * stream): GNNB_OK or GNNB_ERR_GRAPH. */
+int gnnb_workspace_check(gnnb_workspace *ws, void *stream);
+
+/* ------------------------------------------------------------------ stage entry points
+ * The individual kernels, for parity tests, profiling and the roofline measurement. */
+
+/* compute_degree_tables + compute_neighbor_tables for a whole batch
+ * (gnn_builder_lib.h:1051-1124): fills the workspace's row_ptr[N+1], col[E]
+ * (CSR by destination, stable in COO order), in-degree, node tiles. */
+int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *node_ptr_dev,
+                    const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges,
+                    float pna_delta, void *stream);
+/* copy the tables of the last prep to host arrays (any may be NULL); synchronises */
+int gnnb_graph_tables_to_host(gnnb_workspace *ws, int32_t *row_ptr /*[N+1]*/, int32_t *col /*[E]*/,
+                              int32_t *in_deg /*[N]*/, void *stream);
+
+typedef enum gnnb_agg {
+    GNNB_AGG_GCN = 0,  /* sum_j x_j/sqrt((1+d_i)(1+d_j)) + x_i/(1+d_i)   gnn_builder_lib.h:1213-1289 */
+    GNNB_AGG_SUM = 1,  /* sum_j x_j + (1+eps) x_i                         gnn_builder_lib.h:1389-1437,1525-1535 */
+    GNNB_AGG_MEAN = 2, /* mean_j x_j (0 if no neighbour)                  gnn_builder_lib.h:2161-2209 */
+    GNNB_AGG_PNA = 3   /* [max|min|mean|std]_j (q_i + p_j), out width 4w  gnn_builder_lib.h:1750-1834, PyG std */
+} gnnb_agg;
+/* Gather-aggregate over the prepared batch.  x_dev [N,width]; out_dev [N,width]
+ * ([N,4*width] for PNA).  self_dev: PNA only, the per-destination term q [N,width]
+ * (NULL otherwise).  eps: GIN's epsilon (SUM only). */
+int gnnb_aggregate(gnnb_workspace *ws, int agg_kind, const float *x_dev, const float *self_dev,
+                   float *out_dev, int width, float eps, void *stream);
+
+/* Dense update on the matrix cores: for up to 4 K-segments s,
+ *   Y[M,N] = act( sum_s (rowscale_s[m] * A_s[M,K_s]) . W[:, koff_s : koff_s+K_s]^T + bias + skip )
+ * W is row-major [N, ldw] (torch Linear layout); A_s row-major with leading dim lda_s.
+ * One segment with rowscale NULL is a plain batched `linear` (gnn_builder_lib.h:808-905). */
+typedef struct gnnb_gemm_seg {
+    const float *a_dev;        /* [M, lda] */
+    const float *rowscale_dev; /* [M] or NULL */
+    int32_t lda;
+    int32_t k;                 /* K_s */
+} gnnb_gemm_seg;
+int gnnb_linear(const gnnb_gemm_seg *segs, int num_segs, const float *w_dev, int ldw,
+                const float *bias_dev /*[N] or NULL*/, const float *skip_dev /*[M,N] or NULL*/,
+                float *y_dev /*[M,N]*/, int M, int N, int act, void *stream);
+
+/* global_{add,mean,max}_pool per graph, concatenated in `pools` order
+ * (gnn_builder_lib.h:2709-2803, model.cpp.jinja:440-448): x_dev [N,d] -> out_dev [B, num_pools*d] */
+int gnnb_global_pool(gnnb_workspace *ws, const float *x_dev, int d, const int32_t *pools,
+                     int num_pools, float *out_dev, void *stream);
+
+/* ------------------------------------------------------------------ timing helpers
+ * hipEvent wrappers so the C harness and bench.py time kernels on the stream they run on. */
+int gnnb_event_create(void **out_event);
+int gnnb_event_record(void *event, void *stream);
+int gnnb_event_elapsed_ms(void *start, void *stop, float *out_ms); /* synchronises on stop */
+void gnnb_event_destroy(void *event);
+
+/* device memory helpers for hosts without another allocator (the generated C harness) */
+int gnnb_malloc(void **out_dev, size_t bytes);
+void gnnb_free(void *dev);
+int gnnb_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
+int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
+
+/* tuning knobs (also read from the environment at load: GNNB_TILE_ROWS, GNNB_AGG_LDS_KB) */
+int gnnb_set_option(const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNB_HIP_H */

@@ -323,3 +323,19 @@ def ref_forward(spec: dict, params, x, coo) -> np.ndarray:
         if i != nl - 1:
             h = activation(h, spec["mlp_activation"], use_ref=True)
     return h
+
+
+def ref_forward_batched(spec: dict, params, x, coo, node_ptr, edge_ptr) -> np.ndarray:
+    """The reference's per-graph loop over a packed batch, entirely inside the compiled
+    reference library (no Python per graph): bench.py's cpu_baseline of kind "reference"."""
+    d = make_desc(spec, "hls")
+    keep, arr = _param_array(params)
+    x = _f32(x).reshape(-1, spec["in_dim"])
+    coo = _i32(coo).reshape(-1, 2)
+    node_ptr, edge_ptr = _i32(node_ptr), _i32(edge_ptr)
+    B = node_ptr.shape[0] - 1
+    out = np.zeros((B, spec["mlp_out"]), np.float32)
+    rc = ref().gnnb_ref_forward_batched(C.byref(d), arr, _p(x), _p(coo), _p(node_ptr), _p(edge_ptr), B, _p(out))
+    if rc != 0:
+        raise ValueError("reference build has no instantiation for this model / graph size")
+    return out

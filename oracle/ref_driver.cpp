@@ -241,4 +241,107 @@ void gnnb_ref_activation(float *x, long count, int kind)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Whole model on ONE graph, composed from the reference's compiled kernels in the order its
+// generated top uses (templates/model.cpp.jinja:737-765): tables -> per layer conv, skip on
+// middle layers (:304-311), activation (:313-322) -> pooling concat (:440-448) -> MLP head
+// (:454-530).  `desc` has the layout of gnnb_oracle_desc (oracle/gnnb_oracle.h); params in the
+// canonical order documented there.  Returns -1 when a size has no instantiation.
+struct ref_desc {
+    int32_t conv_type, num_layers, in_dim, hidden_dim, out_dim, activation, skip, num_pools;
+    int32_t pools[3];
+    int32_t mlp_num_linear, mlp_hidden, mlp_out, mlp_activation;
+    float gin_eps, pna_delta;
+    int32_t pna_std_mode;
+};
+
+int gnnb_ref_forward(const ref_desc *d, const float *const *params, const float *x,
+                     const int32_t *coo, int n, int e, float *out)
+{
+    if (n > REF_MAX_NODES || e > REF_MAX_EDGES)
+        return -1;
+    static int32_t in_deg[REF_MAX_NODES], out_deg[REF_MAX_NODES], offsets[REF_MAX_NODES],
+        nbrs[REF_MAX_EDGES];
+    static float bufa[REF_MAX_NODES * 256], bufb[REF_MAX_NODES * 256];
+    static float pooled[3 * 256], h0[1024], h1[1024];
+    if (d->in_dim > 256 || d->hidden_dim > 256 || d->out_dim > 256 || d->mlp_hidden > 1024 ||
+        d->mlp_out > 1024)
+        return -1;
+    if (gnnb_ref_tables(coo, n, e, in_deg, out_deg, offsets, nbrs) != 0)
+        return -1;
+    float *cur = bufa, *nxt = bufb;
+    memcpy(cur, x, sizeof(float) * (size_t)n * d->in_dim);
+    int width = d->in_dim;
+    const int slots = d->conv_type == 0 ? 2 : d->conv_type == 1 ? 4 : d->conv_type == 2 ? 3 : 6;
+    const float *const *p = params;
+    for (int l = 0; l < d->num_layers; l++) {
+        int fin, fout;
+        if (d->num_layers == 1) { fin = d->in_dim; fout = d->out_dim; }
+        else if (l == 0) { fin = d->in_dim; fout = d->hidden_dim; }
+        else if (l == d->num_layers - 1) { fin = d->hidden_dim; fout = d->out_dim; }
+        else { fin = d->hidden_dim; fout = d->hidden_dim; }
+        int rc = -1;
+        switch (d->conv_type) {
+        case 0: rc = gnnb_ref_gcn_conv(n, e, cur, nxt, coo, offsets, nbrs, in_deg, out_deg, p[0], p[1], fin, fout); break;
+        case 1: rc = gnnb_ref_gin_conv(n, e, cur, nxt, coo, offsets, nbrs, in_deg, out_deg, p[0], p[1], p[2], p[3], d->gin_eps, fin, fout); break;
+        case 2: rc = gnnb_ref_sage_conv(n, e, cur, nxt, coo, offsets, nbrs, in_deg, out_deg, p[0], p[1], p[2], fin, fout); break;
+        case 3: rc = gnnb_ref_pna_conv(n, e, cur, nxt, coo, offsets, nbrs, in_deg, out_deg, p[0], p[1], p[2], p[3], p[4], p[5], d->pna_delta, fin, fout); break;
+        }
+        if (rc != 0)
+            return -1;
+        p += slots;
+        if (d->skip && l != 0 && l != d->num_layers - 1)
+            for (long i = 0; i < (long)n * fout; i++)
+                nxt[i] = nxt[i] + cur[i];
+        gnnb_ref_activation(nxt, (long)n * fout, d->activation);
+        float *t = cur; cur = nxt; nxt = t;
+        width = fout;
+    }
+    for (int k = 0; k < d->num_pools; k++)
+        if (gnnb_ref_global_pool(cur, n, width, d->pools[k], pooled + (size_t)k * width) != 0)
+            return -1;
+    int din = d->num_pools * width;
+    if (din > 1024)
+        return -1;
+    memcpy(h0, pooled, sizeof(float) * din);
+    float *a = h0, *b = h1;
+    for (int l = 0; l < d->mlp_num_linear; l++) {
+        const int last = (l == d->mlp_num_linear - 1);
+        const int dout = last ? d->mlp_out : d->mlp_hidden;
+        if (gnnb_ref_linear(a, b, p[0], p[1], din, dout) != 0)
+            return -1;
+        p += 2;
+        if (!last)
+            gnnb_ref_activation(b, dout, d->mlp_activation);
+        float *t = a; a = b; b = t;
+        din = dout;
+    }
+    memcpy(out, a, sizeof(float) * d->mlp_out);
+    return 0;
+}
+
+// The reference's per-graph loop (templates/model_tb.cpp.jinja:189-205) over a packed batch.
+int gnnb_ref_forward_batched(const ref_desc *d, const float *const *params, const float *x,
+                             const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
+                             int num_graphs, float *out)
+{
+    static int32_t local[REF_MAX_EDGES * 2];
+    for (int g = 0; g < num_graphs; g++) {
+        const int n0 = node_ptr[g], n = node_ptr[g + 1] - n0;
+        const int e0 = edge_ptr[g], e = edge_ptr[g + 1] - e0;
+        if (e > REF_MAX_EDGES)
+            return -1;
+        for (int i = 0; i < e; i++) {
+            local[2 * i] = coo[2 * (size_t)(e0 + i)] - n0;
+            local[2 * i + 1] = coo[2 * (size_t)(e0 + i) + 1] - n0;
+        }
+        int rc = gnnb_ref_forward(d, params, x + (size_t)n0 * d->in_dim, local, n, e,
+                                  out + (size_t)g * d->mlp_out);
+        if (rc != 0)
+            return rc;
+    }
+    return 0;
+}
+
 } // extern "C"

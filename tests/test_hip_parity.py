@@ -1,0 +1,282 @@
+"""Parity tests proper: the HIP path (through the C ABI of libgnnb_hip.so) against the CPU
+oracle and the reference's golden vectors.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerance: 1e-4 absolute on O(1) outputs (BASELINE.json north_star: "outputs within 1e-4 of the
+PyTorch reference"); integer tables bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from gnnbuilder_amd import runtime, synthetic
+from gnnbuilder_amd.batching import GraphBatch, pack_graphs
+from helpers import canon, make_model, to_dev
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    runtime.load_library(require_gpu=True)  # fails loudly: no fallback
+    return torch.device("cuda:0")
+
+
+def fixture_batch():
+    x, coo = G.graph()
+    return pack_graphs([(x, coo)])
+
+
+def oracle_tables_batched(batch: GraphBatch):
+    row_ptr, cols = [0], []
+    for g in range(batch.num_graphs):
+        xg, cg = batch.graph(g)
+        in_deg, _, offsets, nbrs = O.tables(cg, xg.shape[0])
+        n0 = int(batch.node_ptr[g])
+        for d in in_deg:
+            row_ptr.append(row_ptr[-1] + int(d))
+        cols.append(nbrs + n0)
+    return np.asarray(row_ptr, np.int32), (np.concatenate(cols) if cols else np.zeros(0, np.int32)).astype(np.int32)
+
+
+def plain_model(conv, fin, fout):
+    # one layer; identity-ish tail so stage tests can reuse CompiledModel's workspace
+    return make_model(conv, in_dim=fin, hidden=fout, layers=1, out_dim=fout, task_out=3, mlp_layers=0)
+
+
+# --------------------------------------------------------------------------- graph prep
+def edge_case_batch():
+    rng = np.random.default_rng(5)
+    graphs = []
+    graphs.append((rng.uniform(-1, 1, (1, 8)), np.zeros((0, 2), np.int32)))                    # single node, E=0
+    graphs.append((rng.uniform(-1, 1, (5, 8)), np.array([[0, 1], [1, 0], [2, 2], [3, 1], [3, 1]])))  # self loop, dup edge, isolated node 4
+    graphs.append((rng.uniform(-1, 1, (0, 8)), np.zeros((0, 2), np.int32)))                    # empty graph
+    n = 150                                                                                     # > 64 nodes: several lane chunks
+    e = np.stack([rng.integers(0, n, 700), rng.integers(0, n, 700)], 1)                         # > 512 edges: uncached path
+    graphs.append((rng.uniform(-1, 1, (n, 8)), e))
+    graphs.append((rng.uniform(-1, 1, (3, 8)), np.array([[0, 1], [1, 2], [2, 0]])))
+    return pack_graphs([(np.asarray(x, np.float32), np.asarray(c, np.int32)) for x, c in graphs])
+
+
+@pytest.mark.parametrize("which", ["fixture", "qm9", "molhiv", "edge"])
+def test_graph_prep_bit_exact(dev, which):
+    batch = {"fixture": fixture_batch, "qm9": lambda: synthetic.make_batch("qm9", 300, 1),
+             "molhiv": lambda: synthetic.make_batch("molhiv", 200, 2), "edge": edge_case_batch}[which]()
+    cm = runtime.CompiledModel.from_model(plain_model("gcn", batch.x.shape[1], 8), batch.num_graphs + 1,
+                                          batch.num_nodes + 1, batch.num_edges + 1)
+    _, coo, nptr, eptr = to_dev(batch, dev)
+    cm.graph_prep(coo, nptr, eptr, batch.num_nodes)
+    cm.check()
+    row_ptr, col, in_deg = cm.tables_to_host()
+    rp_ref, col_ref = oracle_tables_batched(batch)
+    assert np.array_equal(row_ptr, rp_ref)
+    assert np.array_equal(col, col_ref)
+    if which == "fixture":  # the reference's own committed tables (test.cpp:884-1054)
+        assert np.array_equal(in_deg, G.i32("tb_in_degree_table"))
+        assert np.array_equal(row_ptr[:-1], G.i32("tb_neighbor_table_offsets"))
+        assert np.array_equal(col, G.i32("tb_neighbor_table"))
+
+
+def test_malformed_batch_is_reported(dev):
+    batch = synthetic.make_batch("qm9", 8, 0)
+    bad = batch.coo.copy()
+    bad[3, 0] = batch.num_nodes - 1  # edge of graph 0 pointing into the last graph
+    cm = runtime.CompiledModel.from_model(plain_model("gcn", 11, 8), 8, batch.num_nodes, batch.num_edges)
+    _, _, nptr, eptr = to_dev(batch, dev)
+    cm.graph_prep(torch.from_numpy(bad).to(dev), nptr, eptr, batch.num_nodes)
+    with pytest.raises(runtime.GnnbError):
+        cm.check()
+
+
+def test_capacity_is_checked(dev):
+    batch = synthetic.make_batch("qm9", 8, 0)
+    cm = runtime.CompiledModel.from_model(plain_model("gcn", 11, 8), 4, batch.num_nodes, batch.num_edges)
+    with pytest.raises(runtime.GnnbError, match="exceeds workspace"):
+        cm.forward(*to_dev(batch, dev))
+
+
+# --------------------------------------------------------------------------- single conv layers vs the PyG goldens
+@pytest.mark.parametrize("kind", ["gcn", "gin", "sage", "pna"])
+def test_conv_layer_matches_reference_golden(dev, kind):
+    """One conv layer on the reference's 100-node fixture graph, weights from its tb_data,
+    expected output = its PyG-generated golden (test.cpp:1056-1726 accepts 1e-3 / 1e-2)."""
+    x, coo = G.graph()
+    batch = pack_graphs([(x, coo)])
+    w = [torch.from_numpy(np.array(t)).to(dev) for t in G.conv_weights(kind)]
+    cm = runtime.CompiledModel.from_model(plain_model(kind, 8, 8), 1, G.N, G.E)
+    xd, cood, nptr, eptr = to_dev(batch, dev)
+    cm.desc.pna_delta = G.conv_kwargs("pna")["delta"] if kind == "pna" else 1.0
+    cm.graph_prep(cood, nptr, eptr, G.N)
+    if kind == "gcn":
+        y = runtime.linear([(cm.aggregate("gcn", xd), None)], w[0], w[1])
+    elif kind == "gin":
+        z = cm.aggregate("sum", xd, eps=G.conv_kwargs("gin")["eps"])
+        y = runtime.linear([(runtime.linear([(z, None)], w[0], w[1], act="relu"), None)], w[2], w[3])
+    elif kind == "sage":
+        m = cm.aggregate("mean", xd)
+        y = runtime.linear([(m, None), (xd, None)], torch.cat([w[0], w[2]], 1).contiguous(), w[1])
+    else:
+        wpre = w[0]
+        q = runtime.linear([(xd, None)], wpre[:, :8], w[1])
+        p = runtime.linear([(xd, None)], wpre[:, 8:], None)
+        a = cm.aggregate("pna", p, self_term=q)
+        deg = torch.from_numpy(G.i32("tb_in_degree_table")).to(dev).clamp(min=1).float()
+        delta = G.conv_kwargs("pna")["delta"]
+        amp = (torch.log(deg + 1) / delta).contiguous()
+        att = (delta / torch.log(deg + 1)).contiguous()
+        hid = runtime.linear([(xd, None), (a, None), (a, amp), (a, att)], w[2], w[3])
+        y = runtime.linear([(hid, None)], w[4], w[5])
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - G.conv_golden(kind)).max() < 2e-6
+
+
+# --------------------------------------------------------------------------- dense update vs a torch fp32 reference
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 19, 11), (128, 64, 32), (300, 128, 128), (257, 130, 100),
+                                   (1000, 256, 143), (4096, 64, 384)])
+@pytest.mark.parametrize("act", ["none", "relu", "gelu", "sigmoid", "tanh"])
+def test_linear_matches_torch(dev, M, N, K, act):
+    if act not in ("none", "relu") and M > 300:
+        pytest.skip("activation coverage on the small shapes is enough")
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
+    a = torch.rand(M, K, generator=g) * 2 - 1
+    w = (torch.rand(N, K, generator=g) * 2 - 1) / max(K, 1) ** 0.5
+    b = torch.rand(N, generator=g) * 2 - 1
+    skip = torch.rand(M, N, generator=g) * 2 - 1
+    ref = a.double() @ w.double().T + b.double() + skip.double()
+    ref = {"none": lambda t: t, "relu": torch.relu, "gelu": lambda t: torch.nn.functional.gelu(t),
+           "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](ref).float()
+    y = runtime.linear([(a.to(dev), None)], w.to(dev), b.to(dev), skip=skip.to(dev), act=act)
+    torch.cuda.synchronize()
+    assert (y.cpu() - ref).abs().max().item() < 2e-5
+
+
+def test_linear_segments_and_rowscale(dev):
+    g = torch.Generator().manual_seed(7)
+    M, N = 333, 96
+    ks = [11, 44, 44, 44]  # the PNA shape at F=11: [x | A | amp.A | att.A]
+    x = torch.rand(M, 11, generator=g) - 0.5
+    A = torch.rand(M, 44, generator=g) - 0.5
+    amp, att = torch.rand(M, generator=g) + 0.5, torch.rand(M, generator=g) + 0.5
+    w = (torch.rand(N, sum(ks), generator=g) - 0.5) / 6
+    b = torch.rand(N, generator=g)
+    cat = torch.cat([x, A, A * amp[:, None], A * att[:, None]], 1).double()
+    ref = (cat @ w.double().T + b.double()).float()
+    Ad = A.to(dev)
+    y = runtime.linear([(x.to(dev), None), (Ad, None), (Ad, amp.to(dev)), (Ad, att.to(dev))], w.to(dev), b.to(dev))
+    torch.cuda.synchronize()
+    assert (y.cpu() - ref).abs().max().item() < 2e-5
+
+
+# --------------------------------------------------------------------------- pooling
+@pytest.mark.parametrize("d", [8, 64, 128, 100, 7])
+def test_global_pool_matches_oracle(dev, d):
+    batch = synthetic.make_batch("molhiv", 50, 4)
+    rng = np.random.default_rng(d)
+    h = rng.uniform(-1, 1, (batch.num_nodes, d)).astype(np.float32)
+    cm = runtime.CompiledModel.from_model(plain_model("gcn", 9, 8), 50, batch.num_nodes, batch.num_edges)
+    _, coo, nptr, eptr = to_dev(batch, dev)
+    cm.graph_prep(coo, nptr, eptr, batch.num_nodes)
+    pools = ["max", "add", "mean"]
+    out = cm.global_pool(torch.from_numpy(h).to(dev), pools)
+    torch.cuda.synchronize()
+    ref = np.stack([np.concatenate([O.global_pool(h[batch.node_ptr[g]:batch.node_ptr[g + 1]], k) for k in pools])
+                    for g in range(50)])
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-5
+
+
+# --------------------------------------------------------------------------- whole models vs the oracle
+MODEL_CASES = [
+    # conv, in, hidden, layers, act, skip, pools, shape, graphs
+    ("gcn", 11, 128, 2, "relu", True, ("add", "mean", "max"), "qm9", 256),      # BASELINE config 2 (shape)
+    ("gcn", 9, 64, 2, "relu", True, ("add", "mean", "max"), "esol", 40),        # BASELINE config 1 (shape)
+    ("gin", 9, 128, 3, "relu", True, ("add",), "molhiv", 128),                  # config 3
+    ("pna", 11, 128, 3, "relu", True, ("add", "mean", "max"), "qm9", 96),       # config 4
+    ("sage", 9, 256, 2, "relu", True, ("add", "mean", "max"), "molhiv", 128),   # config 5
+    ("gcn", 11, 32, 4, "tanh", True, ("max", "add"), "qm9", 64),
+    ("gin", 11, 48, 4, "gelu", True, ("mean",), "qm9", 64),
+    ("sage", 9, 40, 3, "sigmoid", False, ("mean", "max"), "molhiv", 64),
+    ("pna", 9, 24, 2, "tanh", False, ("max",), "molhiv", 48),
+    ("sage", 11, 16, 1, "relu", True, ("add",), "qm9", 32),
+    ("gcn", 11, 11, 0, "relu", False, ("add", "max"), "qm9", 32),               # gnn_num_layers = 0
+]
+
+
+@pytest.mark.parametrize("case", MODEL_CASES, ids=lambda c: f"{c[0]}-L{c[3]}-d{c[2]}-{c[4]}")
+def test_whole_model_matches_oracle(dev, case):
+    conv, fin, hidden, layers, act, skip, pools, shape, ngraphs = case
+    model = make_model(conv, in_dim=fin, hidden=hidden, layers=layers, act=act, skip=skip, pools=pools,
+                       task_out=synthetic.SHAPES[shape]["out"], seed=layers * 17 + hidden)
+    batch = synthetic.make_batch(shape, ngraphs, seed=hidden)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    out = cm.forward(*to_dev(batch, dev))
+    cm.check()
+    torch.cuda.synchronize()
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < TOL, f"max err {np.abs(got - ref).max():.3e}, |ref| {np.abs(ref).max():.3e}"
+
+
+def test_host_entry_and_single_graph(dev):
+    """forward_batched_host (what <name>_top uses) == device entry; a graph alone == inside a batch."""
+    model = make_model("gcn", hidden=64)
+    batch = synthetic.make_batch("qm9", 33, seed=9)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    out_d = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    out_h = cm.forward_host(batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    assert np.array_equal(out_d, out_h)
+    one = batch.slice(7, 8)
+    out_1 = cm.forward_host(one.x, one.coo, one.node_ptr, one.edge_ptr)
+    assert np.abs(out_1[0] - out_d[7]).max() < 1e-6
+
+
+def test_degenerate_graphs(dev):
+    """Isolated nodes, E=0 graphs, an empty graph, self loops, duplicate edges (SURVEY section 4 gaps)."""
+    batch = edge_case_batch()
+    for conv in ("gcn", "gin", "sage", "pna"):
+        model = make_model(conv, in_dim=8, hidden=16, layers=2, task_out=3)
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+        out = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+        ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+        assert np.isfinite(out).all()
+        assert np.abs(out - ref).max() < TOL, conv
+
+
+# --------------------------------------------------------------------------- full BASELINE sizes: properties + sampled oracle
+def test_full_size_config2_properties(dev):
+    """BASELINE config 2 at full size (B=4096): (1) a sample of graphs against the oracle,
+    (2) batch-composition independence: reversing the order of the graphs permutes the outputs."""
+    model = make_model("gcn", in_dim=11, hidden=128, layers=2)
+    batch = synthetic.make_batch("qm9", 4096, seed=0)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    out = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    cm.check()
+    idx = np.random.default_rng(0).choice(4096, 192, replace=False)
+    sub = pack_graphs([batch.graph(int(g)) for g in idx])
+    ref = O.forward_batched(model.spec(), canon(model), sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
+    assert np.abs(out[idx] - ref).max() < TOL
+    rev = pack_graphs([batch.graph(g) for g in range(4095, -1, -1)])
+    out_rev = cm.forward(*to_dev(rev, dev)).cpu().numpy()
+    assert np.abs(out_rev[::-1] - out).max() < 1e-5
+
+
+@pytest.mark.parametrize("opt", [dict(tile_rows=8), dict(tile_rows=64, agg_tiles_per_wg=2), dict(agg_lds_kb=8),
+                                 dict(agg_overshoot=0)])
+def test_tiling_options_do_not_change_results(dev, opt):
+    """Every LDS-staged / direct-from-L2 / multi-tile path of the aggregate kernel agrees."""
+    model = make_model("pna", in_dim=9, hidden=32, layers=2, task_out=1)
+    batch = synthetic.make_batch("molhiv", 64, seed=11)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    defaults = dict(tile_rows=32, agg_tiles_per_wg=1, agg_lds_kb=48, agg_overshoot=32)
+    try:
+        for k, v in opt.items():
+            runtime.set_option(k, v)
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+        out = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    finally:
+        for k, v in defaults.items():
+            runtime.set_option(k, v)
+    assert np.abs(out - ref).max() < TOL
