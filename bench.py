@@ -60,7 +60,7 @@ def build_model(w, seed=0):
                          gnnb.MLP(len(w["pools"]) * w["hidden"], shp["out"], 64, 2), None).eval()
 
 
-def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200):
+def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("hbm", "l3_resident")):
     """GCN gather-aggregate at `width`, timed with HIP events on the launch stream.  Returns both
     the HBM regime (inputs/outputs rotate over > 256 MiB of distinct buffers) and the regime the
     kernel sees inside the pipeline (same buffers every launch: Infinity-Cache resident)."""
@@ -76,18 +76,11 @@ def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200):
     nbuf = max(2, int(np.ceil(320 * 2**20 / per_pair)) + 1)
     ins = [torch.rand(N, width, device=dev) * 2 - 1 for _ in range(nbuf)]
     outs = [torch.empty(N, width, device=dev) for _ in range(nbuf)]
-    timer = runtime.HipTimer()
     res = {}
-    for regime, rotate in (("hbm", True), ("l3_resident", False)):
-        for i in range(10):
-            cm.aggregate("gcn", ins[i % nbuf if rotate else 0], out=outs[i % nbuf if rotate else 0])
-        torch.cuda.synchronize()
-        timer.start()
-        for i in range(iters):
-            k = i % nbuf if rotate else 0
-            cm.aggregate("gcn", ins[k], out=outs[k])
-        timer.stop()
-        us = timer.elapsed_ms() * 1e3 / iters
+    for regime, n in (("hbm", nbuf), ("l3_resident", 1)):
+        if regime not in regimes:
+            continue
+        us = cm.aggregate_timed("gcn", ins[:n], outs[:n], iters)  # launches issued from C
         res[regime] = dict(us=us, gbps=alg_bytes / (us * 1e-6) / 1e9)
     del ins, outs
     return alg_bytes, res
@@ -103,21 +96,14 @@ def measure_update_mfma(w, N, dev, iters=100):
     wt = (torch.rand(d, d, device=dev) - 0.5) / d ** 0.5
     b = torch.rand(d, device=dev)
     y = torch.empty(N, d, device=dev)
-    timer = runtime.HipTimer()
-    for _ in range(5):
-        runtime.linear([(a, None)], wt, b, act="relu", out=y)
-    torch.cuda.synchronize()
-    timer.start()
-    for _ in range(iters):
-        runtime.linear([(a, None)], wt, b, act="relu", out=y)
-    timer.stop()
-    us = timer.elapsed_ms() * 1e3 / iters
+    us = runtime.linear_timed(a, wt, b, y, "relu", iters)
     flops = 2.0 * N * d * d
     return dict(us=us, tflops=flops / (us * 1e-6) / 1e12, frac=flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
 
 
-def cpu_baseline(model, batch, budget_s=12.0):
-    """Reference CPU path on ONE core over a bounded sample of the same graphs."""
+def cpu_baseline(model, batches, budget_s=12.0):
+    """Reference CPU path on ONE core over a bounded sample (~budget_s of CPU work) of the same
+    workload: the per-graph loop of the reference testbench (model_tb.cpp.jinja:189-205)."""
     from oracle import oracle as O
 
     try:
@@ -126,26 +112,59 @@ def cpu_baseline(model, batch, budget_s=12.0):
         pass
     spec, params = model.spec(), [p.numpy() for p in model.canonical_params()]
     kind = "reference" if O.have_ref() else "port"
-    chunk, done, t_total = 128, 0, 0.0
-    B = batch.num_graphs
-    while t_total < budget_s and done < B:
-        g1 = min(done + chunk, B)
-        sub = batch.slice(done, g1)
+    chunk, done, t_total = 256, 0, 0.0
+    bi, g0 = 0, 0
+    while t_total < budget_s:
+        batch = batches[bi]
+        g1 = min(g0 + chunk, batch.num_graphs)
+        sub = batch.slice(g0, g1)
         t0 = time.perf_counter()
         if kind == "reference":
             try:
                 O.ref_forward_batched(spec, params, sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
-            except ValueError:
+            except ValueError:  # a graph beyond the reference build's MAX_NODES / an uninstantiated size
                 kind = "port"
                 continue
         else:
             O.forward_batched(spec, params, sub.x, sub.coo, sub.node_ptr, sub.edge_ptr, std="pyg")
         t_total += time.perf_counter() - t0
-        done = g1
-    what = ("reference C++ kernel library (gnn_builder_lib.h, float, g++ -O2) via oracle/_ref"
-            if kind == "reference" else "C oracle port (oracle/gnnb_oracle.c, gcc -O2)")
+        done += g1 - g0
+        g0 = g1
+        if g0 >= batch.num_graphs:
+            bi, g0 = (bi + 1) % len(batches), 0  # cycle: the sample is bounded by CPU time, not by graphs
+    what = ("the reference's own C++ kernel library (gnn_builder_lib.h, float mode, g++ -O2) compiled in place "
+            "as oracle/_ref" if kind == "reference" else "C oracle port (oracle/gnnb_oracle.c, gcc -O2)")
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu_model = "unknown"
     return {"value": done / t_total, "unit": "graphs/s", "cores": 1, "kind": kind,
-            "sample": f"first {done} graphs of the step's batch, per-graph loop, {t_total:.1f} s; {what}"}
+            "sample": f"{done} graphs of the timed workload (its batches in order, cycled), one graph per call, {t_total:.1f} s of CPU time; {what}",
+            "host_cpu": cpu_model, "host_cores_available": os.cpu_count()}
+
+
+def copy_ceiling(N, width, dev, iters=200):
+    """Calibration beside the roofline: a plain streaming copy (torch's vectorised kernel) of the
+    same [N, width] fp32 matrix = the same read + write bytes with no gather at all."""
+    import torch
+
+    nbuf = max(2, int(np.ceil(320 * 2**20 / (2 * 4 * width * N))) + 1)
+    a = [torch.rand(N, width, device=dev) for _ in range(nbuf)]
+    b = [torch.empty(N, width, device=dev) for _ in range(nbuf)]
+    out = {}
+    for regime, n in (("hbm", nbuf), ("l3_resident", 1)):
+        for i in range(10):
+            b[i % n].copy_(a[i % n])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            b[i % n].copy_(a[i % n])
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out[regime] = dict(us=us, gbps=2 * 4 * width * N / (us * 1e-6) / 1e9)
+    return out
 
 
 def main():
@@ -157,6 +176,8 @@ def main():
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches rotated per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the HBM-regime gather-aggregate loop (for a rocprofv3 run whose kernel average is that loop)")
     args = ap.parse_args()
 
     import torch
@@ -181,6 +202,13 @@ def main():
 
     w = WORKLOADS[args.workload]
     model = build_model(w)
+    if args.roofline_only:
+        batch = synthetic.make_batch(w["shape"], w["batch"], seed=0)
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+        bd = tuple(torch.from_numpy(a).to(dev) for a in (batch.x, batch.coo, batch.node_ptr, batch.edge_ptr))
+        alg_bytes, agg = measure_aggregate_roofline(cm, bd, w["hidden"], dev, regimes=("hbm",))
+        print(json.dumps({"roofline_only": True, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"]}))
+        return
     # rank-distinct synthetic batches (weak scaling: every GPU gets its own `batch` graphs per step)
     batches = [synthetic.make_batch(w["shape"], w["batch"], seed=1000 * rank + i) for i in range(args.batches)]
     maxn = max(b.num_nodes for b in batches)
@@ -259,12 +287,14 @@ def main():
     if rank == 0 and not args.no_roofline:
         alg_bytes, agg = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev)
         result["roofline"] = {
-            "kernel": "k_aggregate<GCN> (gather-aggregate, width %d)" % w["hidden"],
+            "kernel": "k_aggregate_stream<GCN> (gather-aggregate, width %d)" % w["hidden"],
             "bound": "hbm", "achieved": agg["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": agg["hbm"]["us"],
-            "regime": "inputs/outputs rotate over >256 MiB of distinct buffers (HBM-served)",
-            "l3_resident": agg["l3_resident"],
+            "regime": "inputs/outputs rotate over >256 MiB of distinct buffers (HBM-served); launches issued "
+                      "back to back from C, HIP events on the launch stream",
+            "in_pipeline_l3_resident": agg["l3_resident"],
+            "copy_ceiling_same_bytes": copy_ceiling(batches[0].num_nodes, w["hidden"], dev),
         }
         result["roofline_update"] = dict(kernel="k_linear (fp32 MFMA 32x32x2), full-width layer update",
                                          bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
@@ -272,7 +302,7 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(model, batches[0])
+        result["cpu_baseline"] = cpu_baseline(model, batches)
 
     if rank == 0:
         print(json.dumps(result))

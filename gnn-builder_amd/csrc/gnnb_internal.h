@@ -13,9 +13,13 @@ namespace gnnb {
 struct BatchTables {
     int32_t *row_ptr;    // [N+1] CSR by destination, batch-global
     int32_t *col;        // [E]   source node (batch-global id) of every in-edge, stable COO order
+    int4 *node_rec;      // [2N]  per node {rp0, deg, j0, j1}{j2, j3, -, -}: CSR row start, in-degree and
+                         //       its first four sources, so one 32-B read feeds the whole gather
+    float *dinv;         // [N]   GCN normaliser     1/sqrt(1 + in_degree)
     float *amp;          // [N]   PNA amplification  log(max(d,1)+1)/delta
     float *att;          // [N]   PNA attenuation    delta/log(max(d,1)+1)
     int32_t *tile_first; // [T+1] first node of node-tile t; tiles are cut at graph boundaries
+    int32_t *tile_edge;  // [T+1] row_ptr[tile_first[t]] (first CSR entry of the tile)
     int32_t *err;        // [1]   != 0 when the batch was malformed
     const int32_t *node_ptr; // [B+1] caller's graph_node_ptr (device)
     int32_t num_graphs, num_nodes, num_edges;
@@ -28,6 +32,9 @@ struct Options {
     int agg_lds_kb;   // LDS budget per aggregate workgroup
     int agg_tiles_per_wg;
     int agg_overshoot; // LDS rows reserved for the graph that straddles a tile's end
+    int agg_variant;   // 0 = CSR-streamed gather (default), 1 = LDS-staged small tiles,
+                       // 2 = pipelined LDS-DMA, 3 = record-streamed, 4 = LDS-DMA single burst
+    int agg_rows_per_wg; // streaming variant: destination rows per workgroup
 };
 Options &options();
 

@@ -7,11 +7,34 @@
 //
 // Wavefront = 64 lanes everywhere.  Reference semantics are cited per kernel
 // (paths relative to the reference repository root).
+#include <algorithm>
+
 #include "gnnb_internal.h"
 
 namespace gnnb {
 
 static constexpr int WG = 256; // 4 wavefronts
+
+// Diagnostic build only (-DGNNB_PROBE, tools/probe_agg.py): per-workgroup phase stamps.  The
+// product library is built without it and executes no stamp.
+#ifdef GNNB_PROBE
+__device__ unsigned long long g_probe[8 * 8192];
+#define GNNB_STAMP(slot)                                                                   \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                       \
+            g_probe[blockIdx.x * 8 + 2 * (slot)] = wall_clock64();                         \
+            g_probe[blockIdx.x * 8 + 2 * (slot) + 1] = clock64();                          \
+        }                                                                                  \
+    } while (0)
+#define GNNB_STAMP_END(slot)                                                               \
+    do {                                                                                   \
+        __builtin_amdgcn_s_waitcnt(0); /* drain this wave's stores first */                \
+        GNNB_STAMP(slot);                                                                  \
+    } while (0)
+#else
+#define GNNB_STAMP(slot) do { } while (0)
+#define GNNB_STAMP_END(slot) do { } while (0)
+#endif
 
 // =====================================================================================
 // graph prep
@@ -28,8 +51,11 @@ static constexpr int PREP_EDGE_CAP = 512; // edges cached in LDS per wavefront
 __global__ __launch_bounds__(WG) void k_graph_prep(
     const int2 *__restrict__ coo, const int32_t *__restrict__ node_ptr,
     const int32_t *__restrict__ edge_ptr, int B, int N, int E, int32_t *__restrict__ row_ptr,
-    int32_t *__restrict__ col, float *__restrict__ amp, float *__restrict__ att, float delta,
-    int32_t *__restrict__ tile_first, int tile_rows, int num_tiles, int32_t *__restrict__ err)
+    int32_t *__restrict__ col, int4 *__restrict__ node_rec, float *__restrict__ dinv,
+    float *__restrict__ amp,
+    float *__restrict__ att, float delta,
+    int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int tile_rows, int num_tiles,
+    int32_t *__restrict__ err)
 {
     __shared__ int2 s_edges[WG / 64][PREP_EDGE_CAP];
     const int lane = threadIdx.x & 63;
@@ -44,8 +70,12 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         const int p = (g == B) ? N : min(max(node_ptr[g], 0), N);
         const int t_lo = (g == 0) ? 0 : max(min(max(node_ptr[g - 1], 0), N) / tile_rows + 1, 0);
         const int t_hi = (g == B) ? num_tiles : min(p / tile_rows, num_tiles);
-        for (int t = t_lo + lane; t <= t_hi; t += 64)
+        // edges are grouped by graph, so the CSR segment of graph g starts at edge_ptr[g]
+        const int pe = (g == B) ? E : min(max(edge_ptr[g], 0), E);
+        for (int t = t_lo + lane; t <= t_hi; t += 64) {
             tile_first[t] = p;
+            tile_edge[t] = pe;
+        }
     }
     if (g == B) {
         if (lane == 0) {
@@ -113,25 +143,40 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         const int start = base + incl - cnt;
         if (active) {
             row_ptr[v] = start;
+            dinv[v] = 1.0f / sqrtf(1.0f + (float)cnt);
             const int dcl = cnt < 1 ? 1 : cnt; // gnn_builder_lib.h:1972-1982
             const float logd = logf((float)(dcl + 1));
             amp[v] = logd / delta;
             att[v] = delta / logd;
         }
-        // stable fill: edges are visited in COO order
+        // stable fill: edges are visited in COO order; the first four sources also go into the
+        // node record
         int pos = start;
+        int jf[4] = {v, v, v, v};
+        auto put = [&](int src) {
+            const int q = pos - start;
+            if (q == 0) jf[0] = src;
+            else if (q == 1) jf[1] = src;
+            else if (q == 2) jf[2] = src;
+            else if (q == 3) jf[3] = src;
+            col[pos++] = src;
+        };
         if (cached) {
             for (int i = 0; i < ne; i++) {
                 int2 ed = se[i];
                 if (ed.y == v)
-                    col[pos++] = ed.x;
+                    put(ed.x);
             }
         } else {
             for (int i = 0; i < ne; i++) {
                 int2 ed = coo[e0 + i];
                 if (ed.y == v && ed.x >= n0 && ed.x < n1)
-                    col[pos++] = ed.x;
+                    put(ed.x);
             }
+        }
+        if (active) {
+            node_rec[2 * (size_t)v] = make_int4(start, cnt, jf[0], jf[1]);
+            node_rec[2 * (size_t)v + 1] = make_int4(jf[2], jf[3], 0, 0);
         }
         base += __shfl(incl, 63, 64);
     }
@@ -148,8 +193,9 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
     const int waves = t.num_graphs + 1;
     const int grid = (waves + (WG / 64) - 1) / (WG / 64);
     hipLaunchKernelGGL(k_graph_prep, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
-                       edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.amp,
-                       t.att, pna_delta, t.tile_first, t.tile_rows, t.num_tiles, t.err);
+                       edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.node_rec,
+                       t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_rows, t.num_tiles,
+                       t.err);
     return hipGetLastError();
 }
 
@@ -407,13 +453,885 @@ static hipError_t launch_aggregate_t(const BatchTables &t, const float *x, const
     return hipGetLastError();
 }
 
+
+// -------------------------------------------------------------------------------------
+// CSR-streamed variant (default: fastest measured, see profiles/).  A workgroup owns `rows_per_wg` consecutive destination rows.
+// Only the CSR slice (row_ptr, col) is staged in LDS; feature rows are gathered straight from
+// global memory: a row is fetched from HBM by whoever touches it first (its own lane group or a
+// neighbour's) and the other ~2 uses hit the XCD's L2 microseconds later, because a graph's
+// rows are contiguous and handled by the same or the adjacent workgroup.  Per destination row a
+// lane group issues the self row and two neighbour rows together (three independent 16-B loads
+// per lane in flight), so the kernel behaves like a streaming copy with L2-side gathers: no
+// barrier between load and compute, no LDS capacity limit, any graph size.
+// GCN uses the PyG form of the same normaliser: dinv_i * dinv_j with dinv = (1+d)^-1/2.
+// Per-row state of the streaming kernel: `begin` issues the self row and the first two
+// neighbour rows (three independent 16-B loads per lane), `finish` consumes them.  Two rows per
+// lane group are begun before either is finished, so six loads per lane are in flight.
+template <int MODE, int VEC>
+struct AggRow {
+    typedef Vf<VEC> V;
+    int node, rp0, rp1, j0, j1;
+    float di, s0, s1;
+    V xi, a, b;
+    bool valid;
+
+    __device__ inline void begin(bool ok, int nb, int r, const int32_t *srp, const int32_t *scol, int eb,
+                                 bool ecached, const int32_t *__restrict__ col,
+                                 const float *__restrict__ x, const float *__restrict__ xs,
+                                 const float *__restrict__ dinv, int w, int fo)
+    {
+        valid = ok;
+        if (!ok)
+            return;
+        node = nb + r;
+        rp0 = srp[r];
+        rp1 = srp[r + 1];
+        // neighbours 0 and 1; a missing one aliases the self row (cache hit, result discarded)
+        j0 = rp0 < rp1 ? (ecached ? scol[rp0 - eb] : col[rp0]) : node;
+        j1 = rp0 + 1 < rp1 ? (ecached ? scol[rp0 + 1 - eb] : col[rp0 + 1]) : j0;
+        xi = V::load(xs + (size_t)node * w + fo);
+        a = V::load(x + (size_t)j0 * w + fo);
+        b = V::load(x + (size_t)j1 * w + fo);
+        if (MODE == GNNB_AGG_GCN) {
+            di = dinv[node];
+            s0 = dinv[j0];
+            s1 = dinv[j1];
+        }
+    }
+
+    __device__ inline void finish(const int32_t *scol, int eb, bool ecached,
+                                  const int32_t *__restrict__ col, const float *__restrict__ x,
+                                  const float *__restrict__ dinv, float *__restrict__ out, int w,
+                                  int fo, float eps)
+    {
+        if (!valid)
+            return;
+        const int deg = rp1 - rp0;
+        V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
+        auto take = [&](const V &v, float sc, bool first) {
+            if (MODE == GNNB_AGG_GCN) {
+                acc = vadd(acc, vmul(v, V::splat(di * sc)));
+            } else if (MODE == GNNB_AGG_PNA) {
+                const V h = vadd(xi, v);
+                if (first) {
+                    vmx = h;
+                    vmn = h;
+                } else {
+                    vmx = vmax(vmx, h);
+                    vmn = vmin(vmn, h);
+                }
+                acc = vadd(acc, h);
+                s2 = vadd(s2, vmul(h, h));
+            } else {
+                acc = vadd(acc, v);
+            }
+        };
+        if (deg > 0)
+            take(a, s0, true);
+        if (deg > 1)
+            take(b, s1, false);
+        for (int k = rp0 + 2; k < rp1; k++) { // degree > 2: the remaining neighbours, in CSR order
+            const int j = ecached ? scol[k - eb] : col[k];
+            const V v = V::load(x + (size_t)j * w + fo);
+            take(v, (MODE == GNNB_AGG_GCN) ? dinv[j] : 0.0f, false);
+        }
+        if (MODE == GNNB_AGG_GCN) {
+            acc = vadd(acc, vmul(xi, V::splat(di * di)));
+            acc.store(out + (size_t)node * w + fo);
+        } else if (MODE == GNNB_AGG_SUM) {
+            acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
+            acc.store(out + (size_t)node * w + fo);
+        } else if (MODE == GNNB_AGG_MEAN) {
+            if (deg > 0)
+                acc = vdiv(acc, V::splat((float)deg));
+            acc.store(out + (size_t)node * w + fo);
+        } else {
+            V mean = V::splat(0.0f), sd = V::splat(0.0f);
+            if (deg > 0) {
+                const V dn = V::splat((float)deg);
+                mean = vdiv(acc, dn);
+                sd = pyg_std(vdiv(s2, dn), mean);
+            }
+            float *o = out + (size_t)node * 4 * w + fo;
+            vmx.store(o);
+            vmn.store(o + w);
+            mean.store(o + 2 * (size_t)w);
+            sd.store(o + 3 * (size_t)w);
+        }
+    }
+};
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(WG) void k_aggregate_stream(
+    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
+    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const float *__restrict__ dinv, int N, int w, int glog2, int rows_per_wg, int edge_cap, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *srp = reinterpret_cast<int32_t *>(smem);    // [rows_per_wg + 1]
+    int32_t *scol = srp + ((rows_per_wg + 1 + 3) & ~3);  // [edge_cap]
+
+    const int tid = threadIdx.x;
+    const int nb = blockIdx.x * rows_per_wg;
+    const int rows = min(rows_per_wg, N - nb);
+    for (int i = tid; i <= rows; i += WG)
+        srp[i] = row_ptr[nb + i];
+    __syncthreads();
+    const int eb = srp[0];
+    const int nedges = srp[rows] - eb;
+    const bool ecached = nedges <= edge_cap; // workgroup-uniform
+    if (ecached) {
+        for (int i = tid; i < nedges; i += WG)
+            scol[i] = col[eb + i];
+        __syncthreads();
+    }
+
+    const int nvec = w / VEC;
+    const int G = 1 << glog2;
+    const int groups = WG >> glog2;
+    const int grp = tid >> glog2;
+    const int gl = tid & (G - 1);
+    const float *xs = (MODE == GNNB_AGG_PNA) ? selfq : x; // PNA: the self term is q_i, neighbours p_j
+
+    for (int r = grp; r < rows; r += 2 * groups) {
+        for (int f = gl; f < nvec; f += G) {
+            const int fo = f * VEC;
+            AggRow<MODE, VEC> A, B;
+            A.begin(true, nb, r, srp, scol, eb, ecached, col, x, xs, dinv, w, fo);
+            B.begin(r + groups < rows, nb, r + groups, srp, scol, eb, ecached, col, x, xs, dinv, w, fo);
+            A.finish(scol, eb, ecached, col, x, dinv, out, w, fo, eps);
+            B.finish(scol, eb, ecached, col, x, dinv, out, w, fo, eps);
+        }
+    }
+}
+
+template <int MODE, int VEC>
+static hipError_t launch_aggregate_stream_t(const BatchTables &t, const float *x, const float *selfq,
+                                            float *out, int w, float eps, hipStream_t s)
+{
+    const Options &o = options();
+    const int nvec = w / VEC;
+    int glog2 = 2;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    const int rpw = o.agg_rows_per_wg;
+    const int edge_cap = rpw * 6;
+    const size_t lds = (size_t)((rpw + 1 + 3) & ~3) * 4 + (size_t)edge_cap * 4;
+    const int grid = (t.num_nodes + rpw - 1) / rpw;
+    if (grid <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL((k_aggregate_stream<MODE, VEC>), dim3(grid), dim3(WG), lds, s, x, selfq, out,
+                       t.row_ptr, t.col, t.dinv, t.num_nodes, w, glog2, rpw, edge_cap, eps);
+    return hipGetLastError();
+}
+
+
+// -------------------------------------------------------------------------------------
+// Record-streamed variant.  No LDS, no barrier, two dependent memory trips instead
+// of CSR's three: lane k of a lane group reads the 32-byte node record of the group's k-th row
+// ({rp0, deg, j0..j3}, written by graph prep), the records are handed round the group with
+// wave shuffles, and for two destination rows at a time the group issues the self row plus up
+// to four neighbour rows each (ten independent 16-B loads per lane) before consuming any.  A row
+// is fetched from HBM by whoever touches it first; its other ~2 uses hit the XCD's L2, because a
+// graph's rows are contiguous and handled by adjacent lane groups.  Rows of degree > 4 (rare in
+// molecules) finish from the CSR col array.
+template <int MODE, int VEC>
+struct RecRow {
+    typedef Vf<VEC> V;
+    int node, rp0, deg, j[4];
+    float di, sj[4];
+    V xi, nb[4];
+    bool valid;
+
+    __device__ inline void begin(bool ok, int node_, int4 r0, int4 r1, const float *__restrict__ x,
+                                 const float *__restrict__ xs, const float *__restrict__ dinv, int w, int fo)
+    {
+        valid = ok;
+        if (!ok)
+            return;
+        node = node_;
+        rp0 = r0.x;
+        deg = r0.y;
+        j[0] = r0.z;
+        j[1] = r0.w;
+        j[2] = r1.x;
+        j[3] = r1.y;
+        xi = V::load(xs + (size_t)node * w + fo);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            nb[q] = V::load(x + (size_t)j[q] * w + fo); // unused slots alias the self row (cache hit)
+        if (MODE == GNNB_AGG_GCN) {
+            di = dinv[node];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                sj[q] = dinv[j[q]];
+        }
+    }
+
+    __device__ inline void finish(const int32_t *__restrict__ col, const float *__restrict__ x,
+                                  const float *__restrict__ dinv, float *__restrict__ out, int w, int fo, float eps)
+    {
+        if (!valid)
+            return;
+        V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
+        auto take = [&](const V &v, float sc, bool first) {
+            if (MODE == GNNB_AGG_GCN) {
+                acc = vadd(acc, vmul(v, V::splat(di * sc)));
+            } else if (MODE == GNNB_AGG_PNA) {
+                const V h = vadd(xi, v);
+                if (first) {
+                    vmx = h;
+                    vmn = h;
+                } else {
+                    vmx = vmax(vmx, h);
+                    vmn = vmin(vmn, h);
+                }
+                acc = vadd(acc, h);
+                s2 = vadd(s2, vmul(h, h));
+            } else {
+                acc = vadd(acc, v);
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (deg > q)
+                take(nb[q], sj[q], q == 0);
+        for (int k = rp0 + 4; k < rp0 + deg; k++) { // degree > 4: the rest, in CSR order
+            const int jj = col[k];
+            const V v = V::load(x + (size_t)jj * w + fo);
+            take(v, (MODE == GNNB_AGG_GCN) ? dinv[jj] : 0.0f, false);
+        }
+        if (MODE == GNNB_AGG_GCN) {
+            acc = vadd(acc, vmul(xi, V::splat(di * di)));
+            acc.store(out + (size_t)node * w + fo);
+        } else if (MODE == GNNB_AGG_SUM) {
+            acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
+            acc.store(out + (size_t)node * w + fo);
+        } else if (MODE == GNNB_AGG_MEAN) {
+            if (deg > 0)
+                acc = vdiv(acc, V::splat((float)deg));
+            acc.store(out + (size_t)node * w + fo);
+        } else {
+            V mean = V::splat(0.0f), sd = V::splat(0.0f);
+            if (deg > 0) {
+                const V dn = V::splat((float)deg);
+                mean = vdiv(acc, dn);
+                sd = pyg_std(vdiv(s2, dn), mean);
+            }
+            float *o = out + (size_t)node * 4 * w + fo;
+            vmx.store(o);
+            vmn.store(o + w);
+            mean.store(o + 2 * (size_t)w);
+            sd.store(o + 3 * (size_t)w);
+        }
+    }
+};
+
+__device__ inline int4 shfl4(int4 v, int src, int width)
+{
+    return make_int4(__shfl(v.x, src, width), __shfl(v.y, src, width), __shfl(v.z, src, width),
+                     __shfl(v.w, src, width));
+}
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(WG) void k_aggregate_rec(
+    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
+    const int4 *__restrict__ node_rec, const int32_t *__restrict__ col,
+    const float *__restrict__ dinv, int N, int w, int glog2, int rows_per_group, float eps)
+{
+    const int tid = threadIdx.x;
+    const int G = 1 << glog2;
+    const int groups = WG >> glog2;
+    const int grp = tid >> glog2;
+    const int gl = tid & (G - 1);
+    const int nvec = w / VEC;
+    const int nb = blockIdx.x * groups * rows_per_group;
+    const float *xs = (MODE == GNNB_AGG_PNA) ? selfq : x; // PNA: self term q_i, neighbours p_j
+
+    // lane k of the group fetches the record of the group's k-th row: rows nb + grp + k*groups
+    int4 r0 = make_int4(0, 0, 0, 0), r1 = r0;
+    {
+        const int my = nb + grp + gl * groups;
+        if (gl < rows_per_group && my < N) {
+            r0 = node_rec[2 * (size_t)my];
+            r1 = node_rec[2 * (size_t)my + 1];
+        }
+    }
+    for (int k = 0; k < rows_per_group; k += 2) {
+        const int nodeA = nb + grp + k * groups;
+        const int nodeB = nodeA + groups;
+        if (nodeA >= N)
+            break; // group-uniform, and rows only grow
+        const int4 a0 = shfl4(r0, k, G), a1 = shfl4(r1, k, G);
+        const int4 b0 = shfl4(r0, k + 1, G), b1 = shfl4(r1, k + 1, G);
+        const bool okB = (k + 1 < rows_per_group) && nodeB < N;
+        for (int f = gl; f < nvec; f += G) {
+            const int fo = f * VEC;
+            RecRow<MODE, VEC> A, B;
+            A.begin(true, nodeA, a0, a1, x, xs, dinv, w, fo);
+            B.begin(okB, nodeB, b0, b1, x, xs, dinv, w, fo);
+            A.finish(col, x, dinv, out, w, fo, eps);
+            B.finish(col, x, dinv, out, w, fo, eps);
+        }
+    }
+}
+
+template <int MODE, int VEC>
+static hipError_t launch_aggregate_rec_t(const BatchTables &t, const float *x, const float *selfq,
+                                         float *out, int w, float eps, hipStream_t s)
+{
+    const Options &o = options();
+    const int nvec = w / VEC;
+    int glog2 = 2;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    const int G = 1 << glog2, groups = WG >> glog2;
+    int rpg = o.agg_rows_per_wg / groups; // rows per lane group
+    if (rpg < 2)
+        rpg = 2;
+    if (rpg > G)
+        rpg = G; // one record per lane
+    rpg &= ~1;
+    const int rows_per_wg = rpg * groups;
+    const int grid = (t.num_nodes + rows_per_wg - 1) / rows_per_wg;
+    if (grid <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL((k_aggregate_rec<MODE, VEC>), dim3(grid), dim3(WG), 0, s, x, selfq, out,
+                       t.node_rec, t.col, t.dinv, t.num_nodes, w, glog2, rpg, eps);
+    return hipGetLastError();
+}
+
+
+// -------------------------------------------------------------------------------------
+// LDS-DMA single-burst variant.  Each feature row crosses the vector-memory path exactly
+// once.  The grid is sized so that every workgroup is resident at the same time (two per CU at
+// the default LDS budget) and owns a contiguous run of node tiles = a few dozen whole graphs.
+// Phase 1: all four waves fire `global_load_lds` (LDS-DMA, no VGPR staging) for the whole run:
+//   feature rows in 1-KiB pieces, plus the row_ptr / col / dinv slices -- up to ~80 KB in flight
+//   per workgroup, the deepest read burst the CU can hold.
+// Phase 2 (after one barrier): lane groups reduce each destination row from LDS in CSR order and
+//   stream the result out with 16-B coalesced stores.
+// A run that does not fit the LDS budget (a very large graph) takes the same arithmetic with
+// rows read straight from global memory.
+typedef __attribute__((address_space(3))) void *lds_vptr;
+typedef const __attribute__((address_space(1))) void *glb_vptr;
+
+// LDS destination = wave-uniform base + lane * size (cdna_hip_programming.md section 5, Caveat);
+// the size argument must be a literal, so one function per width.
+__device__ inline void dma16_to_lds(const void *gsrc_lane, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((glb_vptr)gsrc_lane, (lds_vptr)lds_wave_base, 16, 0, 0);
+}
+__device__ inline void dma4_to_lds(const void *gsrc_lane, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((glb_vptr)gsrc_lane, (lds_vptr)lds_wave_base, 4, 0, 0);
+}
+
+// copy `count` dwords global -> LDS, spread over the workgroup's waves, 64 dwords per instruction
+__device__ inline void dma_dwords(const void *g, void *l, int count, int wave, int lane, int nwaves)
+{
+    const char *gs = reinterpret_cast<const char *>(g);
+    char *ls = reinterpret_cast<char *>(l);
+    for (int c = wave * 64; c < count; c += nwaves * 64)
+        if (c + lane < count)
+            dma4_to_lds(gs + (size_t)(c + lane) * 4, ls + (size_t)c * 4);
+}
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(WG) void k_aggregate_dma(
+    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
+    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const float *__restrict__ dinv, const int32_t *__restrict__ tile_first,
+    const int32_t *__restrict__ tile_edge, int num_tiles, int w, int glog2, int rows_cap,
+    int edge_cap, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sx = reinterpret_cast<float *>(smem);                          // [rows_cap * w]
+    int32_t *srp = reinterpret_cast<int32_t *>(sx + (size_t)rows_cap * w); // [rows_cap + 1]
+    float *sdinv = reinterpret_cast<float *>(srp + ((rows_cap + 1 + 3) & ~3)); // [rows_cap]
+    int32_t *scol = reinterpret_cast<int32_t *>(sdinv + ((rows_cap + 3) & ~3)); // [edge_cap]
+    typedef Vf<VEC> V;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // balanced contiguous tile ranges: workgroup b owns tiles [b*T/G, (b+1)*T/G)
+    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
+    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    if (t1 <= t0)
+        return;
+    const int nb = tile_first[t0], ne = tile_first[t1];
+    const int eb = tile_edge[t0], nedges = tile_edge[t1] - eb;
+    const int rows = ne - nb;
+    if (rows <= 0)
+        return;
+    const bool staged = rows <= rows_cap;    // workgroup-uniform
+    const bool ecached = nedges <= edge_cap; // workgroup-uniform
+    GNNB_STAMP(0);
+
+    if (staged) {
+        const char *gsrc = reinterpret_cast<const char *>(x + (size_t)nb * w);
+        char *ldst = reinterpret_cast<char *>(sx);
+        const int bytes = rows * w * 4;
+        if (VEC == 4) {
+            for (int c = wave * 1024; c < bytes; c += (WG / 64) * 1024)
+                if (c + lane * 16 < bytes)
+                    dma16_to_lds(gsrc + c + lane * 16, ldst + c);
+        } else {
+            dma_dwords(gsrc, ldst, rows * w, wave, lane, WG / 64);
+        }
+        dma_dwords(row_ptr + nb, srp, rows + 1, wave, lane, WG / 64);
+        if (MODE == GNNB_AGG_GCN)
+            dma_dwords(dinv + nb, sdinv, rows, wave, lane, WG / 64);
+    }
+    if (ecached)
+        dma_dwords(col + eb, scol, nedges, wave, lane, WG / 64);
+    GNNB_STAMP(1);
+    __syncthreads(); // the fence drains vmcnt (every DMA has landed) before the barrier releases
+    GNNB_STAMP(2);
+
+    const int nvec = w / VEC;
+    const int G = 1 << glog2;
+    const int groups = WG >> glog2;
+    const int grp = tid >> glog2;
+    const int gl = tid & (G - 1);
+
+    for (int r = grp; r < rows; r += groups) {
+        const int node = nb + r;
+        const int rp0 = staged ? srp[r] : row_ptr[node];
+        const int rp1 = staged ? srp[r + 1] : row_ptr[node + 1];
+        const int deg = rp1 - rp0;
+        float di = 0.0f;
+        if (MODE == GNNB_AGG_GCN)
+            di = staged ? sdinv[r] : dinv[node];
+        for (int f = gl; f < nvec; f += G) {
+            const int fo = f * VEC;
+            V xi;
+            if (MODE == GNNB_AGG_PNA)
+                xi = V::load(selfq + (size_t)node * w + fo);
+            else
+                xi = staged ? V::load(sx + (size_t)r * w + fo) : V::load(x + (size_t)node * w + fo);
+            V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
+            for (int k = rp0; k < rp1; k++) {
+                const int j = ecached ? scol[k - eb] : col[k];
+                const int jr = j - nb;
+                const V xj = staged ? V::load(sx + (size_t)jr * w + fo) : V::load(x + (size_t)j * w + fo);
+                if (MODE == GNNB_AGG_GCN) {
+                    const float dj = staged ? sdinv[jr] : dinv[j];
+                    acc = vadd(acc, vmul(xj, V::splat(di * dj)));
+                } else if (MODE == GNNB_AGG_PNA) {
+                    const V h = vadd(xi, xj);
+                    if (k == rp0) {
+                        vmx = h;
+                        vmn = h;
+                    } else {
+                        vmx = vmax(vmx, h);
+                        vmn = vmin(vmn, h);
+                    }
+                    acc = vadd(acc, h);
+                    s2 = vadd(s2, vmul(h, h));
+                } else {
+                    acc = vadd(acc, xj);
+                }
+            }
+            if (MODE == GNNB_AGG_GCN) {
+                acc = vadd(acc, vmul(xi, V::splat(di * di)));
+                acc.store(out + (size_t)node * w + fo);
+            } else if (MODE == GNNB_AGG_SUM) {
+                acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
+                acc.store(out + (size_t)node * w + fo);
+            } else if (MODE == GNNB_AGG_MEAN) {
+                if (deg > 0)
+                    acc = vdiv(acc, V::splat((float)deg));
+                acc.store(out + (size_t)node * w + fo);
+            } else {
+                V mean = V::splat(0.0f), sd = V::splat(0.0f);
+                if (deg > 0) {
+                    const V dn = V::splat((float)deg);
+                    mean = vdiv(acc, dn);
+                    sd = pyg_std(vdiv(s2, dn), mean);
+                }
+                float *o = out + (size_t)node * 4 * w + fo;
+                vmx.store(o);
+                vmn.store(o + w);
+                mean.store(o + 2 * (size_t)w);
+                sd.store(o + 3 * (size_t)w);
+            }
+        }
+    }
+    GNNB_STAMP_END(3);
+}
+
+template <int MODE, int VEC>
+static hipError_t launch_aggregate_dma_t(const BatchTables &t, const float *x, const float *selfq,
+                                         float *out, int w, float eps, hipStream_t s)
+{
+    const Options &o = options();
+    const int nvec = w / VEC;
+    int glog2 = 2;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    if (t.num_tiles <= 0)
+        return hipSuccess;
+    // LDS budget per workgroup -> rows it can stage (row + row_ptr + dinv + ~4 col entries each)
+    const size_t budget = (size_t)o.agg_lds_kb * 1024;
+    int rows_cap = (int)(budget / ((size_t)w * 4 + 24)) & ~3;
+    if (rows_cap < 8)
+        rows_cap = 8;
+    // grid: every workgroup resident at once when the batch allows it, else as many as needed
+    // for a workgroup's run (plus the graph straddling its end) to fit the budget
+    const int margin = t.tile_rows + o.agg_overshoot;
+    const int usable = rows_cap > 2 * margin ? rows_cap - margin : rows_cap / 2;
+    long long grid = ((long long)t.num_nodes + usable - 1) / usable;
+    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (budget + 1024)));
+    const long long resident = 256LL * wg_per_cu;
+    if (grid < resident)
+        grid = resident;
+    if (grid > t.num_tiles)
+        grid = t.num_tiles;
+    // shrink the allocation to what a run of this grid actually needs
+    const int need = (int)(((long long)t.num_nodes + grid - 1) / grid) + margin;
+    if (rows_cap > need)
+        rows_cap = (need + 3) & ~3;
+    const int edge_cap = rows_cap * 4;
+    const size_t lds = (size_t)rows_cap * w * 4 + (size_t)((rows_cap + 1 + 3) & ~3) * 4 +
+                       (size_t)((rows_cap + 3) & ~3) * 4 + (size_t)edge_cap * 4;
+    auto kern = k_aggregate_dma<MODE, VEC>;
+    static size_t lds_allowed = 64 * 1024; // per instantiation
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, x, selfq, out, t.row_ptr, t.col,
+                       t.dinv, t.tile_first, t.tile_edge, t.num_tiles, w, glog2, rows_cap, edge_cap, eps);
+    return hipGetLastError();
+}
+
+
+// -------------------------------------------------------------------------------------
+// Pipelined LDS-DMA variant.  The chip's whole LDS (256 x 160 KiB) is about the size of one
+// feature matrix, so the rows cannot all be resident at once: instead every workgroup is
+// persistent (grid = what fits the chip), owns a contiguous run of node tiles and walks it in
+// stages of whole graphs that fit one LDS buffer.  Two buffers: while the lane groups reduce
+// stage s from one, the LDS-DMA engine (global_load_lds, no VGPRs) fills the other with stage
+// s+1 -- feature rows, their 32-B node records and the dinv slice.  Each feature row crosses the
+// vector-memory path exactly once; every gather is an LDS read; one barrier per stage.
+struct PipeStage {
+    int ta, tb;   // tiles [ta, tb)
+    int nb, rows; // node range
+    bool staged;  // fits the LDS buffer
+};
+
+template <int MODE, int VEC>
+struct LdsRow {
+    typedef Vf<VEC> V;
+    int node, r, rp0, deg, jr[4];
+    float di, sj[4];
+    V xi, nbv[4];
+    bool valid;
+
+    __device__ inline void begin(bool ok, int nb, int r_, const float *sx, const int4 *srec,
+                                 const float *sdinv, const float *__restrict__ selfq, int w, int fo)
+    {
+        valid = ok;
+        if (!ok)
+            return;
+        r = r_;
+        node = nb + r_;
+        const int4 r0 = srec[2 * r_], r1 = srec[2 * r_ + 1];
+        rp0 = r0.x;
+        deg = r0.y;
+        jr[0] = r0.z - nb;
+        jr[1] = r0.w - nb;
+        jr[2] = r1.x - nb;
+        jr[3] = r1.y - nb;
+        if (MODE == GNNB_AGG_PNA)
+            xi = V::load(selfq + (size_t)node * w + fo);
+        else
+            xi = V::load(sx + (size_t)r_ * w + fo);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            nbv[q] = V::load(sx + (size_t)jr[q] * w + fo); // unused slots alias the row itself
+        if (MODE == GNNB_AGG_GCN) {
+            di = sdinv[r_];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                sj[q] = sdinv[jr[q]];
+        }
+    }
+
+    __device__ inline void finish(int nb, const float *sx, const float *sdinv,
+                                  const int32_t *__restrict__ col, float *__restrict__ out, int w, int fo,
+                                  float eps)
+    {
+        if (!valid)
+            return;
+        V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
+        auto take = [&](const V &v, float sc, bool first) {
+            if (MODE == GNNB_AGG_GCN) {
+                acc = vadd(acc, vmul(v, V::splat(di * sc)));
+            } else if (MODE == GNNB_AGG_PNA) {
+                const V h = vadd(xi, v);
+                if (first) {
+                    vmx = h;
+                    vmn = h;
+                } else {
+                    vmx = vmax(vmx, h);
+                    vmn = vmin(vmn, h);
+                }
+                acc = vadd(acc, h);
+                s2 = vadd(s2, vmul(h, h));
+            } else {
+                acc = vadd(acc, v);
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (deg > q)
+                take(nbv[q], sj[q], q == 0);
+        for (int k = rp0 + 4; k < rp0 + deg; k++) { // degree > 4: the rest of the CSR row
+            const int j = col[k] - nb;
+            const V v = V::load(sx + (size_t)j * w + fo);
+            take(v, (MODE == GNNB_AGG_GCN) ? sdinv[j] : 0.0f, false);
+        }
+        if (MODE == GNNB_AGG_GCN) {
+            acc = vadd(acc, vmul(xi, V::splat(di * di)));
+            acc.store(out + (size_t)node * w + fo);
+        } else if (MODE == GNNB_AGG_SUM) {
+            acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
+            acc.store(out + (size_t)node * w + fo);
+        } else if (MODE == GNNB_AGG_MEAN) {
+            if (deg > 0)
+                acc = vdiv(acc, V::splat((float)deg));
+            acc.store(out + (size_t)node * w + fo);
+        } else {
+            V mean = V::splat(0.0f), sd = V::splat(0.0f);
+            if (deg > 0) {
+                const V dn = V::splat((float)deg);
+                mean = vdiv(acc, dn);
+                sd = pyg_std(vdiv(s2, dn), mean);
+            }
+            float *o = out + (size_t)node * 4 * w + fo;
+            vmx.store(o);
+            vmn.store(o + w);
+            mean.store(o + 2 * (size_t)w);
+            sd.store(o + 3 * (size_t)w);
+        }
+    }
+};
+
+static constexpr int PIPE_TCAP = 512; // tile-table entries a workgroup keeps in LDS
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(WG) void k_aggregate_pipe(
+    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
+    const int4 *__restrict__ node_rec, const int32_t *__restrict__ row_ptr,
+    const int32_t *__restrict__ col, const float *__restrict__ dinv,
+    const int32_t *__restrict__ tile_first, int num_tiles, int w, int glog2, int rows_cap, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // one buffer = [rows_cap*w floats | rows_cap*2 int4 | rows_cap floats]
+    const size_t buf_bytes = ((size_t)rows_cap * w * 4 + (size_t)rows_cap * 32 + (size_t)rows_cap * 4 + 15) & ~(size_t)15;
+    int32_t *stile = reinterpret_cast<int32_t *>(smem + 2 * buf_bytes); // [PIPE_TCAP + 1]
+    typedef Vf<VEC> V;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
+    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    if (t1 <= t0)
+        return;
+    for (int i = tid; i <= t1 - t0; i += WG)
+        stile[i] = tile_first[t0 + i];
+    __syncthreads();
+
+    auto plan = [&](int ta) {
+        PipeStage st;
+        st.ta = ta;
+        st.tb = ta;
+        st.nb = 0;
+        st.rows = 0;
+        st.staged = true;
+        if (ta >= t1)
+            return st;
+        st.nb = stile[ta - t0];
+        int tb = ta + 1;
+        // whole tiles while they fit one buffer
+        while (tb < t1 && stile[tb + 1 - t0] - st.nb <= rows_cap)
+            tb++;
+        st.tb = tb;
+        st.rows = stile[tb - t0] - st.nb;
+        st.staged = st.rows <= rows_cap; // a single tile larger than the buffer: direct path
+        return st;
+    };
+    auto issue = [&](const PipeStage &st, int b) {
+        if (!st.staged || st.rows <= 0)
+            return;
+        char *base = smem + (size_t)b * buf_bytes;
+        char *lx = base;
+        char *lrec = base + (size_t)rows_cap * w * 4;
+        char *ldinv = lrec + (size_t)rows_cap * 32;
+        const char *gx = reinterpret_cast<const char *>(x + (size_t)st.nb * w);
+        const int bytes = st.rows * w * 4;
+        if (VEC == 4) {
+            for (int c = wave * 1024; c < bytes; c += (WG / 64) * 1024)
+                if (c + lane * 16 < bytes)
+                    dma16_to_lds(gx + c + lane * 16, lx + c);
+        } else {
+            dma_dwords(gx, lx, st.rows * w, wave, lane, WG / 64);
+        }
+        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
+        const int rbytes = st.rows * 32;
+        for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
+            if (c + lane * 16 < rbytes)
+                dma16_to_lds(grec + c + lane * 16, lrec + c);
+        if (MODE == GNNB_AGG_GCN)
+            dma_dwords(dinv + st.nb, ldinv, st.rows, wave, lane, WG / 64);
+    };
+
+    const int nvec = w / VEC;
+    const int G = 1 << glog2;
+    const int groups = WG >> glog2;
+    const int grp = tid >> glog2;
+    const int gl = tid & (G - 1);
+
+    PipeStage cur = plan(t0);
+    issue(cur, 0);
+    int b = 0;
+    while (cur.ta < t1) {
+        const PipeStage nxt = plan(cur.tb);
+        __syncthreads(); // drains vmcnt: stage `cur` has landed; every wave is done with the other buffer
+        issue(nxt, b ^ 1);
+        if (cur.staged) {
+            const char *base = smem + (size_t)b * buf_bytes;
+            const float *sx = reinterpret_cast<const float *>(base);
+            const int4 *srec = reinterpret_cast<const int4 *>(base + (size_t)rows_cap * w * 4);
+            const float *sdinv = reinterpret_cast<const float *>(base + (size_t)rows_cap * w * 4 + (size_t)rows_cap * 32);
+            for (int r = grp; r < cur.rows; r += 2 * groups) {
+                for (int f = gl; f < nvec; f += G) {
+                    const int fo = f * VEC;
+                    LdsRow<MODE, VEC> A, B;
+                    A.begin(true, cur.nb, r, sx, srec, sdinv, selfq, w, fo);
+                    B.begin(r + groups < cur.rows, cur.nb, r + groups, sx, srec, sdinv, selfq, w, fo);
+                    A.finish(cur.nb, sx, sdinv, col, out, w, fo, eps);
+                    B.finish(cur.nb, sx, sdinv, col, out, w, fo, eps);
+                }
+            }
+        } else {
+            // a graph larger than the LDS buffer: same arithmetic straight from global memory
+            for (int r = grp; r < cur.rows; r += groups) {
+                const int node = cur.nb + r;
+                const int rp0 = row_ptr[node], rp1 = row_ptr[node + 1];
+                const int deg = rp1 - rp0;
+                const float di = (MODE == GNNB_AGG_GCN) ? dinv[node] : 0.0f;
+                for (int f = gl; f < nvec; f += G) {
+                    const int fo = f * VEC;
+                    const V xi = V::load((MODE == GNNB_AGG_PNA ? selfq : x) + (size_t)node * w + fo);
+                    V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
+                    for (int k = rp0; k < rp1; k++) {
+                        const int j = col[k];
+                        const V xj = V::load(x + (size_t)j * w + fo);
+                        if (MODE == GNNB_AGG_GCN) {
+                            acc = vadd(acc, vmul(xj, V::splat(di * dinv[j])));
+                        } else if (MODE == GNNB_AGG_PNA) {
+                            const V h = vadd(xi, xj);
+                            vmx = (k == rp0) ? h : vmax(vmx, h);
+                            vmn = (k == rp0) ? h : vmin(vmn, h);
+                            acc = vadd(acc, h);
+                            s2 = vadd(s2, vmul(h, h));
+                        } else {
+                            acc = vadd(acc, xj);
+                        }
+                    }
+                    if (MODE == GNNB_AGG_GCN) {
+                        vadd(acc, vmul(xi, V::splat(di * di))).store(out + (size_t)node * w + fo);
+                    } else if (MODE == GNNB_AGG_SUM) {
+                        vadd(acc, vmul(xi, V::splat(1.0f + eps))).store(out + (size_t)node * w + fo);
+                    } else if (MODE == GNNB_AGG_MEAN) {
+                        (deg > 0 ? vdiv(acc, V::splat((float)deg)) : acc).store(out + (size_t)node * w + fo);
+                    } else {
+                        V mean = V::splat(0.0f), sd = V::splat(0.0f);
+                        if (deg > 0) {
+                            mean = vdiv(acc, V::splat((float)deg));
+                            sd = pyg_std(vdiv(s2, V::splat((float)deg)), mean);
+                        }
+                        float *o = out + (size_t)node * 4 * w + fo;
+                        vmx.store(o);
+                        vmn.store(o + w);
+                        mean.store(o + 2 * (size_t)w);
+                        sd.store(o + 3 * (size_t)w);
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        b ^= 1;
+    }
+}
+
+template <int MODE, int VEC>
+static hipError_t launch_aggregate_pipe_t(const BatchTables &t, const float *x, const float *selfq,
+                                          float *out, int w, float eps, hipStream_t s)
+{
+    const Options &o = options();
+    const int nvec = w / VEC;
+    int glog2 = 2;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    if (t.num_tiles <= 0)
+        return hipSuccess;
+    // two LDS buffers per workgroup inside the per-workgroup budget
+    const size_t budget = (size_t)o.agg_lds_kb * 1024;
+    const size_t per_row = (size_t)w * 4 + 32 + 4;
+    int rows_cap = (int)((budget - (PIPE_TCAP + 1) * 4 - 64) / 2 / per_row) & ~3;
+    if (rows_cap < 8)
+        rows_cap = 8;
+    const size_t buf_bytes = ((size_t)rows_cap * per_row + 15) & ~(size_t)15;
+    const size_t lds = 2 * buf_bytes + (PIPE_TCAP + 1) * 4;
+    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
+    long long grid = 256LL * wg_per_cu; // persistent: everything resident
+    if (grid > t.num_tiles)
+        grid = t.num_tiles;
+    const long long min_grid = ((long long)t.num_tiles + PIPE_TCAP - 2) / (PIPE_TCAP - 1);
+    if (grid < min_grid)
+        grid = min_grid; // a workgroup's tile table must fit its LDS copy
+    auto kern = k_aggregate_pipe<MODE, VEC>;
+    static size_t lds_allowed = 64 * 1024; // per instantiation
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, x, selfq, out, t.node_rec, t.row_ptr,
+                       t.col, t.dinv, t.tile_first, t.num_tiles, w, glog2, rows_cap, eps);
+    return hipGetLastError();
+}
+
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s)
 {
     const bool v4 = (width % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0) &&
                     (selfq == nullptr || ((uintptr_t)selfq & 15) == 0);
+    const bool stream = options().agg_variant == 0;
+    const bool rec = options().agg_variant == 3;
+    const bool dma = options().agg_variant == 4;
+    const bool pipe = options().agg_variant == 2;
 #define GNNB_AGG_CASE(K)                                                                         \
     case K:                                                                                      \
+        if (pipe)                                                                                \
+            return v4 ? launch_aggregate_pipe_t<K, 4>(t, x, selfq, out, width, eps, s)           \
+                      : launch_aggregate_pipe_t<K, 1>(t, x, selfq, out, width, eps, s);          \
+        if (dma)                                                                                 \
+            return v4 ? launch_aggregate_dma_t<K, 4>(t, x, selfq, out, width, eps, s)            \
+                      : launch_aggregate_dma_t<K, 1>(t, x, selfq, out, width, eps, s);           \
+        if (rec)                                                                                 \
+            return v4 ? launch_aggregate_rec_t<K, 4>(t, x, selfq, out, width, eps, s)            \
+                      : launch_aggregate_rec_t<K, 1>(t, x, selfq, out, width, eps, s);           \
+        if (stream)                                                                              \
+            return v4 ? launch_aggregate_stream_t<K, 4>(t, x, selfq, out, width, eps, s)         \
+                      : launch_aggregate_stream_t<K, 1>(t, x, selfq, out, width, eps, s);        \
         return v4 ? launch_aggregate_t<K, 4>(t, x, selfq, out, width, eps, s)                    \
                   : launch_aggregate_t<K, 1>(t, x, selfq, out, width, eps, s);
     switch (kind) {
@@ -738,5 +1656,12 @@ hipError_t launch_global_pool(const float *x, const int32_t *node_ptr, int num_g
                            glog2, p0, p1, p2, num_pools, out);
     return hipGetLastError();
 }
+
+#ifdef GNNB_PROBE
+extern "C" int gnnb_probe_read(unsigned long long *host, int count)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * count);
+}
+#endif
 
 } // namespace gnnb

@@ -51,8 +51,9 @@ static int env_int(const char *name, int dflt)
 
 Options &options()
 {
-    static Options o = {env_int("GNNB_TILE_ROWS", 32), env_int("GNNB_AGG_LDS_KB", 48),
-                        env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32)};
+    static Options o = {env_int("GNNB_TILE_ROWS", 16), env_int("GNNB_AGG_LDS_KB", 39),
+                        env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32),
+                        env_int("GNNB_AGG_VARIANT", 0),      env_int("GNNB_AGG_ROWS_PER_WG", 48)};
     return o;
 }
 
@@ -185,6 +186,10 @@ int gnnb_set_option(const char *name, int value)
         o.agg_tiles_per_wg = value;
     else if (!strcmp(name, "agg_overshoot") && value >= 0)
         o.agg_overshoot = value;
+    else if (!strcmp(name, "agg_variant") && value >= 0 && value <= 4)
+        o.agg_variant = value;
+    else if (!strcmp(name, "agg_rows_per_wg") && value >= 8 && value <= 4096)
+        o.agg_rows_per_wg = value;
     else
         return fail(GNNB_ERR_INVALID, "unknown option or bad value: %s=%d", name, value);
     return GNNB_OK;
@@ -346,8 +351,8 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
         return o;
     };
     const size_t N = max_nodes, E = std::max(max_edges, 1), B = max_graphs;
-    const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_amp = carve(N * 4),
-                 o_att = carve(N * 4), o_tile = carve((max_tiles + 1) * 4), o_err = carve(4),
+    const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
+                 o_att = carve(N * 4), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_err = carve(4),
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
                  o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
                  o_pool = carve(B * pooledw * 4), o_m0 = carve(B * mlpw * 4),
@@ -362,9 +367,12 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     char *b = ws->blob;
     ws->t.row_ptr = (int32_t *)(b + o_rp);
     ws->t.col = (int32_t *)(b + o_col);
+    ws->t.node_rec = (int4 *)(b + o_rec);
+    ws->t.dinv = (float *)(b + o_dinv);
     ws->t.amp = (float *)(b + o_amp);
     ws->t.att = (float *)(b + o_att);
     ws->t.tile_first = (int32_t *)(b + o_tile);
+    ws->t.tile_edge = (int32_t *)(b + o_tedge);
     ws->t.err = (int32_t *)(b + o_err);
     ws->act[0] = (float *)(b + o_a0);
     ws->act[1] = (float *)(b + o_a1);
@@ -691,6 +699,67 @@ int gnnb_forward_batched_host(const gnnb_model *model, gnnb_workspace *ws, const
     ws->t.node_ptr = nullptr; // the temporary ptr array dies with this call
     ws->prepared = false;
     (void)hipFree(dev);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+int gnnb_aggregate_timed(gnnb_workspace *ws, int agg_kind, const float *const *x_dev_list,
+                         const float *self_dev, float *const *out_dev_list, int nbuf, int width,
+                         float eps, int iters, void *stream, float *out_us_per_launch)
+{
+    if (!x_dev_list || !out_dev_list || nbuf < 1 || iters < 1 || !out_us_per_launch)
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_aggregate_timed");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    GNNB_HIP_TRY(hipEventCreate(&e0));
+    GNNB_HIP_TRY(hipEventCreate(&e1));
+    int rc = GNNB_OK;
+    for (int i = 0; i < nbuf && rc == GNNB_OK; i++) // warm-up, also touches every buffer
+        rc = gnnb_aggregate(ws, agg_kind, x_dev_list[i], self_dev, out_dev_list[i], width, eps, stream);
+    if (rc == GNNB_OK) {
+        GNNB_HIP_TRY(hipStreamSynchronize(s));
+        GNNB_HIP_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters && rc == GNNB_OK; i++)
+            rc = gnnb_aggregate(ws, agg_kind, x_dev_list[i % nbuf], self_dev, out_dev_list[i % nbuf], width,
+                                eps, stream);
+        GNNB_HIP_TRY(hipEventRecord(e1, s));
+        GNNB_HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        GNNB_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *out_us_per_launch = ms * 1000.0f / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int gnnb_linear_timed(const float *a_dev, int lda, int k, const float *w_dev, int ldw,
+                      const float *bias_dev, float *y_dev, int M, int N, int act, int iters,
+                      void *stream, float *out_us_per_launch)
+{
+    if (iters < 1 || !out_us_per_launch)
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_linear_timed");
+    hipStream_t s = (hipStream_t)stream;
+    gnnb_gemm_seg seg = {a_dev, nullptr, lda, k};
+    hipEvent_t e0, e1;
+    GNNB_HIP_TRY(hipEventCreate(&e0));
+    GNNB_HIP_TRY(hipEventCreate(&e1));
+    int rc = GNNB_OK;
+    for (int i = 0; i < 3 && rc == GNNB_OK; i++)
+        rc = gnnb_linear(&seg, 1, w_dev, ldw, bias_dev, nullptr, y_dev, M, N, act, stream);
+    if (rc == GNNB_OK) {
+        GNNB_HIP_TRY(hipStreamSynchronize(s));
+        GNNB_HIP_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters && rc == GNNB_OK; i++)
+            rc = gnnb_linear(&seg, 1, w_dev, ldw, bias_dev, nullptr, y_dev, M, N, act, stream);
+        GNNB_HIP_TRY(hipEventRecord(e1, s));
+        GNNB_HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        GNNB_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *out_us_per_launch = ms * 1000.0f / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return rc;
 }
 

@@ -18,7 +18,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libgnnb_hip.so"
+LIB_PATH = Path(os.environ.get("GNNB_HIP_LIB", PKG_DIR / "libgnnb_hip.so"))  # override: diagnostic builds only
 CSRC_DIR = PKG_DIR / "csrc"
 
 CONV = {"gcn": 0, "gin": 1, "sage": 2, "pna": 3}
@@ -71,6 +71,7 @@ EXPORTED_SYMBOLS = [
     "gnnb_graph_prep", "gnnb_graph_tables_to_host", "gnnb_aggregate", "gnnb_linear", "gnnb_global_pool",
     "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
     "gnnb_malloc", "gnnb_free", "gnnb_memcpy_h2d", "gnnb_memcpy_d2h", "gnnb_set_option",
+    "gnnb_aggregate_timed", "gnnb_linear_timed",
 ]
 
 
@@ -127,6 +128,11 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
         lib.gnnb_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         lib.gnnb_stream_sync.argtypes = [C.c_void_p]
         lib.gnnb_set_option.argtypes = [C.c_char_p, C.c_int]
+        lib.gnnb_aggregate_timed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_int, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+        lib.gnnb_linear_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.POINTER(C.c_float)]
         _lib = lib
     if require_gpu and _lib.gnnb_device_count() <= 0:
         raise GnnbUnavailable("libgnnb_hip.so loaded but no MI355X (HIP device) is visible; "
@@ -294,6 +300,18 @@ class CompiledModel:
                                        float(eps), _stream_ptr(stream)))
         return out
 
+    def aggregate_timed(self, kind: str, xs, outs, iters: int, self_term=None, eps: float = 0.0, stream=None) -> float:
+        """Mean microseconds per launch over ``iters`` back-to-back launches issued from C,
+        rotating over the (x, out) buffer pairs; HIP events on the launch stream."""
+        n = len(xs)
+        xa = (C.c_void_p * n)(*[_dptr(t) for t in xs])
+        oa = (C.c_void_p * n)(*[_dptr(t) for t in outs])
+        us = C.c_float()
+        _check(self.lib.gnnb_aggregate_timed(self._ws, AGG[kind], xa, _dptr(self_term) if self_term is not None else None,
+                                             oa, n, int(xs[0].shape[1]), float(eps), int(iters), _stream_ptr(stream),
+                                             C.byref(us)))
+        return float(us.value)
+
     def global_pool(self, x, pools: Sequence[str], out=None, stream=None):
         import torch
         d = int(x.shape[1])
@@ -323,6 +341,16 @@ def linear(segments, weight, bias=None, skip=None, act: str = "none", out=None, 
                            _dptr(skip) if skip is not None else None, _dptr(out), M, N, ACT[act],
                            _stream_ptr(stream)))
     return out
+
+
+def linear_timed(a, weight, bias, out, act: str, iters: int, stream=None) -> float:
+    """Mean microseconds per launch of one ``gnnb_linear`` configuration, launched from C."""
+    lib = load_library(require_gpu=True)
+    us = C.c_float()
+    _check(lib.gnnb_linear_timed(_dptr(a), int(a.stride(0)), int(a.shape[1]), _dptr(weight), int(weight.stride(0)),
+                                 _dptr(bias) if bias is not None else None, _dptr(out), int(a.shape[0]),
+                                 int(weight.shape[0]), ACT[act], int(iters), _stream_ptr(stream), C.byref(us)))
+    return float(us.value)
 
 
 class HipTimer:

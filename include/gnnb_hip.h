@@ -187,6 +187,18 @@ int gnnb_event_record(void *event, void *stream);
 int gnnb_event_elapsed_ms(void *start, void *stop, float *out_ms); /* synchronises on stop */
 void gnnb_event_destroy(void *event);
 
+/* Launch gnnb_aggregate `iters` times back to back from C (host launch cost ~3.6 us, below the
+ * kernel's duration, so the stream stays busy) rotating over `nbuf` input/output buffers, and
+ * return the mean wall time per launch between two HIP events on `stream`.  Measurement aid for
+ * bench.py's roofline object; synchronises. */
+int gnnb_aggregate_timed(gnnb_workspace *ws, int agg_kind, const float *const *x_dev_list,
+                         const float *self_dev, float *const *out_dev_list, int nbuf, int width,
+                         float eps, int iters, void *stream, float *out_us_per_launch);
+/* Same for one gnnb_linear configuration (single segment). */
+int gnnb_linear_timed(const float *a_dev, int lda, int k, const float *w_dev, int ldw,
+                      const float *bias_dev, float *y_dev, int M, int N, int act, int iters,
+                      void *stream, float *out_us_per_launch);
+
 /* device memory helpers for hosts without another allocator (the generated C harness) */
 int gnnb_malloc(void **out_dev, size_t bytes);
 void gnnb_free(void *dev);

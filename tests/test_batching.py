@@ -1,0 +1,74 @@
+"""Host logic: packing graphs into the batched layout, slicing, node-balanced sharding."""
+import numpy as np
+import pytest
+
+from gnnbuilder_amd import synthetic
+from gnnbuilder_amd.batching import pack_graphs, shard_batch, shard_bounds
+
+
+def test_pack_roundtrip_and_validate():
+    rng = np.random.default_rng(0)
+    graphs = []
+    for n in (3, 1, 0, 7):
+        e = rng.integers(0, max(n, 1), size=(2 * n, 2)) if n else np.zeros((0, 2), np.int64)
+        graphs.append((rng.uniform(-1, 1, (n, 5)).astype(np.float32), e))
+    b = pack_graphs(graphs)
+    b.validate()
+    assert b.num_graphs == 4 and b.num_nodes == 11 and b.num_edges == sum(g[1].shape[0] for g in graphs)
+    for g, (x, e) in enumerate(graphs):
+        xg, cg = b.graph(g)
+        assert np.array_equal(xg, x) and np.array_equal(cg, np.asarray(e, np.int32).reshape(-1, 2))
+
+
+def test_pack_accepts_edge_index_layout():
+    x = np.zeros((4, 2), np.float32)
+    ei = np.array([[0, 1, 2], [1, 2, 3]])  # PyG [2, E]
+    b = pack_graphs([(x, ei)])
+    assert np.array_equal(b.coo, np.array([[0, 1], [1, 2], [2, 3]], np.int32))
+
+
+def test_pack_rejects_bad_input():
+    x = np.zeros((2, 3), np.float32)
+    with pytest.raises(ValueError):
+        pack_graphs([(x, np.array([[0, 5]]))])
+    with pytest.raises(ValueError):
+        pack_graphs([(x, np.zeros((0, 2))), (np.zeros((2, 4), np.float32), np.zeros((0, 2)))])
+    with pytest.raises(ValueError):
+        pack_graphs([])
+
+
+def test_validate_catches_cross_graph_edge():
+    b = synthetic.make_batch("qm9", 5, 0)
+    b.coo[0, 0] = b.num_nodes - 1
+    with pytest.raises(ValueError):
+        b.validate()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shards_partition_the_batch_and_balance_nodes(world):
+    b = synthetic.make_batch("molhiv", 257, 3)
+    bounds = shard_bounds(b.node_ptr, world)
+    assert bounds[0][0] == 0 and bounds[-1][1] == b.num_graphs
+    assert all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+    nodes = [int(b.node_ptr[g1] - b.node_ptr[g0]) for g0, g1 in bounds]
+    assert sum(nodes) == b.num_nodes
+    assert max(nodes) - min(nodes) <= 2 * 222  # within a graph or two of each other
+    parts = [shard_batch(b, world, r) for r in range(world)]
+    for p in parts:
+        p.validate()
+    assert np.array_equal(np.concatenate([p.x for p in parts]), b.x)
+    assert sum(p.num_edges for p in parts) == b.num_edges
+
+
+def test_synthetic_shapes_follow_the_survey_recipe():
+    b = synthetic.make_batch("qm9", 2000, 0)
+    b.validate()
+    sizes = np.diff(b.node_ptr)
+    assert 3 <= sizes.min() and sizes.max() <= 29 and abs(sizes.mean() - 18) < 0.5
+    assert abs(b.num_edges / b.num_nodes - 2.15) < 0.15
+    assert b.x.shape[1] == 11 and b.x.dtype == np.float32 and np.abs(b.x).max() <= 1.0
+    # both directions stored, no self loops
+    assert not np.any(b.coo[:, 0] == b.coo[:, 1])
+    fwd = set(map(tuple, b.coo.tolist()))
+    assert all((t, s) in fwd for s, t in list(fwd)[:500])
+    assert np.array_equal(synthetic.make_batch("qm9", 50, 7).coo, synthetic.make_batch("qm9", 50, 7).coo)

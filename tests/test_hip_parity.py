@@ -263,14 +263,26 @@ def test_full_size_config2_properties(dev):
     assert np.abs(out_rev[::-1] - out).max() < 1e-5
 
 
-@pytest.mark.parametrize("opt", [dict(tile_rows=8), dict(tile_rows=64, agg_tiles_per_wg=2), dict(agg_lds_kb=8),
-                                 dict(agg_overshoot=0)])
+AGG_OPTION_SETS = [
+    dict(agg_variant=0, agg_rows_per_wg=8), dict(agg_variant=0, agg_rows_per_wg=500),           # CSR-streamed
+    dict(agg_variant=1), dict(agg_variant=1, tile_rows=8), dict(agg_variant=1, tile_rows=64, agg_tiles_per_wg=2),
+    dict(agg_variant=1, agg_lds_kb=8), dict(agg_variant=1, agg_overshoot=0),                    # staged small tiles
+    dict(agg_variant=2), dict(agg_variant=2, agg_lds_kb=8), dict(agg_variant=2, tile_rows=64),
+    dict(agg_variant=2, agg_lds_kb=150), dict(agg_variant=2, tile_rows=4),                      # pipelined LDS-DMA
+    dict(agg_variant=3), dict(agg_variant=3, agg_rows_per_wg=16),                               # record-streamed
+    dict(agg_variant=4), dict(agg_variant=4, agg_lds_kb=8),                                     # single-burst LDS-DMA
+]
+
+
+@pytest.mark.parametrize("opt", AGG_OPTION_SETS, ids=lambda o: "-".join(f"{k[4:] if k.startswith('agg_') else k}{v}" for k, v in o.items()))
 def test_tiling_options_do_not_change_results(dev, opt):
-    """Every LDS-staged / direct-from-L2 / multi-tile path of the aggregate kernel agrees."""
+    """Every gather-aggregate kernel variant (incl. its direct-from-L2 and multi-stage paths) agrees
+    with the oracle at every launch geometry."""
     model = make_model("pna", in_dim=9, hidden=32, layers=2, task_out=1)
     batch = synthetic.make_batch("molhiv", 64, seed=11)
     ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
-    defaults = dict(tile_rows=32, agg_tiles_per_wg=1, agg_lds_kb=48, agg_overshoot=32)
+    defaults = dict(tile_rows=16, agg_tiles_per_wg=1, agg_lds_kb=39, agg_overshoot=32, agg_variant=0,
+                    agg_rows_per_wg=48)
     try:
         for k, v in opt.items():
             runtime.set_option(k, v)
