@@ -1383,6 +1383,36 @@ __device__ inline float act_apply(float v, int act)
     }
 }
 
+// Compile-time activation: the epilogues dispatch on `act` ONCE and run a straight-line copy of
+// the store loop per activation (a runtime switch inside the unrolled loops replicates the inlined
+// erff/tanhf/expf bodies per element: thousands of instructions and hundreds of branches).
+template <int ACT>
+__device__ inline float act_t(float v)
+{
+    if (ACT == GNNB_ACT_RELU)
+        return v > 0.0f ? v : 0.0f;
+    if (ACT == GNNB_ACT_GELU)
+        return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == GNNB_ACT_SIGMOID)
+        return 1.0f / (1.0f + expf(-v));
+    if (ACT == GNNB_ACT_TANH)
+        return tanhf(v);
+    return v;
+}
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
+// calls f(IntTag<act>{}) with `act` turned into a compile-time constant
+#define GNNB_DISPATCH_ACT(act, f)                        \
+    switch (act) {                                       \
+    case GNNB_ACT_RELU: f(IntTag<GNNB_ACT_RELU>{}); break;       \
+    case GNNB_ACT_GELU: f(IntTag<GNNB_ACT_GELU>{}); break;       \
+    case GNNB_ACT_SIGMOID: f(IntTag<GNNB_ACT_SIGMOID>{}); break; \
+    case GNNB_ACT_TANH: f(IntTag<GNNB_ACT_TANH>{}); break;       \
+    default: f(IntTag<GNNB_ACT_NONE>{}); break;                  \
+    }
+
 __device__ inline float4 load4_guard(const float *p, int remaining, bool vec)
 {
     // `remaining` = number of valid floats at p (<= 0: none)
@@ -1524,25 +1554,393 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    auto epilogue = [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++)
+        for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-        for (int ni = 0; ni < NT; ni++) {
-            const int colg = n0 + wn * 32 * NT + ni * 32 + li;
-            if (colg >= N)
-                continue;
-            const float bv = bias ? bias[colg] : 0.0f;
+            for (int ni = 0; ni < NT; ni++) {
+                const int colg = n0 + wn * 32 * NT + ni * 32 + li;
+                if (colg >= N)
+                    continue;
+                const float bv = bias ? bias[colg] : 0.0f;
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int rowg = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                if (rowg < M) {
-                    float v = acc[mi][ni][reg] + bv;
-                    if (skip)
-                        v += skip[(size_t)rowg * N + colg];
-                    Y[(size_t)rowg * N + colg] = act_apply(v, act);
+                for (int reg = 0; reg < 16; reg++) {
+                    const int rowg = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    if (rowg < M) {
+                        float v = acc[mi][ni][reg] + bv;
+                        if (skip)
+                            v += skip[(size_t)rowg * N + colg];
+                        Y[(size_t)rowg * N + colg] = act_t<ACT>(v);
+                    }
+                }
+            }
+    };
+    GNNB_DISPATCH_ACT(act, epilogue)
+}
+
+
+// -------------------------------------------------------------------------------------
+// Register-resident-weight variant for K <= 128 (every full-width layer of the d<=128 models, the
+// first layer, the MLP head's 64-wide linears).  The weight matrix is tiny next to the activation
+// stream, so each wave keeps ITS 32 output columns x K of W in VGPRs for the whole kernel (K/2
+// registers) and the workgroup is persistent: it walks a contiguous range of 16-row units, the A
+// rows arriving through a double-buffered LDS stage filled by LDS-DMA (global_load_lds) while the
+// previous stage is on the matrix cores.  v_mfma_f32_16x16x4_f32 (exact fp32) gives a 16-row
+// scheduling quantum, which keeps the persistent ranges balanced.  LDS rows are XOR-swizzled by
+// pre-swizzling the DMA *source* address (the DMA destination is lane-linear), which makes the
+// ds_read_b128 fragment reads conflict-free:  slot = chunk ^ (row & (P-1)).
+// Lane (i = l&15, g = l>>4) reads chunk 4q+g of row i: k = 16q+4g .. +3; MFMA step (q,s) contracts
+// k in {16q + 4g + s : g = 0..3}, the same k-permutation on A and W.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KQ, bool VEC_A> // KQ = ceil(K/16) in {1,2,4,8}; VEC_A: K % 4 == 0 and 16-B aligned rows
+__global__ __launch_bounds__(WG, 3) void k_linear_reg(
+    const float *__restrict__ A, int lda, int K, const float *__restrict__ W, int ldw,
+    const float *__restrict__ bias, const float *__restrict__ skip, float *__restrict__ Y, int M, int N,
+    int act, int rg_log2, int P, int vec_out)
+{
+    constexpr int SR = 2;      // 16-row units per stage
+    constexpr int EPI_LD = 36; // padded row of the epilogue transpose scratch
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int RG = 1 << rg_log2;     // row groups: waves that take different rows
+    const int cw = wave >> rg_log2;  // which 32-column slice this wave owns
+    const int rgi = wave & (RG - 1); // which row group
+    const int n0 = blockIdx.y * (128 >> rg_log2) + cw * 32;
+    const int unit_rows = 16 * RG;
+    const int stage_rows = SR * unit_rows;
+    const size_t buf_bytes = (((size_t)stage_rows * K * 4) + 15) & ~(size_t)15;
+    float *sC = reinterpret_cast<float *>(smem + 2 * buf_bytes) + (size_t)wave * 32 * EPI_LD;
+
+    // ---- persistent range, balanced in UNITS of 16*RG rows (half a stage), so the remainder a
+    // workgroup may carry is half a stage.  Local stage j covers units [u0+2j, min(u0+2j+2, u1)).
+    const int num_units = (M + unit_rows - 1) / unit_rows;
+    const int u0 = (int)(((long long)blockIdx.x * num_units) / gridDim.x);
+    const int u1 = (int)(((long long)(blockIdx.x + 1) * num_units) / gridDim.x);
+    if (u1 <= u0)
+        return;
+    const int nstages = (u1 - u0 + SR - 1) / SR;
+    const int C = K >> 2; // 16-B chunks per row (VEC_A)
+    auto row_begin = [&](int j) { return (u0 + SR * j) * unit_rows; };
+    auto rows_of = [&](int j) { return min(min(u0 + SR * j + SR, u1) * unit_rows, M) - (u0 + SR * j) * unit_rows; };
+
+    // ---- this wave's weight slice -> registers
+    float breg[2][KQ * 4];
+    // fast path (wave-uniform): the 32 x K slice is in range and 16-B aligned.  Its rows are read
+    // whole (coalesced LDS-DMA) into this wave's share of the not-yet-used stage buffers and picked
+    // apart into fragments from LDS; fragment-shaped global loads (16 rows x 64 B per instruction)
+    // took ~2 us per workgroup and serialised co-resident workgroups' start.
+    const bool wfast = VEC_A && (ldw % 4 == 0) && (K == 16 * KQ) && (n0 + 32 <= N) && (((uintptr_t)W & 15) == 0);
+    if (wfast) {
+        float *wl = reinterpret_cast<float *>(smem) + (size_t)wave * 16 * K; // 4 x 16*K floats <= 2 buffers
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int nrow0 = n0 + 16 * u;
+            const int nch = 16 * C;
+            for (int c0 = 0; c0 < nch; c0 += 64) {
+                const int L = c0 + lane;
+                if (L < nch) {
+                    const int rr = L / C, cc = L - rr * C;
+                    dma16_to_lds(W + (size_t)(nrow0 + rr) * ldw + cc * 4, reinterpret_cast<char *>(wl) + (size_t)c0 * 16);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // own DMA, wave-private region: no barrier
+#pragma unroll
+            for (int q = 0; q < KQ; q++) {
+                const float4 v = *reinterpret_cast<const float4 *>(wl + (size_t)li * K + 16 * q + 4 * lg);
+                breg[u][q * 4 + 0] = v.x;
+                breg[u][q * 4 + 1] = v.y;
+                breg[u][q * 4 + 2] = v.z;
+                breg[u][q * 4 + 3] = v.w;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // fragments read before the region is reused
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int n = n0 + 16 * u + li;
+#pragma unroll
+            for (int q = 0; q < KQ; q++) {
+                const int k = 16 * q + 4 * lg;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < N)
+                    v = load4_guard(W + (size_t)n * ldw + k, K - k, VEC_A && (ldw % 4 == 0));
+                breg[u][q * 4 + 0] = v.x;
+                breg[u][q * 4 + 1] = v.y;
+                breg[u][q * 4 + 2] = v.z;
+                breg[u][q * 4 + 3] = v.w;
+            }
+        }
+    }
+    float bv[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int n = n0 + 16 * u + li;
+        bv[u] = (bias != nullptr && n < N) ? bias[n] : 0.0f;
+    }
+    // loop-invariant epilogue operands, loaded ONCE: a global load inside the stage loop would make
+    // its s_waitcnt also wait for the next stage's DMA (VM operations retire in order)
+    const int c4 = (lane & 7) * 4;
+    const int nq = n0 + c4;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec_out && bias != nullptr && nq < N)
+        bq = *reinterpret_cast<const float4 *>(bias + nq);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq.x), "+v"(bq.y), "+v"(bq.z), "+v"(bq.w), "+v"(bv[0]), "+v"(bv[1])::"memory");
+    __syncthreads(); // every wave is out of the stage buffers (weight prologue) before A lands there
+
+    auto issue = [&](int j, int bb) {
+        char *dst = smem + (size_t)bb * buf_bytes;
+        const int m0i = row_begin(j);
+        const int rows = rows_of(j);
+        if (VEC_A) {
+            const int nchunks = rows * C;
+            for (int c0 = wave * 64; c0 < nchunks; c0 += 4 * 64) {
+                const int L = c0 + lane;
+                if (L < nchunks) {
+                    const int i = L / C, sl = L - i * C;
+                    const int c = sl ^ (i & (P - 1));
+                    dma16_to_lds(A + (size_t)(m0i + i) * lda + c * 4, dst + (size_t)c0 * 16);
+                }
+            }
+        } else {
+            const int nd = rows * K;
+            for (int c0 = wave * 64; c0 < nd; c0 += 4 * 64) {
+                const int L = c0 + lane;
+                if (L < nd) {
+                    const int i = L / K, kk = L - i * K;
+                    dma4_to_lds(A + (size_t)(m0i + i) * lda + kk, dst + (size_t)c0 * 4);
                 }
             }
         }
+    };
+
+#ifdef GNNB_PROBE
+    unsigned long long pt_wait = 0, pt_mma = 0, pt_epi = 0, pt0 = clock64(), pw0 = wall_clock64();
+#define GNNB_PT(var, since) do { const unsigned long long _n = clock64(); var += _n - since; since = _n; } while (0)
+    unsigned long long pt_last = pt0;
+#else
+#define GNNB_PT(var, since) do { } while (0)
+#endif
+    // Stores count in vmcnt on CDNA4 and VM operations retire in order.  A full stage's vector
+    // epilogue issues EXACTLY four 16-B stores per wave after the next stage's DMA, so waiting for
+    // vmcnt <= 4 proves that DMA has landed while the stores stay in flight; anything irregular
+    // (ragged stage, scalar epilogue, a wave without columns) falls back to a full drain.
+    const bool wave_has_cols = nq < N || (n0 < N); // some lane of this wave stores
+    bool prev_counted = false;
+    issue(0, 0);
+    int b = 0;
+    for (int j = 0; j < nstages; j++, b ^= 1) {
+        if (prev_counted)
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (j + 1 < nstages)
+            issue(j + 1, b ^ 1);
+        GNNB_PT(pt_wait, pt_last);
+        const float *sA = reinterpret_cast<const float *>(smem + (size_t)b * buf_bytes);
+        const int m0 = row_begin(j);
+        const int m_end = m0 + rows_of(j); // rows past it belong to another workgroup (or nobody)
+
+        f32x4 acc[SR][2];
+#pragma unroll
+        for (int rt = 0; rt < SR; rt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                acc[rt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int q = 0; q < KQ; q++) {
+            float4 a[SR];
+#pragma unroll
+            for (int rt = 0; rt < SR; rt++) {
+                const int row = (rt * RG + rgi) * 16 + li; // row inside the stage: unit rt, row group rgi
+                if (VEC_A) {
+                    const int c = 4 * q + lg;
+                    a[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < C)
+                        a[rt] = *reinterpret_cast<const float4 *>(sA + (size_t)row * K + ((c ^ (row & (P - 1))) << 2));
+                } else {
+                    const int k = 16 * q + 4 * lg;
+                    const float *pr = sA + (size_t)row * K + k;
+                    a[rt].x = (k + 0 < K) ? pr[0] : 0.f;
+                    a[rt].y = (k + 1 < K) ? pr[1] : 0.f;
+                    a[rt].z = (k + 2 < K) ? pr[2] : 0.f;
+                    a[rt].w = (k + 3 < K) ? pr[3] : 0.f;
+                }
+            }
+            // k-step outermost: consecutive MFMAs hit the four different accumulators, so the 40-cycle
+            // dependent latency of v_mfma_f32_16x16x4_f32 hides behind its 32-cycle issue interval
+            const float as[SR][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+#pragma unroll
+            for (int sk = 0; sk < 4; sk++)
+#pragma unroll
+                for (int rt = 0; rt < SR; rt++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        acc[rt][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[rt][sk], breg[u][q * 4 + sk], acc[rt][u], 0, 0, 0);
+        }
+#ifdef GNNB_PROBE
+        asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[SR - 1][1][3]));
+#endif
+        GNNB_PT(pt_mma, pt_last);
+        // epilogue: C/D of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+        const bool full = (m_end - m0) == stage_rows;
+        prev_counted = vec_out && full && wave_has_cols && (skip == nullptr);
+        auto epilogue = [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
+            if (vec_out) {
+                // transpose the wave's 32x32 block through its LDS scratch, then 4 x (ds_read_b128 +
+                // 16-B global store) instead of 16 dword stores: 8 lanes cover one 128-B row segment
+#pragma unroll
+                for (int rt = 0; rt < SR; rt++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            sC[(rt * 16 + lg * 4 + r) * EPI_LD + u * 16 + li] = acc[rt][u][r];
+                // (same wave wrote and reads: the compiler's lgkmcnt wait orders it; no barrier)
+#pragma unroll
+                for (int ps = 0; ps < 4; ps++) {
+                    const int rl = ps * 8 + (lane >> 3); // row inside the wave's 32 (unit rl>>4)
+                    const int m = m0 + ((rl >> 4) * RG + rgi) * 16 + (rl & 15);
+                    float4 v = *reinterpret_cast<const float4 *>(sC + rl * EPI_LD + c4);
+                    if (m < m_end && nq < N) {
+                        v.x += bq.x;
+                        v.y += bq.y;
+                        v.z += bq.z;
+                        v.w += bq.w;
+                        if (skip) {
+                            const float4 sk = *reinterpret_cast<const float4 *>(skip + (size_t)m * N + nq);
+                            v.x += sk.x;
+                            v.y += sk.y;
+                            v.z += sk.z;
+                            v.w += sk.w;
+                        }
+                        v.x = act_t<ACT>(v.x);
+                        v.y = act_t<ACT>(v.y);
+                        v.z = act_t<ACT>(v.z);
+                        v.w = act_t<ACT>(v.w);
+                        *reinterpret_cast<float4 *>(Y + (size_t)m * N + nq) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < SR; rt++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int n = n0 + 16 * u + li;
+                        if (n >= N)
+                            continue;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int m = m0 + (rt * RG + rgi) * 16 + lg * 4 + r;
+                            if (m < m_end) {
+                                float v = acc[rt][u][r] + bv[u];
+                                if (skip)
+                                    v += skip[(size_t)m * N + n];
+                                Y[(size_t)m * N + n] = act_t<ACT>(v);
+                            }
+                        }
+                    }
+            }
+        };
+        GNNB_DISPATCH_ACT(act, epilogue)
+        GNNB_PT(pt_epi, pt_last);
+    }
+#ifdef GNNB_PROBE
+    if (tid == 0 && blockIdx.x < 8192 && blockIdx.y == 0) {
+        unsigned long long *o = g_probe + blockIdx.x * 8;
+        o[0] = pw0;
+        o[1] = wall_clock64();
+        o[2] = pt_wait;
+        o[3] = pt_mma;
+        o[4] = pt_epi;
+        o[5] = clock64() - pt0;
+        o[6] = (unsigned long long)nstages;
+    }
+#endif
+}
+
+template <int KQ, bool VEC_A>
+static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const float *W, int ldw,
+                                      const float *bias, const float *skip, float *Y, int M, int N,
+                                      int act, hipStream_t s)
+{
+    // waves: N <= 32 -> 4 row groups x 1 column slice; N <= 64 -> 2 x 2; else 1 x 4 (128 cols / WG)
+    const int rg_log2 = N <= 32 ? 2 : (N <= 64 ? 1 : 0);
+    const int cols_per_wg = 128 >> rg_log2;
+    const int stage_rows = (16 * 2) << rg_log2;
+    const int gy = (N + cols_per_wg - 1) / cols_per_wg;
+    const size_t buf = (((size_t)stage_rows * K * 4) + 15) & ~(size_t)15;
+    const size_t lds = 2 * buf + 4 * 32 * 36 * 4; // two stage buffers + per-wave epilogue scratch
+    const int vec_out = (N % 4 == 0) && (((uintptr_t)Y & 15) == 0) && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
+                        (skip == nullptr || ((uintptr_t)skip & 15) == 0);
+    int P = 1;
+    if (VEC_A) {
+        const int C = K / 4;
+        while (P < 16 && C % (2 * P) == 0)
+            P *= 2;
+    }
+    const int num_stages = (M + stage_rows - 1) / stage_rows;
+    auto kern = k_linear_reg<KQ, VEC_A>;
+    static size_t lds_allowed = 64 * 1024;
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        lds_allowed = lds;
+    }
+    // persistent grid = what is resident at once (registers + LDS), asked of the runtime once per
+    // LDS size and capped (MI355X_MICROARCH: keep <= 4 blocks of 256 threads per CU)
+    static size_t occ_lds = (size_t)-1;
+    static int occ_blocks = 1, num_cus = 256;
+    if (occ_lds != lds) {
+        int nb = 0, devid = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WG, lds) != hipSuccess || nb < 1)
+            nb = 1;
+        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+            num_cus = prop.multiProcessorCount;
+        occ_blocks = nb;
+        occ_lds = lds;
+    }
+    const int cap = options().gemm_max_wg_per_cu;
+    int gx = num_cus * (occ_blocks > cap ? cap : occ_blocks) / gy;
+    if (gx < 1)
+        gx = 1;
+    if (gx > num_stages)
+        gx = num_stages; // at least one full stage per workgroup
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(WG), lds, s, A, lda, K, W, ldw, bias, skip, Y, M, N, act,
+                       rg_log2, P, vec_out);
+    return hipGetLastError();
+}
+
+static bool linear_reg_eligible(const GemmArgs &g)
+{
+    return options().gemm_variant == 0 && g.nseg == 1 && g.rs[0] == nullptr && g.k[0] <= 128;
+}
+
+static hipError_t launch_linear_reg(const GemmArgs &g, const float *w, int ldw, const float *bias,
+                                    const float *skip, float *y, int M, int N, int act, hipStream_t s)
+{
+    const int K = g.k[0];
+    const bool vec = g.avec[0] != 0;
+    const int kq = K <= 16 ? 1 : (K <= 32 ? 2 : (K <= 64 ? 4 : 8));
+#define GNNB_LR_CASE(Q)                                                                              \
+    case Q:                                                                                          \
+        return vec ? launch_linear_reg_t<Q, true>(g.a[0], g.lda[0], K, w, ldw, bias, skip, y, M, N, act, s) \
+                   : launch_linear_reg_t<Q, false>(g.a[0], g.lda[0], K, w, ldw, bias, skip, y, M, N, act, s);
+    switch (kq) {
+        GNNB_LR_CASE(1)
+        GNNB_LR_CASE(2)
+        GNNB_LR_CASE(4)
+        GNNB_LR_CASE(8)
+    }
+#undef GNNB_LR_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
@@ -1550,6 +1948,8 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
 {
     if (M <= 0 || N <= 0)
         return hipSuccess;
+    if (linear_reg_eligible(g))
+        return launch_linear_reg(g, w, ldw, bias, skip, y, M, N, act, s);
     const int gm = (M + BM - 1) / BM;
     if (N > 64) {
         constexpr int NT = 2;

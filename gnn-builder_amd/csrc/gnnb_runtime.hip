@@ -53,7 +53,8 @@ Options &options()
 {
     static Options o = {env_int("GNNB_TILE_ROWS", 16), env_int("GNNB_AGG_LDS_KB", 39),
                         env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32),
-                        env_int("GNNB_AGG_VARIANT", 0),      env_int("GNNB_AGG_ROWS_PER_WG", 48)};
+                        env_int("GNNB_AGG_VARIANT", 0),      env_int("GNNB_AGG_ROWS_PER_WG", 48),
+                        env_int("GNNB_GEMM_VARIANT", 0),     env_int("GNNB_GEMM_MAX_WG_PER_CU", 2)};
     return o;
 }
 
@@ -190,6 +191,10 @@ int gnnb_set_option(const char *name, int value)
         o.agg_variant = value;
     else if (!strcmp(name, "agg_rows_per_wg") && value >= 8 && value <= 4096)
         o.agg_rows_per_wg = value;
+    else if (!strcmp(name, "gemm_variant") && value >= 0 && value <= 1)
+        o.gemm_variant = value;
+    else if (!strcmp(name, "gemm_max_wg_per_cu") && value >= 1 && value <= 8)
+        o.gemm_max_wg_per_cu = value;
     else
         return fail(GNNB_ERR_INVALID, "unknown option or bad value: %s=%d", name, value);
     return GNNB_OK;

@@ -153,6 +153,23 @@ def test_linear_matches_torch(dev, M, N, K, act):
     assert (y.cpu() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(37, 19, 11), (300, 128, 128), (129, 64, 64), (1000, 33, 16), (50, 200, 36)])
+def test_linear_lds_tiled_kernel_on_small_k(dev, M, N, K):
+    """K <= 128 normally takes the register-resident-weight kernel; force the LDS-tiled one too."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.rand(M, K, generator=g) - 0.5
+    w = torch.rand(N, K, generator=g) - 0.5
+    b = torch.rand(N, generator=g)
+    ref = (a.double() @ w.double().T + b.double()).float()
+    try:
+        runtime.set_option("gemm_variant", 1)
+        y1 = runtime.linear([(a.to(dev), None)], w.to(dev), b.to(dev)).cpu()
+    finally:
+        runtime.set_option("gemm_variant", 0)
+    y0 = runtime.linear([(a.to(dev), None)], w.to(dev), b.to(dev)).cpu()
+    assert (y1 - ref).abs().max().item() < 2e-5 and (y0 - ref).abs().max().item() < 2e-5
+
+
 def test_linear_segments_and_rowscale(dev):
     g = torch.Generator().manual_seed(7)
     M, N = 333, 96
