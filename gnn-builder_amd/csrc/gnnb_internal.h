@@ -35,6 +35,7 @@ struct Options {
     int agg_variant;   // 0 = CSR-streamed gather (default), 1 = LDS-staged small tiles,
                        // 2 = pipelined LDS-DMA, 3 = record-streamed, 4 = LDS-DMA single burst
     int agg_rows_per_wg; // streaming variant: destination rows per workgroup
+    int agg_xcd_remap; // remap block ids so each XCD owns a contiguous run of row chunks
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
     int gemm_max_wg_per_cu;
 };

@@ -187,9 +187,8 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
 hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
                              BatchTables &t, float pna_delta, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(t.err, 0, sizeof(int32_t), s);
-    if (e != hipSuccess)
-        return e;
+    // t.err is zeroed when the workspace is created and again whenever it is read
+    // (gnnb_workspace_check), so no per-batch memset node sits in front of this launch
     const int waves = t.num_graphs + 1;
     const int grid = (waves + (WG / 64) - 1) / (WG / 64);
     hipLaunchKernelGGL(k_graph_prep, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
@@ -197,6 +196,17 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
                        t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_rows, t.num_tiles,
                        t.err);
     return hipGetLastError();
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD, each XCD has
+// its own L2).  Kernels whose neighbouring blocks touch neighbouring rows remap the block id so
+// that each XCD owns one CONTIGUOUS run of chunks: a neighbour row fetched by the adjacent chunk
+// is then an L2 hit instead of a second HBM fetch by another XCD.  Bijective for any grid size
+// (cdna_hip_programming.md, "XCD swizzle must be bijective").  Speed only, never correctness.
+__device__ inline int xcd_contiguous_block(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
 // =====================================================================================
@@ -565,14 +575,16 @@ template <int MODE, int VEC>
 __global__ __launch_bounds__(WG) void k_aggregate_stream(
     const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
     const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const float *__restrict__ dinv, int N, int w, int glog2, int rows_per_wg, int edge_cap, float eps)
+    const float *__restrict__ dinv, int N, int w, int glog2, int rows_per_wg, int edge_cap, float eps,
+    int xcd_remap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t *srp = reinterpret_cast<int32_t *>(smem);    // [rows_per_wg + 1]
     int32_t *scol = srp + ((rows_per_wg + 1 + 3) & ~3);  // [edge_cap]
 
     const int tid = threadIdx.x;
-    const int nb = blockIdx.x * rows_per_wg;
+    const int chunk = xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int nb = chunk * rows_per_wg;
     const int rows = min(rows_per_wg, N - nb);
     for (int i = tid; i <= rows; i += WG)
         srp[i] = row_ptr[nb + i];
@@ -621,7 +633,7 @@ static hipError_t launch_aggregate_stream_t(const BatchTables &t, const float *x
     if (grid <= 0)
         return hipSuccess;
     hipLaunchKernelGGL((k_aggregate_stream<MODE, VEC>), dim3(grid), dim3(WG), lds, s, x, selfq, out,
-                       t.row_ptr, t.col, t.dinv, t.num_nodes, w, glog2, rpw, edge_cap, eps);
+                       t.row_ptr, t.col, t.dinv, t.num_nodes, w, glog2, rpw, edge_cap, eps, o.agg_xcd_remap);
     return hipGetLastError();
 }
 

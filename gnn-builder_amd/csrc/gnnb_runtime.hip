@@ -54,7 +54,8 @@ Options &options()
     static Options o = {env_int("GNNB_TILE_ROWS", 16), env_int("GNNB_AGG_LDS_KB", 39),
                         env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32),
                         env_int("GNNB_AGG_VARIANT", 0),      env_int("GNNB_AGG_ROWS_PER_WG", 48),
-                        env_int("GNNB_GEMM_VARIANT", 0),     env_int("GNNB_GEMM_MAX_WG_PER_CU", 2)};
+                        env_int("GNNB_AGG_XCD_REMAP", 1),    env_int("GNNB_GEMM_VARIANT", 0),
+                        env_int("GNNB_GEMM_MAX_WG_PER_CU", 2)};
     return o;
 }
 
@@ -191,6 +192,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_variant = value;
     else if (!strcmp(name, "agg_rows_per_wg") && value >= 8 && value <= 4096)
         o.agg_rows_per_wg = value;
+    else if (!strcmp(name, "agg_xcd_remap") && value >= 0 && value <= 1)
+        o.agg_xcd_remap = value;
     else if (!strcmp(name, "gemm_variant") && value >= 0 && value <= 1)
         o.gemm_variant = value;
     else if (!strcmp(name, "gemm_max_wg_per_cu") && value >= 1 && value <= 8)
@@ -387,6 +390,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->pooled = (float *)(b + o_pool);
     ws->mlp[0] = (float *)(b + o_m0);
     ws->mlp[1] = (float *)(b + o_m1);
+    (void)hipMemset(ws->t.err, 0, sizeof(int32_t));
     *out_ws = ws;
     return GNNB_OK;
 }
@@ -437,6 +441,10 @@ int gnnb_workspace_check(gnnb_workspace *ws, void *stream)
     int32_t err = 0;
     GNNB_HIP_TRY(hipMemcpyAsync(&err, ws->t.err, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream));
     GNNB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (err != 0) {
+        (void)hipMemsetAsync(ws->t.err, 0, sizeof(int32_t), (hipStream_t)stream); // reset on read
+        (void)hipStreamSynchronize((hipStream_t)stream);
+    }
     if (err != 0)
         return fail(GNNB_ERR_GRAPH, "malformed batch (flags 0x%x): ptr arrays not monotone/complete, "
                                     "or an edge leaves its graph", err);

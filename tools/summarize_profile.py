@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs that tools/profile_r.sh leaves under gpurun_out/prof/ into the small
+tracked summaries under profiles/ (per-kernel stats of the default bench.py command and of the
+roofline-only loop; per-launch HBM traffic of the gather-aggregate kernel from the PMC passes,
+corrected as MI355X_MICROARCH.md's HBM section prescribes)."""
+import collections
+import csv
+import json
+import re
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "prof"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+dst = ROOT / "profiles"
+dst.mkdir(exist_ok=True)
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(.*", "", name).replace("void ", "")
+    return name if len(name) < 90 else name[:87] + "..."
+
+
+def kernel_stats(path: Path, out: Path, title: str) -> None:
+    rows = list(csv.DictReader(open(path)))
+    with open(out, "w") as f:
+        f.write(f"# {title}\n# source: rocprofv3 --kernel-trace --stats ({path.name}); durations in microseconds\n")
+        f.write("kernel,calls,total_us,avg_us,min_us,max_us,percent\n")
+        for r in rows:
+            f.write(f"\"{short(r['Name'])}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e3:.1f},"
+                    f"{float(r['AverageNs']) / 1e3:.2f},{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f},"
+                    f"{float(r['Percentage']):.2f}\n")
+
+
+kernel_stats(src / "bench" / "bench_kernel_stats.csv", dst / f"{tag}_bench_kernel_stats.csv",
+             "python3 bench.py  (default: N=1, workload c2)")
+kernel_stats(src / "roofline" / "roofline_kernel_stats.csv", dst / f"{tag}_roofline_only_kernel_stats.csv",
+             "python3 bench.py --roofline-only  (HBM-regime gather-aggregate loop only)")
+
+pmc = {}
+for sub, fname in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("pmc_l2", "l2")):
+    p = src / sub / f"{fname}_counter_collection.csv"
+    if not p.exists():
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        if "k_aggregate" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        pmc[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+
+log = (src / "roofline.log").read_text().strip().splitlines()
+meas = json.loads([l for l in log if l.startswith("{")][-1])
+summary = {"command": "rocprofv3 --pmc <counter> -- python3 bench.py --roofline-only (one pass per counter)",
+           "kernel": "gnnb::k_aggregate_* <GCN, float4>, width 128, BASELINE config 2 batch",
+           "raw_counters_per_launch": pmc,
+           "algorithmic_bytes_per_launch": meas["algorithmic_bytes_per_launch"],
+           "events_us_per_launch": meas["us"]}
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    fetch = pmc["FETCH_SIZE"]["mean"] * 1024.0 * 2.0   # KiB units; gfx950 reports 1/2 of wide coalesced reads
+    write = pmc["WRITE_SIZE"]["mean"] * 1024.0
+    summary["hbm_traffic_bytes_per_launch"] = {"read_corrected_x2": fetch, "write": write, "total": fetch + write,
+                                               "over_algorithmic": (fetch + write) / meas["algorithmic_bytes_per_launch"]}
+if "TCC_HIT_sum" in pmc:
+    h, m = pmc["TCC_HIT_sum"]["mean"], pmc["TCC_MISS_sum"]["mean"]
+    summary["l2_hit_rate"] = h / (h + m)
+(dst / f"{tag}_aggregate_pmc.json").write_text(json.dumps(summary, indent=2) + "\n")
+print(json.dumps(summary, indent=2))
