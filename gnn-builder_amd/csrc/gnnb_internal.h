@@ -38,6 +38,7 @@ struct Options {
     int agg_xcd_remap; // remap block ids so each XCD owns a contiguous run of row chunks
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
     int gemm_max_wg_per_cu;
+    int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
 };
 Options &options();
 
@@ -60,6 +61,18 @@ struct GemmArgs {
 };
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
                          const float *skip, float *y, int M, int N, int act, hipStream_t s);
+
+// Fused readout: global pooling + the whole MLP head in one launch (16 graphs per workgroup).
+struct HeadArgs {
+    const float *w[8];
+    const float *b[8];
+    int32_t dims[9]; // dims[0] = num_pools * d, dims[i+1] = output width of linear i
+    int32_t nlin;
+};
+// returns hipErrorNotSupported when the head does not fit the fused kernel (caller falls back)
+hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_graphs, int d,
+                           const int32_t *pools, int num_pools, const HeadArgs &head, int act,
+                           float *out, hipStream_t s);
 
 hipError_t launch_global_pool(const float *x, const int32_t *node_ptr, int num_graphs, int d,
                               const int32_t *pools, int num_pools, float *out, hipStream_t s);

@@ -55,7 +55,7 @@ Options &options()
                         env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32),
                         env_int("GNNB_AGG_VARIANT", 0),      env_int("GNNB_AGG_ROWS_PER_WG", 48),
                         env_int("GNNB_AGG_XCD_REMAP", 1),    env_int("GNNB_GEMM_VARIANT", 0),
-                        env_int("GNNB_GEMM_MAX_WG_PER_CU", 2)};
+                        env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_FUSE_HEAD", 1)};
     return o;
 }
 
@@ -194,6 +194,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_rows_per_wg = value;
     else if (!strcmp(name, "agg_xcd_remap") && value >= 0 && value <= 1)
         o.agg_xcd_remap = value;
+    else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
+        o.fuse_head = value;
     else if (!strcmp(name, "gemm_variant") && value >= 0 && value <= 1)
         o.gemm_variant = value;
     else if (!strcmp(name, "gemm_max_wg_per_cu") && value >= 1 && value <= 8)
@@ -635,6 +637,28 @@ int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const flo
     }
 
     const int gw = gnn_out_width(d);
+    {
+        // fused readout (pooling + whole MLP head, one launch) when the head fits LDS
+        HeadArgs head;
+        memset(&head, 0, sizeof(head));
+        head.nlin = d.mlp_num_linear;
+        if (head.nlin <= 8) {
+            for (int i = 0; i < head.nlin; i++) {
+                int din, dout;
+                mlp_dims(d, i, &din, &dout);
+                head.w[i] = model->head_w[i];
+                head.b[i] = model->head_b[i];
+                head.dims[i] = din;
+                head.dims[i + 1] = dout;
+            }
+            hipError_t he = launch_pool_mlp(cur, ws->t.node_ptr, B, gw, d.pools, d.num_pools, head,
+                                            d.mlp_activation, out_dev, (hipStream_t)stream);
+            if (he == hipSuccess)
+                return GNNB_OK;
+            if (he != hipErrorNotSupported)
+                return fail(GNNB_ERR_HIP, "fused readout launch failed: %s", hipGetErrorString(he));
+        }
+    }
     if ((rc = gnnb_global_pool(ws, cur, gw, d.pools, d.num_pools, ws->pooled, stream)))
         return rc;
 

@@ -309,3 +309,24 @@ def test_tiling_options_do_not_change_results(dev, opt):
         for k, v in defaults.items():
             runtime.set_option(k, v)
     assert np.abs(out - ref).max() < TOL
+
+
+@pytest.mark.parametrize("mlp_hidden,mlp_layers,task_out,pools,hidden", [
+    (64, 2, 19, ("add", "mean", "max"), 128), (50, 3, 7, ("max", "add"), 32), (16, 0, 3, ("mean",), 64),
+    (33, 1, 1, ("add",), 20), (64, 2, 19, ("add", "mean", "max"), 256)])
+def test_fused_readout_equals_separate_kernels(dev, mlp_hidden, mlp_layers, task_out, pools, hidden):
+    """Pooling + MLP head as one kernel vs k_global_pool + three GEMMs vs the oracle (odd widths too)."""
+    model = make_model("gcn", in_dim=11, hidden=hidden, layers=2, pools=pools, mlp_hidden=mlp_hidden,
+                       mlp_layers=mlp_layers, task_out=task_out, mlp_act="tanh")
+    batch = synthetic.make_batch("qm9", 100, seed=hidden)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    outs = []
+    try:
+        for fuse in (1, 0):
+            runtime.set_option("fuse_head", fuse)
+            outs.append(cm.forward(*to_dev(batch, dev)).cpu().numpy())
+    finally:
+        runtime.set_option("fuse_head", 1)
+    assert np.abs(outs[0] - ref).max() < TOL and np.abs(outs[1] - ref).max() < TOL
+    assert np.abs(outs[0] - outs[1]).max() < 1e-5
