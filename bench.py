@@ -143,6 +143,22 @@ def cpu_baseline(model, batches, budget_s=12.0):
             "host_cpu": cpu_model, "host_cores_available": os.cpu_count()}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the gather-aggregate kernel from the latest committed rocprofv3 PMC
+    passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/profile_r.sh -> profiles/*_aggregate_pmc.json).
+    Counters cannot be read from inside this process; None when no profile is committed."""
+    try:
+        files = sorted((ROOT / "profiles").glob("*_aggregate_pmc.json"))
+        d = json.loads(files[-1].read_text())
+        return {"bytes_per_launch": d["hbm_traffic_bytes_per_launch"]["total"],
+                "read_bytes_fetch_size_x2": d["hbm_traffic_bytes_per_launch"]["read_corrected_x2"],
+                "write_bytes": d["hbm_traffic_bytes_per_launch"]["write"],
+                "over_algorithmic": d["hbm_traffic_bytes_per_launch"]["over_algorithmic"],
+                "source": f"profiles/{files[-1].name} (rocprofv3 --pmc, separate passes)"}
+    except Exception:
+        return None
+
+
 def copy_ceiling(N, width, dev, iters=200):
     """Calibration beside the roofline: a plain streaming copy (torch's vectorised kernel) of the
     same [N, width] fp32 matrix = the same read + write bytes with no gather at all."""
@@ -174,6 +190,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches rotated per rank")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="batches in flight per GPU: each on its own HIP stream and workspace, so the MFMA-bound "
+                         "update of one batch overlaps the HBM-bound gather / readout of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
@@ -213,17 +232,23 @@ def main():
     batches = [synthetic.make_batch(w["shape"], w["batch"], seed=1000 * rank + i) for i in range(args.batches)]
     maxn = max(b.num_nodes for b in batches)
     maxe = max(b.num_edges for b in batches)
-    cm = runtime.CompiledModel.from_model(model, w["batch"], maxn, maxe)
+    nstreams = max(1, args.streams)
+    cms = [runtime.CompiledModel.from_model(model, w["batch"], maxn, maxe) for _ in range(nstreams)]
+    cm = cms[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
     dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr)) for b in batches]
     outs = [torch.empty(w["batch"], cm.out_dim, device=dev) for _ in batches]
+    torch.cuda.synchronize()
 
     def step(i):
+        # step i = one batched forward of batch i (mod the rotation) on stream i mod nstreams
         k = i % len(dev_batches)
-        cm.forward(*dev_batches[k], out=outs[k])
+        cms[i % nstreams].forward(*dev_batches[k], out=outs[k], stream=streams[i % nstreams])
 
     for i in range(args.warmup):
         step(i)
-    cm.check()  # device-side batch validation (synchronises)
+    for c, st in zip(cms, streams):
+        c.check(stream=st)  # device-side batch validation (synchronises)
 
     def barrier():
         if world > 1:
@@ -280,6 +305,7 @@ def main():
                    "nodes_per_batch": int(np.mean([b.num_nodes for b in batches])),
                    "edges_per_batch": int(np.mean([b.num_edges for b in batches])),
                    "parallelism": f"graph-sharded x{world}, no data-path collective",
+                   "batches_in_flight_per_gpu": nstreams,
                    "csr_build_in_timed_region": True},
         "ms_per_step_prepared_topology": ms_noprep,
     }
@@ -289,7 +315,7 @@ def main():
         result["roofline"] = {
             "kernel": "k_aggregate_stream<GCN> (gather-aggregate, width %d)" % w["hidden"],
             "bound": "hbm", "achieved": agg["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": None,
+            "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(),
             "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": agg["hbm"]["us"],
             "regime": "inputs/outputs rotate over >256 MiB of distinct buffers (HBM-served); launches issued "
                       "back to back from C, HIP events on the launch stream",

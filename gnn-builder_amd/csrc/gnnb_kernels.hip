@@ -43,21 +43,23 @@ __device__ unsigned long long g_probe[8 * 8192];
 // (gnnbuilder/gnn_builder_lib/gnn_builder_lib.h:1051-1083, :1086-1124): in-degree, exclusive
 // prefix sum, stable counting sort of sources by destination.  The reference runs this
 // serially per graph; here ONE WAVEFRONT owns one graph of the batch: lane = destination
-// node, the graph's (few dozen) edges sit in LDS and are scanned by broadcast reads, so the
-// sort is stable by construction and needs no atomics.  Edges of a graph are contiguous
+// node, the graph's (few dozen) edges are scanned by register broadcasts, so the sort is
+// stable by construction and needs no atomics.  Edges of a graph are contiguous
 // (edge_ptr), so the batch-global CSR segment of graph g starts at edge_ptr[g].
-static constexpr int PREP_EDGE_CAP = 512; // edges cached in LDS per wavefront
+// The graph's edges live in REGISTERS: lane l of the wave holds edge 64c+l of chunk c, and the
+// scan over edges broadcasts one edge at a time with v_readlane (scalar index) -- no LDS, no
+// per-edge memory latency.  Graphs of up to 64*PREP_REG_CHUNKS edges take this path; larger ones
+// re-read their edge list from global memory (L2) chunk by chunk.
+static constexpr int PREP_REG_CHUNKS = 4;
 
 __global__ __launch_bounds__(WG) void k_graph_prep(
     const int2 *__restrict__ coo, const int32_t *__restrict__ node_ptr,
     const int32_t *__restrict__ edge_ptr, int B, int N, int E, int32_t *__restrict__ row_ptr,
     int32_t *__restrict__ col, int4 *__restrict__ node_rec, float *__restrict__ dinv,
-    float *__restrict__ amp,
-    float *__restrict__ att, float delta,
+    float *__restrict__ amp, float *__restrict__ att, float delta,
     int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int tile_rows, int num_tiles,
     int32_t *__restrict__ err)
 {
-    __shared__ int2 s_edges[WG / 64][PREP_EDGE_CAP];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = blockIdx.x * (WG / 64) + wave;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         return;
     }
 
+    GNNB_STAMP(0);
     const int n0 = node_ptr[g], n1 = node_ptr[g + 1];
     const int e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
     if (n0 > n1 || e0 > e1 || n1 > N || e1 > E || n0 < 0 || e0 < 0) {
@@ -94,40 +97,58 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         return;
     }
     const int ne = e1 - e0;
-    const bool cached = ne <= PREP_EDGE_CAP;
-    int2 *se = s_edges[wave];
+    const int nchunks = (ne + 63) >> 6;
+    const bool inreg = nchunks <= PREP_REG_CHUNKS; // wave-uniform
     bool bad = false;
-    if (cached) {
-        for (int i = lane; i < ne; i += 64) {
-            int2 ed = coo[e0 + i];
-            // an edge that leaves its graph is an error; clamp so later gathers stay in range
-            if (ed.x < n0 || ed.x >= n1 || ed.y < n0 || ed.y >= n1) {
-                bad = true;
-                ed.x = n0;
-                ed.y = -1;
-            }
-            se[i] = ed;
-        }
-    }
-    // (wave-private LDS region: the wave's own writes are visible to it after the waitcnt
-    //  the compiler inserts; no workgroup barrier needed)
-    __builtin_amdgcn_wave_barrier();
 
+    // an edge that leaves its graph is an error: it is neutralised (dst = -1 never matches, src
+    // clamped) so that later gathers stay in range
+    auto fetch = [&](int c, int &es, int &ed) {
+        const int i = c * 64 + lane;
+        es = n0;
+        ed = -1;
+        if (i < ne) {
+            const int2 e = coo[e0 + i];
+            if (e.x < n0 || e.x >= n1 || e.y < n0 || e.y >= n1)
+                bad = true;
+            else {
+                es = e.x;
+                ed = e.y;
+            }
+        }
+    };
+    int rs[PREP_REG_CHUNKS], rd[PREP_REG_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < PREP_REG_CHUNKS; c++) {
+        rs[c] = n0;
+        rd[c] = -1;
+        if (inreg && c < nchunks)
+            fetch(c, rs[c], rd[c]);
+    }
+
+    GNNB_STAMP(1);
     int base = e0;
     for (int c0 = n0; c0 < n1; c0 += 64) {
         const int v = c0 + lane;
         const bool active = v < n1;
+        // ---- in-degree of node v: scan the edges, one broadcast per edge
         int cnt = 0;
-        if (cached) {
-            for (int i = 0; i < ne; i++)
-                cnt += (se[i].y == v) ? 1 : 0;
+        if (inreg) {
+#pragma unroll
+            for (int c = 0; c < PREP_REG_CHUNKS; c++) {
+                if (c < nchunks) {
+                    const int m = min(64, ne - c * 64);
+                    for (int i = 0; i < m; i++)
+                        cnt += (__builtin_amdgcn_readlane(rd[c], i) == v) ? 1 : 0;
+                }
+            }
         } else {
-            for (int i = 0; i < ne; i++) {
-                int2 ed = coo[e0 + i];
-                if (ed.x < n0 || ed.x >= n1 || ed.y < n0 || ed.y >= n1)
-                    bad = true;
-                else
-                    cnt += (ed.y == v) ? 1 : 0;
+            for (int c = 0; c < nchunks; c++) {
+                int es, ed;
+                fetch(c, es, ed);
+                const int m = min(64, ne - c * 64);
+                for (int i = 0; i < m; i++)
+                    cnt += (__builtin_amdgcn_readlane(ed, i) == v) ? 1 : 0;
             }
         }
         if (!active)
@@ -149,8 +170,9 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             amp[v] = logd / delta;
             att[v] = delta / logd;
         }
-        // stable fill: edges are visited in COO order; the first four sources also go into the
-        // node record
+        GNNB_STAMP(2);
+        // ---- stable fill: edges are visited in COO order; the first four sources also go into
+        // the node record
         int pos = start;
         int jf[4] = {v, v, v, v};
         auto put = [&](int src) {
@@ -161,17 +183,30 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             else if (q == 3) jf[3] = src;
             col[pos++] = src;
         };
-        if (cached) {
-            for (int i = 0; i < ne; i++) {
-                int2 ed = se[i];
-                if (ed.y == v)
-                    put(ed.x);
+        if (inreg) {
+#pragma unroll
+            for (int c = 0; c < PREP_REG_CHUNKS; c++) {
+                if (c < nchunks) {
+                    const int m = min(64, ne - c * 64);
+                    for (int i = 0; i < m; i++) {
+                        const int d = __builtin_amdgcn_readlane(rd[c], i);
+                        const int sc = __builtin_amdgcn_readlane(rs[c], i);
+                        if (d == v)
+                            put(sc);
+                    }
+                }
             }
         } else {
-            for (int i = 0; i < ne; i++) {
-                int2 ed = coo[e0 + i];
-                if (ed.y == v && ed.x >= n0 && ed.x < n1)
-                    put(ed.x);
+            for (int c = 0; c < nchunks; c++) {
+                int es, ed;
+                fetch(c, es, ed);
+                const int m = min(64, ne - c * 64);
+                for (int i = 0; i < m; i++) {
+                    const int d = __builtin_amdgcn_readlane(ed, i);
+                    const int sc = __builtin_amdgcn_readlane(es, i);
+                    if (d == v)
+                        put(sc);
+                }
             }
         }
         if (active) {
@@ -180,6 +215,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         }
         base += __shfl(incl, 63, 64);
     }
+    GNNB_STAMP_END(3);
     if (bad)
         atomicOr(err, 4);
 }
@@ -1135,8 +1171,10 @@ struct LdsRow {
 
 static constexpr int PIPE_TCAP = 512; // tile-table entries a workgroup keeps in LDS
 
+static constexpr int PIPE_THREADS = WG + 64; // 4 reducer waves + 1 loader wave
+
 template <int MODE, int VEC>
-__global__ __launch_bounds__(WG) void k_aggregate_pipe(
+__global__ __launch_bounds__(PIPE_THREADS) void k_aggregate_pipe(
     const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
     const int4 *__restrict__ node_rec, const int32_t *__restrict__ row_ptr,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
@@ -1153,9 +1191,14 @@ __global__ __launch_bounds__(WG) void k_aggregate_pipe(
     const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
     if (t1 <= t0)
         return;
-    for (int i = tid; i <= t1 - t0; i += WG)
+    for (int i = tid; i <= t1 - t0; i += PIPE_THREADS)
         stile[i] = tile_first[t0 + i];
     __syncthreads();
+    // Wave 4 is the loader: it alone issues the LDS-DMA of the next stage and waits for it, so its
+    // vmcnt holds nothing else.  The four reducer waves meet it at a raw s_barrier and never wait on
+    // vmcnt: on CDNA4 that counter includes stores, and a __syncthreads() per stage would make every
+    // stage wait for the previous stage's output rows to reach memory.
+    const bool loader = wave == 4; // wave-uniform
 
     auto plan = [&](int ta) {
         PipeStage st;
@@ -1186,19 +1229,19 @@ __global__ __launch_bounds__(WG) void k_aggregate_pipe(
         const char *gx = reinterpret_cast<const char *>(x + (size_t)st.nb * w);
         const int bytes = st.rows * w * 4;
         if (VEC == 4) {
-            for (int c = wave * 1024; c < bytes; c += (WG / 64) * 1024)
+            for (int c = 0; c < bytes; c += 1024)
                 if (c + lane * 16 < bytes)
                     dma16_to_lds(gx + c + lane * 16, lx + c);
         } else {
-            dma_dwords(gx, lx, st.rows * w, wave, lane, WG / 64);
+            dma_dwords(gx, lx, st.rows * w, 0, lane, 1);
         }
         const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
         const int rbytes = st.rows * 32;
-        for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
+        for (int c = 0; c < rbytes; c += 1024)
             if (c + lane * 16 < rbytes)
                 dma16_to_lds(grec + c + lane * 16, lrec + c);
         if (MODE == GNNB_AGG_GCN)
-            dma_dwords(dinv + st.nb, ldinv, st.rows, wave, lane, WG / 64);
+            dma_dwords(dinv + st.nb, ldinv, st.rows, 0, lane, 1);
     };
 
     const int nvec = w / VEC;
@@ -1208,12 +1251,23 @@ __global__ __launch_bounds__(WG) void k_aggregate_pipe(
     const int gl = tid & (G - 1);
 
     PipeStage cur = plan(t0);
-    issue(cur, 0);
     int b = 0;
+    if (loader) {
+        issue(cur, 0);
+        while (cur.ta < t1) {
+            const PipeStage nxt = plan(cur.tb);
+            // stage `cur` has landed -> release it; passing the barrier also means the reducers are
+            // done with the other buffer, which the next DMA overwrites
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue(nxt, b ^ 1);
+            cur = nxt;
+            b ^= 1;
+        }
+        return;
+    }
     while (cur.ta < t1) {
         const PipeStage nxt = plan(cur.tb);
-        __syncthreads(); // drains vmcnt: stage `cur` has landed; every wave is done with the other buffer
-        issue(nxt, b ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // stage `cur` is in LDS
         if (cur.staged) {
             const char *base = smem + (size_t)b * buf_bytes;
             const float *sx = reinterpret_cast<const float *>(base);
@@ -1316,8 +1370,8 @@ static hipError_t launch_aggregate_pipe_t(const BatchTables &t, const float *x, 
             return e;
         lds_allowed = lds;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, x, selfq, out, t.node_rec, t.row_ptr,
-                       t.col, t.dinv, t.tile_first, t.num_tiles, w, glog2, rows_cap, eps);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PIPE_THREADS), lds, s, x, selfq, out, t.node_rec,
+                       t.row_ptr, t.col, t.dinv, t.tile_first, t.num_tiles, w, glog2, rows_cap, eps);
     return hipGetLastError();
 }
 
