@@ -52,50 +52,14 @@ __device__ unsigned long long g_probe[8 * 8192];
 // re-read their edge list from global memory (L2) chunk by chunk.
 static constexpr int PREP_REG_CHUNKS = 4;
 
-__global__ __launch_bounds__(WG) void k_graph_prep(
-    const int2 *__restrict__ coo, const int32_t *__restrict__ node_ptr,
-    const int32_t *__restrict__ edge_ptr, int B, int N, int E, int32_t *__restrict__ row_ptr,
+// General path (any graph size): lane = destination node, edges scanned one at a time.
+__device__ void prep_graph_scan(
+    const int2 *__restrict__ coo, int n0, int n1, int e0, int e1, int32_t *__restrict__ row_ptr,
     int32_t *__restrict__ col, int4 *__restrict__ node_rec, float *__restrict__ dinv,
-    float *__restrict__ amp, float *__restrict__ att, float delta,
-    int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int tile_rows, int num_tiles,
-    int32_t *__restrict__ err)
+    float *__restrict__ amp, float *__restrict__ att, float delta, int32_t *__restrict__ err)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int g = blockIdx.x * (WG / 64) + wave;
-    if (g > B)
-        return;
 
-    // ---- node tiles: tile_first[t] = min{ node_ptr[g'] : node_ptr[g'] >= t*tile_rows }
-    {
-        // clamped so that a malformed node_ptr (flagged below) cannot write out of range
-        const int p = (g == B) ? N : min(max(node_ptr[g], 0), N);
-        const int t_lo = (g == 0) ? 0 : max(min(max(node_ptr[g - 1], 0), N) / tile_rows + 1, 0);
-        const int t_hi = (g == B) ? num_tiles : min(p / tile_rows, num_tiles);
-        // edges are grouped by graph, so the CSR segment of graph g starts at edge_ptr[g]
-        const int pe = (g == B) ? E : min(max(edge_ptr[g], 0), E);
-        for (int t = t_lo + lane; t <= t_hi; t += 64) {
-            tile_first[t] = p;
-            tile_edge[t] = pe;
-        }
-    }
-    if (g == B) {
-        if (lane == 0) {
-            row_ptr[N] = E;
-            if (node_ptr[B] != N || edge_ptr[B] != E || node_ptr[0] != 0 || edge_ptr[0] != 0)
-                atomicOr(err, 1);
-        }
-        return;
-    }
-
-    GNNB_STAMP(0);
-    const int n0 = node_ptr[g], n1 = node_ptr[g + 1];
-    const int e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
-    if (n0 > n1 || e0 > e1 || n1 > N || e1 > E || n0 < 0 || e0 < 0) {
-        if (lane == 0)
-            atomicOr(err, 2);
-        return;
-    }
     const int ne = e1 - e0;
     const int nchunks = (ne + 63) >> 6;
     const bool inreg = nchunks <= PREP_REG_CHUNKS; // wave-uniform
@@ -126,7 +90,6 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             fetch(c, rs[c], rd[c]);
     }
 
-    GNNB_STAMP(1);
     int base = e0;
     for (int c0 = n0; c0 < n1; c0 += 64) {
         const int v = c0 + lane;
@@ -170,7 +133,6 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             amp[v] = logd / delta;
             att[v] = delta / logd;
         }
-        GNNB_STAMP(2);
         // ---- stable fill: edges are visited in COO order; the first four sources also go into
         // the node record
         int pos = start;
@@ -214,6 +176,192 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             node_rec[2 * (size_t)v + 1] = make_int4(jf[2], jf[3], 0, 0);
         }
         base += __shfl(incl, 63, 64);
+    }
+    if (bad)
+        atomicOr(err, 4);
+}
+
+
+// Fast path (graphs of <= 256 nodes and <= 256 edges, i.e. every molecule): lanes hold EDGES.
+// One loop over the graph's destination nodes: ballot(dst == v) gives, in a single instruction,
+// the in-degree of v (popcount) and the rank of every edge among v's in-edges (popcount of the
+// lower lanes) -- stable, because lanes are in COO order.  Starts come from a wave prefix sum over
+// node lanes, and `col` is then written by ONE scatter per 64 edges instead of a divergent
+// store per edge.  n iterations of ~8 instructions replace 2e iterations of a dependent chain.
+static constexpr int PREP_FAST_NODES = 256; // 4 node chunks of 64 lanes
+static constexpr int PREP_FAST_EDGES = 256; // 4 edge chunks
+
+__global__ __launch_bounds__(WG) void k_graph_prep(
+    const int2 *__restrict__ coo, const int32_t *__restrict__ node_ptr,
+    const int32_t *__restrict__ edge_ptr, int B, int N, int E, int32_t *__restrict__ row_ptr,
+    int32_t *__restrict__ col, int4 *__restrict__ node_rec, float *__restrict__ dinv,
+    float *__restrict__ amp, float *__restrict__ att, float delta,
+    int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int tile_rows, int num_tiles,
+    int32_t *__restrict__ err)
+{
+    __shared__ int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * (WG / 64) + wave;
+    if (g > B)
+        return;
+
+    // ---- node tiles: tile_first[t] = min{ node_ptr[g'] : node_ptr[g'] >= t*tile_rows }
+    {
+        // clamped so that a malformed node_ptr (flagged below) cannot write out of range
+        const int p = (g == B) ? N : min(max(node_ptr[g], 0), N);
+        const int t_lo = (g == 0) ? 0 : max(min(max(node_ptr[g - 1], 0), N) / tile_rows + 1, 0);
+        const int t_hi = (g == B) ? num_tiles : min(p / tile_rows, num_tiles);
+        // edges are grouped by graph, so the CSR segment of graph g starts at edge_ptr[g]
+        const int pe = (g == B) ? E : min(max(edge_ptr[g], 0), E);
+        for (int t = t_lo + lane; t <= t_hi; t += 64) {
+            tile_first[t] = p;
+            tile_edge[t] = pe;
+        }
+    }
+    if (g == B) {
+        if (lane == 0) {
+            row_ptr[N] = E;
+            if (node_ptr[B] != N || edge_ptr[B] != E || node_ptr[0] != 0 || edge_ptr[0] != 0)
+                atomicOr(err, 1);
+        }
+        return;
+    }
+
+    GNNB_STAMP(0);
+    const int n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
+    if (n0 > n1 || e0 > e1 || n1 > N || e1 > E || n0 < 0 || e0 < 0) {
+        if (lane == 0)
+            atomicOr(err, 2);
+        return;
+    }
+    const int n = n1 - n0, ne = e1 - e0;
+    if (n > PREP_FAST_NODES || ne > PREP_FAST_EDGES) { // wave-uniform
+        prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, node_rec, dinv, amp, att, delta, err);
+        return;
+    }
+
+    // ---- edges -> registers (lane l holds edge 64c + l); an edge that leaves its graph is an error
+    // and is dropped (dst = -1 never matches)
+    constexpr int EC = PREP_FAST_EDGES / 64, NC = PREP_FAST_NODES / 64;
+    int es[EC], ed[EC], erank[EC];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < EC; c++) {
+        es[c] = n0;
+        ed[c] = -1;
+        erank[c] = 0;
+        const int i = c * 64 + lane;
+        if (i < ne) {
+            const int2 e = coo[e0 + i];
+            if (e.x < n0 || e.x >= n1 || e.y < n0 || e.y >= n1)
+                bad = true;
+            else {
+                es[c] = e.x;
+                ed[c] = e.y - n0; // local destination
+            }
+        }
+    }
+    GNNB_STAMP(1);
+    // ---- one pass over destination nodes: degree of node v -> node lane (v & 63) of chunk v >> 6;
+    // rank of each matching edge among v's in-edges -> that edge's lane
+    int deg[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++)
+        deg[q] = 0;
+    const int nec = (ne + 63) >> 6;
+    if (nec <= 1 && n <= 64) {
+        // the common molecule case (<= 64 nodes, <= 64 edges): one chunk each, ~6 instructions per node
+        for (int v = 0; v < n; v++) {
+            const unsigned long long m = __ballot(ed[0] == v);
+            if (ed[0] == v)
+                erank[0] = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (lane == v)
+                deg[0] = __popcll(m);
+        }
+    } else {
+        for (int v = 0; v < n; v++) {
+            int before = 0; // in-edges of v in earlier edge chunks
+#pragma unroll
+            for (int c = 0; c < EC; c++) {
+                if (c < nec) {
+                    const unsigned long long m = __ballot(ed[c] == v);
+                    if (ed[c] == v)
+                        erank[c] = before + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    before += __popcll(m);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+                if ((v >> 6) == q && lane == (v & 63))
+                    deg[q] = before;
+        }
+    }
+    GNNB_STAMP(2);
+    // ---- row starts: wave prefix sum over node lanes, chunk by chunk
+    int start[NC];
+    int base = e0;
+#pragma unroll
+    for (int q = 0; q < NC; q++) {
+        start[q] = 0;
+        if (q * 64 < n) {
+            int incl = deg[q];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off)
+                    incl += t;
+            }
+            start[q] = base + incl - deg[q];
+            base += __shfl(incl, 63, 64);
+            const int vl = q * 64 + lane;
+            if (vl < n) {
+                const int v = n0 + vl;
+                row_ptr[v] = start[q];
+                dinv[v] = 1.0f / sqrtf(1.0f + (float)deg[q]);
+                const int dcl = deg[q] < 1 ? 1 : deg[q]; // gnn_builder_lib.h:1972-1982
+                const float logd = logf((float)(dcl + 1));
+                amp[v] = logd / delta;
+                att[v] = delta / logd;
+                // default record: unused source slots alias the node itself
+                int32_t *f = s_first[wave] + vl * 4;
+                f[0] = v;
+                f[1] = v;
+                f[2] = v;
+                f[3] = v;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- scatter: col[start[dst] + rank] = src, one store instruction per 64 edges
+#pragma unroll
+    for (int c = 0; c < EC; c++) {
+        if (c < nec) { // wave-uniform: the cross-lane reads below run with every lane active
+            const int d = ed[c] < 0 ? 0 : ed[c];
+            int st = 0;
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const int t = __shfl(start[q], d & 63, 64);
+                if ((d >> 6) == q)
+                    st = t;
+            }
+            if (ed[c] >= 0) {
+                col[st + erank[c]] = es[c];
+                if (erank[c] < 4)
+                    s_first[wave][d * 4 + erank[c]] = es[c];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < NC; q++) {
+        const int vl = q * 64 + lane;
+        if (vl < n) {
+            const int32_t *f = s_first[wave] + vl * 4;
+            node_rec[2 * (size_t)(n0 + vl)] = make_int4(start[q], deg[q], f[0], f[1]);
+            node_rec[2 * (size_t)(n0 + vl) + 1] = make_int4(f[2], f[3], 0, 0);
+        }
     }
     GNNB_STAMP_END(3);
     if (bad)
