@@ -38,6 +38,7 @@ struct Options {
     int agg_xcd_remap; // remap block ids so each XCD owns a contiguous run of row chunks
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
     int gemm_max_wg_per_cu;
+    int fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
 };
 Options &options();
@@ -59,6 +60,12 @@ struct GemmArgs {
     int32_t wvec[4];   // ... for W
     int32_t nseg;
 };
+// aggregate + dense update of a narrow-input layer in one launch; hipErrorNotSupported -> caller
+// runs launch_aggregate + launch_linear
+hipError_t launch_conv_gather(const BatchTables &t, int agg_kind, float eps, const float *x, int lda,
+                              int K, const float *w, int ldw, const float *bias, const float *skip,
+                              float *y, int N, int act, hipStream_t s);
+
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
                          const float *skip, float *y, int M, int N, int act, hipStream_t s);
 

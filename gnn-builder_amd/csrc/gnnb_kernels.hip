@@ -1807,14 +1807,37 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 // Lane (i = l&15, g = l>>4) reads chunk 4q+g of row i: k = 16q+4g .. +3; MFMA step (q,s) contracts
 // k in {16q + 4g + s : g = 0..3}, the same k-permutation on A and W.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef GNNB_LR_SR
+#define GNNB_LR_SR 2
+#endif
+// a full stage's vector epilogue issues 2*SR 16-B stores per wave
+#if GNNB_LR_SR == 1
+#define GNNB_LR_COUNTED_WAIT "s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier"
+#else
+#define GNNB_LR_COUNTED_WAIT "s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier"
+#endif
+
+// Optional fused gather: when `rec` is set the A stage is not copied from memory but PRODUCED -- the
+// workgroup aggregates its destination rows (GCN / sum / mean semantics of k_aggregate_*) from the
+// raw feature matrix straight into the LDS stage.  Used for narrow first layers (F_in = 9, 11):
+// the gather touches 44-byte rows that live in L2, so the separate aggregate launch and its
+// [N, F_in] round trip through memory disappear (reference gcn_conv / gin_conv do the same per
+// node: aggregate, then `linear`, gnn_builder_lib.h:1346-1379, :1497-1544).
+struct GatherDesc {
+    const int4 *rec;     // node records {rp0, deg, j0, j1}{j2, j3, -, -}; nullptr = plain A copy
+    const int32_t *col;  // CSR sources (degree > 4)
+    const float *dinv;   // GCN normaliser
+    int32_t mode;        // gnnb_agg (GCN, SUM, MEAN)
+    float eps;
+};
 
 template <int KQ, bool VEC_A> // KQ = ceil(K/16) in {1,2,4,8}; VEC_A: K % 4 == 0 and 16-B aligned rows
 __global__ __launch_bounds__(WG, 3) void k_linear_reg(
     const float *__restrict__ A, int lda, int K, const float *__restrict__ W, int ldw,
     const float *__restrict__ bias, const float *__restrict__ skip, float *__restrict__ Y, int M, int N,
-    int act, int rg_log2, int P, int vec_out)
+    int act, int rg_log2, int P, int vec_out, GatherDesc gd)
 {
-    constexpr int SR = 2;      // 16-row units per stage
+    constexpr int SR = GNNB_LR_SR; // 16-row units per stage
     constexpr int EPI_LD = 36; // padded row of the epilogue transpose scratch
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1942,16 +1965,61 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
     // vmcnt <= 4 proves that DMA has landed while the stores stay in flight; anything irregular
     // (ragged stage, scalar epilogue, a wave without columns) falls back to a full drain.
     const bool wave_has_cols = nq < N || (n0 < N); // some lane of this wave stores
+    const bool gather = !VEC_A && gd.rec != nullptr; // workgroup-uniform
+    // gather producer: element (row i, feature f) of stage j, neighbours in CSR order, self term last
+    auto produce = [&](int j, int bb) {
+        float *dst = reinterpret_cast<float *>(smem + (size_t)bb * buf_bytes);
+        const int m0i = row_begin(j);
+        const int rows = rows_of(j);
+        for (int e = tid; e < rows * K; e += WG) {
+            const int i = e / K, f = e - i * K;
+            const int node = m0i + i;
+            const int4 r0 = gd.rec[2 * (size_t)node], r1 = gd.rec[2 * (size_t)node + 1];
+            const int deg = r0.y;
+            const int jn[4] = {r0.z, r0.w, r1.x, r1.y};
+            const float xs = A[(size_t)node * lda + f];
+            float xv[4], sv[4];
+            const float di = gd.mode == GNNB_AGG_GCN ? gd.dinv[node] : 1.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { // unused slots alias the node itself (cache hit, discarded)
+                xv[q] = A[(size_t)jn[q] * lda + f];
+                sv[q] = gd.mode == GNNB_AGG_GCN ? gd.dinv[jn[q]] : 1.0f;
+            }
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (deg > q)
+                    acc += xv[q] * (di * sv[q]);
+            for (int k = r0.x + 4; k < r0.x + deg; k++) {
+                const int jj = gd.col[k];
+                acc += A[(size_t)jj * lda + f] * (di * (gd.mode == GNNB_AGG_GCN ? gd.dinv[jj] : 1.0f));
+            }
+            if (gd.mode == GNNB_AGG_GCN)
+                acc += xs * (di * di);
+            else if (gd.mode == GNNB_AGG_SUM)
+                acc += xs * (1.0f + gd.eps);
+            else if (deg > 0)
+                acc = acc / (float)deg;
+            dst[e] = acc;
+        }
+    };
     bool prev_counted = false;
-    issue(0, 0);
+    if (gather)
+        produce(0, 0);
+    else
+        issue(0, 0);
     int b = 0;
     for (int j = 0; j < nstages; j++, b ^= 1) {
         if (prev_counted)
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile(GNNB_LR_COUNTED_WAIT ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (j + 1 < nstages)
-            issue(j + 1, b ^ 1);
+        if (j + 1 < nstages) {
+            if (gather)
+                produce(j + 1, b ^ 1); // plain loads + ds_write; the next barrier publishes it
+            else
+                issue(j + 1, b ^ 1);
+        }
         GNNB_PT(pt_wait, pt_last);
         const float *sA = reinterpret_cast<const float *>(smem + (size_t)b * buf_bytes);
         const int m0 = row_begin(j);
@@ -1986,7 +2054,14 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
             }
             // k-step outermost: consecutive MFMAs hit the four different accumulators, so the 40-cycle
             // dependent latency of v_mfma_f32_16x16x4_f32 hides behind its 32-cycle issue interval
-            const float as[SR][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+            float as[SR][4];
+#pragma unroll
+            for (int rt = 0; rt < SR; rt++) {
+                as[rt][0] = a[rt].x;
+                as[rt][1] = a[rt].y;
+                as[rt][2] = a[rt].z;
+                as[rt][3] = a[rt].w;
+            }
 #pragma unroll
             for (int sk = 0; sk < 4; sk++)
 #pragma unroll
@@ -2001,7 +2076,7 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
         GNNB_PT(pt_mma, pt_last);
         // epilogue: C/D of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
         const bool full = (m_end - m0) == stage_rows;
-        prev_counted = vec_out && full && wave_has_cols && (skip == nullptr);
+        prev_counted = vec_out && full && wave_has_cols && (skip == nullptr) && !gather;
         auto epilogue = [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
             if (vec_out) {
@@ -2016,8 +2091,8 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
                             sC[(rt * 16 + lg * 4 + r) * EPI_LD + u * 16 + li] = acc[rt][u][r];
                 // (same wave wrote and reads: the compiler's lgkmcnt wait orders it; no barrier)
 #pragma unroll
-                for (int ps = 0; ps < 4; ps++) {
-                    const int rl = ps * 8 + (lane >> 3); // row inside the wave's 32 (unit rl>>4)
+                for (int ps = 0; ps < 2 * SR; ps++) {
+                    const int rl = ps * 8 + (lane >> 3); // row inside the wave's 16*SR (unit rl>>4)
                     const int m = m0 + ((rl >> 4) * RG + rgi) * 16 + (rl & 15);
                     float4 v = *reinterpret_cast<const float4 *>(sC + rl * EPI_LD + c4);
                     if (m < m_end && nq < N) {
@@ -2080,12 +2155,12 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
 template <int KQ, bool VEC_A>
 static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const float *W, int ldw,
                                       const float *bias, const float *skip, float *Y, int M, int N,
-                                      int act, hipStream_t s)
+                                      int act, hipStream_t s, const GatherDesc &gd = GatherDesc{})
 {
     // waves: N <= 32 -> 4 row groups x 1 column slice; N <= 64 -> 2 x 2; else 1 x 4 (128 cols / WG)
     const int rg_log2 = N <= 32 ? 2 : (N <= 64 ? 1 : 0);
     const int cols_per_wg = 128 >> rg_log2;
-    const int stage_rows = (16 * 2) << rg_log2;
+    const int stage_rows = (16 * GNNB_LR_SR) << rg_log2;
     const int gy = (N + cols_per_wg - 1) / cols_per_wg;
     const size_t buf = (((size_t)stage_rows * K * 4) + 15) & ~(size_t)15;
     const size_t lds = 2 * buf + 4 * 32 * 36 * 4; // two stage buffers + per-wave epilogue scratch
@@ -2121,14 +2196,16 @@ static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const floa
         occ_blocks = nb;
         occ_lds = lds;
     }
-    const int cap = options().gemm_max_wg_per_cu;
+    // K = 128 keeps 64 weight registers per lane and is MFMA-bound: 2 workgroups per CU measured
+    // best.  Narrow K is store- / gather-latency-bound: the more resident workgroups the better.
+    const int cap = KQ >= 8 ? options().gemm_max_wg_per_cu : (KQ >= 4 ? 3 : 6);
     int gx = num_cus * (occ_blocks > cap ? cap : occ_blocks) / gy;
     if (gx < 1)
         gx = 1;
     if (gx > num_stages)
         gx = num_stages; // at least one full stage per workgroup
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(WG), lds, s, A, lda, K, W, ldw, bias, skip, Y, M, N, act,
-                       rg_log2, P, vec_out);
+                       rg_log2, P, vec_out, gd);
     return hipGetLastError();
 }
 
@@ -2155,6 +2232,24 @@ static hipError_t launch_linear_reg(const GemmArgs &g, const float *w, int ldw, 
     }
 #undef GNNB_LR_CASE
     return hipErrorInvalidValue;
+}
+
+// Fused narrow-input conv: Y = act(aggregate(x) . W^T + b (+ skip)) in one launch (K <= 32).
+hipError_t launch_conv_gather(const BatchTables &t, int agg_kind, float eps, const float *x, int lda,
+                              int K, const float *w, int ldw, const float *bias, const float *skip,
+                              float *y, int N, int act, hipStream_t s)
+{
+    if (K > 32 || agg_kind == GNNB_AGG_PNA || t.num_nodes <= 0)
+        return hipErrorNotSupported;
+    GatherDesc gd;
+    gd.rec = t.node_rec;
+    gd.col = t.col;
+    gd.dinv = t.dinv;
+    gd.mode = agg_kind;
+    gd.eps = eps;
+    if (K <= 16)
+        return launch_linear_reg_t<1, false>(x, lda, K, w, ldw, bias, skip, y, t.num_nodes, N, act, s, gd);
+    return launch_linear_reg_t<2, false>(x, lda, K, w, ldw, bias, skip, y, t.num_nodes, N, act, s, gd);
 }
 
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,

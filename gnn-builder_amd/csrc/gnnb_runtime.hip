@@ -55,7 +55,8 @@ Options &options()
                         env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32),
                         env_int("GNNB_AGG_VARIANT", 0),      env_int("GNNB_AGG_ROWS_PER_WG", 48),
                         env_int("GNNB_AGG_XCD_REMAP", 1),    env_int("GNNB_GEMM_VARIANT", 0),
-                        env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_FUSE_HEAD", 1)};
+                        env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_FUSE_NARROW", 1),
+                        env_int("GNNB_FUSE_HEAD", 1)};
     return o;
 }
 
@@ -194,6 +195,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_rows_per_wg = value;
     else if (!strcmp(name, "agg_xcd_remap") && value >= 0 && value <= 1)
         o.agg_xcd_remap = value;
+    else if (!strcmp(name, "fuse_narrow") && value >= 0 && value <= 1)
+        o.fuse_narrow = value;
     else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
         o.fuse_head = value;
     else if (!strcmp(name, "gemm_variant") && value >= 0 && value <= 1)
@@ -589,19 +592,39 @@ int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const flo
         switch (d.conv_type) {
         case GNNB_CONV_GCN:
             // aggregate at the input width, then transform (the reference's order, lib:1346-1379)
+            if (options().fuse_narrow && fi <= 32) {
+                hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_GCN, 0.f, cur, fi, fi, p[0], fi, p[1], skip, nxt,
+                                                   fo, d.activation, (hipStream_t)stream);
+                if (he == hipSuccess)
+                    break;
+                if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
+            }
             if ((rc = gnnb_aggregate(ws, GNNB_AGG_GCN, cur, nullptr, ws->agg, fi, 0.f, stream)))
                 return rc;
             if ((rc = linear1(ws->agg, fi, fi, p[0], fi, p[1], skip, nxt, N, fo, d.activation, stream)))
                 return rc;
             break;
-        case GNNB_CONV_GIN:
-            if ((rc = gnnb_aggregate(ws, GNNB_AGG_SUM, cur, nullptr, ws->agg, fi, d.gin_eps, stream)))
-                return rc;
-            if ((rc = linear1(ws->agg, fi, fi, p[0], fi, p[1], nullptr, ws->tmp0, N, fo, GNNB_ACT_RELU, stream)))
-                return rc;
+        case GNNB_CONV_GIN: {
+            bool fused = false;
+            if (options().fuse_narrow && fi <= 32) {
+                hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_SUM, d.gin_eps, cur, fi, fi, p[0], fi, p[1], nullptr,
+                                                   ws->tmp0, fo, GNNB_ACT_RELU, (hipStream_t)stream);
+                if (he == hipSuccess)
+                    fused = true;
+                else if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
+            }
+            if (!fused) {
+                if ((rc = gnnb_aggregate(ws, GNNB_AGG_SUM, cur, nullptr, ws->agg, fi, d.gin_eps, stream)))
+                    return rc;
+                if ((rc = linear1(ws->agg, fi, fi, p[0], fi, p[1], nullptr, ws->tmp0, N, fo, GNNB_ACT_RELU, stream)))
+                    return rc;
+            }
             if ((rc = linear1(ws->tmp0, fo, fo, p[2], fo, p[3], skip, nxt, N, fo, d.activation, stream)))
                 return rc;
             break;
+        }
         case GNNB_CONV_SAGE: {
             if ((rc = gnnb_aggregate(ws, GNNB_AGG_MEAN, cur, nullptr, ws->agg, fi, 0.f, stream)))
                 return rc;

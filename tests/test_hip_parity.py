@@ -330,3 +330,27 @@ def test_fused_readout_equals_separate_kernels(dev, mlp_hidden, mlp_layers, task
         runtime.set_option("fuse_head", 1)
     assert np.abs(outs[0] - ref).max() < TOL and np.abs(outs[1] - ref).max() < TOL
     assert np.abs(outs[0] - outs[1]).max() < 1e-5
+
+
+@pytest.mark.parametrize("conv,fin", [("gcn", 11), ("gin", 9), ("gcn", 17), ("gin", 32), ("gcn", 4)])
+def test_fused_narrow_layer_equals_separate_kernels(dev, conv, fin):
+    """First layer with aggregate + update in one kernel vs the two-kernel path vs the oracle
+    (incl. degree > 4 nodes and empty graphs)."""
+    model = make_model(conv, in_dim=fin, hidden=64, layers=2, task_out=3)
+    rng = np.random.default_rng(fin)
+    star = np.array([[i, 0] for i in range(1, 9)] + [[0, i] for i in range(1, 9)])  # node 0 has in-degree 8
+    graphs = [(rng.uniform(-1, 1, (9, fin)), star), (rng.uniform(-1, 1, (0, fin)), np.zeros((0, 2)))]
+    b0 = synthetic.make_batch("qm9", 60, seed=fin)
+    graphs += [(rng.uniform(-1, 1, (b0.graph(g)[0].shape[0], fin)), b0.graph(g)[1]) for g in range(60)]
+    batch = pack_graphs([(np.asarray(x, np.float32), np.asarray(c, np.int32)) for x, c in graphs])
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    outs = []
+    try:
+        for fuse in (1, 0):
+            runtime.set_option("fuse_narrow", fuse)
+            outs.append(cm.forward(*to_dev(batch, dev)).cpu().numpy())
+    finally:
+        runtime.set_option("fuse_narrow", 1)
+    assert np.abs(outs[0] - ref).max() < TOL and np.abs(outs[1] - ref).max() < TOL
+    assert np.abs(outs[0] - outs[1]).max() < 1e-5
