@@ -20,6 +20,8 @@ struct BatchTables {
     float *att;          // [N]   PNA attenuation    delta/log(max(d,1)+1)
     int32_t *tile_first; // [T+1] first node of node-tile t; tiles are cut at graph boundaries
     int32_t *tile_edge;  // [T+1] row_ptr[tile_first[t]] (first CSR entry of the tile)
+    int32_t *tile_graph; // [T+1] index of the graph that starts at tile_first[t] (B past the end)
+    int32_t max_graph_nodes_hint; // caller's promise (0 = unknown); validated on device by prep
     int32_t *err;        // [1]   != 0 when the batch was malformed
     const int32_t *node_ptr; // [B+1] caller's graph_node_ptr (device)
     int32_t num_graphs, num_nodes, num_edges;
@@ -39,6 +41,7 @@ struct Options {
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
     int gemm_max_wg_per_cu;
     int fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
+    int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
 };
 Options &options();
@@ -79,7 +82,14 @@ struct HeadArgs {
 // returns hipErrorNotSupported when the head does not fit the fused kernel (caller falls back)
 hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_graphs, int d,
                            const int32_t *pools, int num_pools, const HeadArgs &head, int act,
-                           float *out, hipStream_t s);
+                           float *out, hipStream_t s, const float *prepooled = nullptr);
+
+// Whole 2-layer GCN conv stack + pooling in one persistent launch (graphs staged once in LDS):
+// x -> agg -> W0 -> act -> agg -> W1 -> act -> pooled [B, np*h1].  hipErrorNotSupported when the
+// model / batch does not qualify (caller runs the layer-by-layer path).
+hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
+                             int h0, const float *w1, const float *b1, int h1, int act,
+                             const int32_t *pools, int num_pools, float *pooled, hipStream_t s);
 
 hipError_t launch_global_pool(const float *x, const int32_t *node_ptr, int num_graphs, int d,
                               const int32_t *pools, int num_pools, float *out, hipStream_t s);

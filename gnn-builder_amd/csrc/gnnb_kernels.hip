@@ -15,10 +15,16 @@ namespace gnnb {
 
 static constexpr int WG = 256; // 4 wavefronts
 
+// compile-time integer tag (generic lambdas dispatch on it)
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
+
 // Diagnostic build only (-DGNNB_PROBE, tools/probe_agg.py): per-workgroup phase stamps.  The
 // product library is built without it and executes no stamp.
 #ifdef GNNB_PROBE
-__device__ unsigned long long g_probe[8 * 8192];
+__device__ unsigned long long g_probe[16 * 8192];
 #define GNNB_STAMP(slot)                                                                   \
     do {                                                                                   \
         if (threadIdx.x == 0 && blockIdx.x < 8192) {                                       \
@@ -196,8 +202,8 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     const int32_t *__restrict__ edge_ptr, int B, int N, int E, int32_t *__restrict__ row_ptr,
     int32_t *__restrict__ col, int4 *__restrict__ node_rec, float *__restrict__ dinv,
     float *__restrict__ amp, float *__restrict__ att, float delta,
-    int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int tile_rows, int num_tiles,
-    int32_t *__restrict__ err)
+    int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int32_t *__restrict__ tile_graph,
+    int tile_rows, int num_tiles, int max_graph_nodes_hint, int32_t *__restrict__ err)
 {
     __shared__ int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node
     const int lane = threadIdx.x & 63;
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         for (int t = t_lo + lane; t <= t_hi; t += 64) {
             tile_first[t] = p;
             tile_edge[t] = pe;
+            tile_graph[t] = g;
         }
     }
     if (g == B) {
@@ -237,6 +244,8 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         return;
     }
     const int n = n1 - n0, ne = e1 - e0;
+    if (max_graph_nodes_hint > 0 && n > max_graph_nodes_hint && lane == 0)
+        atomicOr(err, 8); // the caller's max_graph_nodes promise does not hold for this batch
     if (n > PREP_FAST_NODES || ne > PREP_FAST_EDGES) { // wave-uniform
         prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, node_rec, dinv, amp, att, delta, err);
         return;
@@ -377,8 +386,8 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
     const int grid = (waves + (WG / 64) - 1) / (WG / 64);
     hipLaunchKernelGGL(k_graph_prep, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                        edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.node_rec,
-                       t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_rows, t.num_tiles,
-                       t.err);
+                       t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.tile_rows,
+                       t.num_tiles, t.max_graph_nodes_hint, t.err);
     return hipGetLastError();
 }
 
@@ -661,7 +670,10 @@ static hipError_t launch_aggregate_t(const BatchTables &t, const float *x, const
 // Per-row state of the streaming kernel: `begin` issues the self row and the first two
 // neighbour rows (three independent 16-B loads per lane), `finish` consumes them.  Two rows per
 // lane group are begun before either is finished, so six loads per lane are in flight.
-template <int MODE, int VEC>
+// EC: the workgroup's col slice is cached in LDS (compile-time, so the index read is a plain ds_read
+// or a plain global_load -- a runtime select between an LDS and a global pointer becomes a FLAT load
+// whose wait also covers every outstanding row load and store)
+template <int MODE, int VEC, bool EC>
 struct AggRow {
     typedef Vf<VEC> V;
     int node, rp0, rp1, j0, j1;
@@ -669,8 +681,15 @@ struct AggRow {
     V xi, a, b;
     bool valid;
 
+    __device__ inline int nbr(const int32_t *scol, const int32_t *__restrict__ col, int k, int eb) const
+    {
+        if (EC)
+            return scol[k - eb];
+        return col[k];
+    }
+
     __device__ inline void begin(bool ok, int nb, int r, const int32_t *srp, const int32_t *scol, int eb,
-                                 bool ecached, const int32_t *__restrict__ col,
+                                 const int32_t *__restrict__ col,
                                  const float *__restrict__ x, const float *__restrict__ xs,
                                  const float *__restrict__ dinv, int w, int fo)
     {
@@ -681,8 +700,8 @@ struct AggRow {
         rp0 = srp[r];
         rp1 = srp[r + 1];
         // neighbours 0 and 1; a missing one aliases the self row (cache hit, result discarded)
-        j0 = rp0 < rp1 ? (ecached ? scol[rp0 - eb] : col[rp0]) : node;
-        j1 = rp0 + 1 < rp1 ? (ecached ? scol[rp0 + 1 - eb] : col[rp0 + 1]) : j0;
+        j0 = rp0 < rp1 ? nbr(scol, col, rp0, eb) : node;
+        j1 = rp0 + 1 < rp1 ? nbr(scol, col, rp0 + 1, eb) : j0;
         xi = V::load(xs + (size_t)node * w + fo);
         a = V::load(x + (size_t)j0 * w + fo);
         b = V::load(x + (size_t)j1 * w + fo);
@@ -693,8 +712,7 @@ struct AggRow {
         }
     }
 
-    __device__ inline void finish(const int32_t *scol, int eb, bool ecached,
-                                  const int32_t *__restrict__ col, const float *__restrict__ x,
+    __device__ inline void finish(const int32_t *scol, int eb, const int32_t *__restrict__ col, const float *__restrict__ x,
                                   const float *__restrict__ dinv, float *__restrict__ out, int w,
                                   int fo, float eps)
     {
@@ -725,7 +743,7 @@ struct AggRow {
         if (deg > 1)
             take(b, s1, false);
         for (int k = rp0 + 2; k < rp1; k++) { // degree > 2: the remaining neighbours, in CSR order
-            const int j = ecached ? scol[k - eb] : col[k];
+            const int j = nbr(scol, col, k, eb);
             const V v = V::load(x + (size_t)j * w + fo);
             take(v, (MODE == GNNB_AGG_GCN) ? dinv[j] : 0.0f, false);
         }
@@ -789,16 +807,23 @@ __global__ __launch_bounds__(WG) void k_aggregate_stream(
     const int gl = tid & (G - 1);
     const float *xs = (MODE == GNNB_AGG_PNA) ? selfq : x; // PNA: the self term is q_i, neighbours p_j
 
-    for (int r = grp; r < rows; r += 2 * groups) {
-        for (int f = gl; f < nvec; f += G) {
-            const int fo = f * VEC;
-            AggRow<MODE, VEC> A, B;
-            A.begin(true, nb, r, srp, scol, eb, ecached, col, x, xs, dinv, w, fo);
-            B.begin(r + groups < rows, nb, r + groups, srp, scol, eb, ecached, col, x, xs, dinv, w, fo);
-            A.finish(scol, eb, ecached, col, x, dinv, out, w, fo, eps);
-            B.finish(scol, eb, ecached, col, x, dinv, out, w, fo, eps);
+    auto run = [&](auto ectag) {
+        constexpr bool EC = decltype(ectag)::value != 0;
+        for (int r = grp; r < rows; r += 2 * groups) {
+            for (int f = gl; f < nvec; f += G) {
+                const int fo = f * VEC;
+                AggRow<MODE, VEC, EC> A, B;
+                A.begin(true, nb, r, srp, scol, eb, col, x, xs, dinv, w, fo);
+                B.begin(r + groups < rows, nb, r + groups, srp, scol, eb, col, x, xs, dinv, w, fo);
+                A.finish(scol, eb, col, x, dinv, out, w, fo, eps);
+                B.finish(scol, eb, col, x, dinv, out, w, fo, eps);
+            }
         }
-    }
+    };
+    if (ecached)
+        run(IntTag<1>{});
+    else
+        run(IntTag<0>{});
 }
 
 template <int MODE, int VEC>
@@ -1032,6 +1057,33 @@ __device__ inline void dma_dwords(const void *g, void *l, int count, int wave, i
         if (c + lane < count)
             dma4_to_lds(gs + (size_t)(c + lane) * 4, ls + (size_t)c * 4);
 }
+
+// "Untracked" forms for software-pipelined kernels.  The compiler's waitcnt pass cannot tell which
+// LDS bytes an in-flight LDS-DMA will write (dynamic shared memory carries no alias scopes), so after
+// the builtin it puts s_waitcnt vmcnt(0) in front of EVERY later ds_read -- which serialises "issue
+// the next stage's DMA, then compute on the current stage" completely.  Issued from inline assembly
+// the DMA is invisible to that pass; the kernel then owns the ordering and MUST wait itself
+// (dma_wait_all / a counted s_waitcnt, then a barrier) before any wave reads the destination.
+// Compiler-inserted vmcnt waits stay correct: extra outstanding operations only make vmcnt(N) stronger.
+__device__ inline void dma16_to_lds_u(const void *gsrc_lane, void *lds_wave_base)
+{
+    const uint32_t a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_vptr)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(gsrc_lane) : "memory");
+}
+__device__ inline void dma4_to_lds_u(const void *gsrc_lane, void *lds_wave_base)
+{
+    const uint32_t a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_vptr)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(a), "v"(gsrc_lane) : "memory");
+}
+__device__ inline void dma_dwords_u(const void *g, void *l, int count, int wave, int lane, int nwaves)
+{
+    const char *gs = reinterpret_cast<const char *>(g);
+    char *ls = reinterpret_cast<char *>(l);
+    for (int c = wave * 64; c < count; c += nwaves * 64)
+        if (c + lane < count)
+            dma4_to_lds_u(gs + (size_t)(c + lane) * 4, ls + (size_t)c * 4);
+}
+__device__ inline void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int MODE, int VEC>
 __global__ __launch_bounds__(WG) void k_aggregate_dma(
@@ -1613,10 +1665,6 @@ __device__ inline float act_t(float v)
         return tanhf(v);
     return v;
 }
-template <int V>
-struct IntTag {
-    static constexpr int value = V;
-};
 // calls f(IntTag<act>{}) with `act` turned into a compile-time constant
 #define GNNB_DISPATCH_ACT(act, f)                        \
     switch (act) {                                       \
@@ -1938,7 +1986,7 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
                 if (L < nchunks) {
                     const int i = L / C, sl = L - i * C;
                     const int c = sl ^ (i & (P - 1));
-                    dma16_to_lds(A + (size_t)(m0i + i) * lda + c * 4, dst + (size_t)c0 * 16);
+                    dma16_to_lds_u(A + (size_t)(m0i + i) * lda + c * 4, dst + (size_t)c0 * 16);
                 }
             }
         } else {
@@ -1947,7 +1995,7 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
                 const int L = c0 + lane;
                 if (L < nd) {
                     const int i = L / K, kk = L - i * K;
-                    dma4_to_lds(A + (size_t)(m0i + i) * lda + kk, dst + (size_t)c0 * 4);
+                    dma4_to_lds_u(A + (size_t)(m0i + i) * lda + kk, dst + (size_t)c0 * 4);
                 }
             }
         }
@@ -2406,12 +2454,15 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_pool_mlp(const float *__restri
                                                  const int32_t *__restrict__ node_ptr, int B, int d,
                                                  int glog2, int p0, int p1, int p2, int np,
                                                  HeadArgs head, float *__restrict__ out,
+                                                 const float *__restrict__ prepooled,
                                                  int act0_floats, int act1_floats, int woff0, int woff1, int woff2, int woff3,
                                                  int woff4, int woff5, int woff6, int woff7)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // buffer 0 holds the pooled tile and every even layer's output, buffer 1 the odd ones
-    float *actbuf[2] = {reinterpret_cast<float *>(smem), reinterpret_cast<float *>(smem) + act0_floats};
+    // (LDS pointers derived arithmetically from smem: a runtime-indexed pointer array turns the
+    // accesses into FLAT loads that wait on vmcnt)
+    float *const act_lo = reinterpret_cast<float *>(smem);
     float *wbase = reinterpret_cast<float *>(smem) + (size_t)act0_floats + act1_floats;
     const int woff[8] = {woff0, woff1, woff2, woff3, woff4, woff5, woff6, woff7};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2453,6 +2504,20 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_pool_mlp(const float *__restri
         }
     }
     GNNB_STAMP(1);
+    if (prepooled != nullptr) {
+        // ---- 1'. the pooled tile already exists ([B, k*d], written by the fused conv stack): DMA this
+        // workgroup's 16 rows into the swizzled LDS tile
+        const int k0 = head.dims[0], C0 = k0 >> 2, P0 = head_swz_p(k0);
+        const int rows = min(HEAD_GRAPHS, B - g0), nch = rows * C0;
+        for (int c0 = wave * 64; c0 < nch; c0 += (HEAD_THREADS / 64) * 64) {
+            const int L = c0 + lane;
+            if (L < nch) {
+                const int r = L / C0, sl = L - r * C0;
+                dma16_to_lds(prepooled + (size_t)(g0 + r) * k0 + ((sl ^ (r & (P0 - 1))) << 2),
+                             reinterpret_cast<char *>(act_lo) + (size_t)c0 * 16);
+            }
+        }
+    } else
     // ---- 1. pooling: one lane group per graph, rows in order
     {
         const int G = 1 << glog2, groups = HEAD_THREADS >> glog2;
@@ -2507,7 +2572,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_pool_mlp(const float *__restri
                         r = n > 0 ? vdiv(sum, V::splat((float)n)) : V::splat(0.0f);
                     else if (pools[kk] == GNNB_POOL_MAX)
                         r = mx;
-                    r.store(actbuf[0] + head_off(gi, kk * d + fo, k0, P0));
+                    r.store(act_lo + head_off(gi, kk * d + fo, k0, P0));
                 }
             }
         }
@@ -2524,8 +2589,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_pool_mlp(const float *__restri
         const int k = head.dims[l], n = head.dims[l + 1];
         const bool last = (l == head.nlin - 1);
         const int Pk = head_swz_p(k), Pn = head_swz_p(n);
-        const float *sA = actbuf[cur];
-        float *sY = actbuf[cur ^ 1];
+        const float *sA = reinterpret_cast<const float *>(smem) + (cur ? act0_floats : 0);
+        float *sY = reinterpret_cast<float *>(smem) + (cur ? 0 : act0_floats);
         const float *sW = wbase + woff[l];
         const float *sbias = sW + (((size_t)n * k + 3) & ~(size_t)3); // staged next to the matrix
         const bool vec = (k & 3) == 0;
@@ -2626,11 +2691,14 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_pool_mlp(const float *__restri
 
 hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_graphs, int d,
                            const int32_t *pools, int num_pools, const HeadArgs &head, int act,
-                           float *out, hipStream_t s)
+                           float *out, hipStream_t s, const float *prepooled)
 {
     if (num_graphs <= 0)
         return hipSuccess;
-    if (!options().fuse_head || head.nlin < 1 || head.nlin > 8 || (d & 3) || (((uintptr_t)x & 15) != 0))
+    const float *src = prepooled ? prepooled : x;
+    if (!options().fuse_head || head.nlin < 1 || head.nlin > 8 || (d & 3) || (((uintptr_t)src & 15) != 0))
+        return hipErrorNotSupported;
+    if (prepooled && (head.dims[0] & 3))
         return hipErrorNotSupported;
     // LDS plan: two activation buffers [16][max width] + every weight matrix
     int maxw0 = 4, maxw1 = 4; // layer l reads buffer l&1 and writes buffer (l+1)&1
@@ -2667,11 +2735,476 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
                 lds_allowed = lds;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(HEAD_THREADS), lds, s, x, node_ptr, num_graphs, d, glog2, p0, p1, p2,
-                           num_pools, head, out, act0_floats, act1_floats, woff[0], woff[1], woff[2], woff[3], woff[4], woff[5],
+                           num_pools, head, out, prepooled, act0_floats, act1_floats, woff[0], woff[1], woff[2], woff[3], woff[4], woff[5],
                            woff[6], woff[7]);
     };
     GNNB_DISPATCH_ACT(act, go)
     return hipGetLastError();
+}
+
+
+// =====================================================================================
+// fused 2-layer GCN stack + pooling (the BASELINE config 1 / 2 model family)
+// =====================================================================================
+// Reference dataflow being fused: compute_gnn_head (two gcn_conv layers with activation,
+// templates/model.cpp.jinja:151-359; gcn_conv gnn_builder_lib.h:1213-1387) and
+// compute_global_graph_pooling (:413-449).  Layer by layer, every intermediate [N, d] matrix makes a
+// round trip through HBM (aggregate out -> GEMM in -> GEMM out -> next aggregate in -> ... -> pooling
+// in).  A molecule is a few dozen rows, so a handful of WHOLE graphs fit in LDS: here a persistent
+// workgroup walks its run of node tiles in stages of <= 48 rows (3 MFMA units) and, per stage,
+//   DMA   raw x rows + node records + dinv of the NEXT stage -> LDS (global_load_lds, double-buffered)
+//   P0    A0 = gcn-aggregate(x)            LDS -> LDS   (width F0, all 256 threads)
+//   M0    H  = act(A0 . W0^T + b0)         MFMA 16x16x4, W0 slice in registers -> LDS
+//   P1    A1 = gcn-aggregate(H)            LDS -> LDS   (lane group per row, XOR-swizzled destination)
+//   M1    H  = act(A1 . W1^T + b1)         MFMA, W1 slice (32 cols x K) in registers -> LDS
+//   PL    pooled[g] = add|mean|max over the rows of each graph of the stage -> HBM
+// HBM traffic = x + tables in, [B, np*d] out: ~5 MB instead of ~270 MB at C2; the kernel is bound by
+// the fp32 matrix cores.  Needs: num_layers == 2, F0 <= 32, h0 in {32,64,128}, h1 <= 128 (h1 % 4 == 0)
+// and the caller's promise max_graph_nodes <= 48 - (tile_rows - 1) (validated by graph prep).
+static constexpr int G2_UNITS = 3;
+static constexpr int G2_CAP = 16 * G2_UNITS; // rows per stage
+static constexpr int G2_TCAP = 256;          // tile-table entries a workgroup keeps in LDS
+
+struct G2Stage {
+    int ta, tb, nb, rows, ga, gb;
+};
+
+template <int ACT, int KQ0, int KQ1>
+__global__ __launch_bounds__(WG, 2) void k_gcn2_fused(
+    const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
+    const int32_t *__restrict__ col, const float *__restrict__ dinv,
+    const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_graph,
+    const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, const float *__restrict__ W0,
+    const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ b1,
+    int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    // ---- LDS carve (bytes, every region 16-B aligned)
+    const int xs_b = ((G2_CAP * f0 * 4) + 15) & ~15;
+    const int in_b = xs_b + G2_CAP * 32 + G2_CAP * 4 + 272; // xs | srec | sdinv | node_ptr of <= 64 graphs (+ end)
+    const int ldh = (h0 > h1 ? h0 : h1) + 4;          // padded H row (floats)
+    // NOTE: LDS pointers are always derived arithmetically from `smem`.  Indexing an array of LDS
+    // pointers with a runtime value makes the compiler lose the address space and emit FLAT loads,
+    // whose s_waitcnt vmcnt(0) also waits for the in-flight DMA of the next stage.
+    constexpr int LD0 = 16 * KQ0; // A0 row: F0 values zero-padded to whole 16-wide MFMA k blocks
+    float *A0 = reinterpret_cast<float *>(smem + 2 * in_b);
+    float *H = A0 + G2_CAP * LD0;
+    float *A1 = H + G2_CAP * ldh;
+    int32_t *stile = reinterpret_cast<int32_t *>(A1 + G2_CAP * h0);
+    int32_t *sgraph = stile + (G2_TCAP + 1);
+
+    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
+    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    if (t1 <= t0)
+        return;
+    for (int i = tid; i <= t1 - t0; i += WG) {
+        stile[i] = tile_first[t0 + i];
+        sgraph[i] = tile_graph[t0 + i];
+    }
+
+    // ---- weight slices -> registers (this wave owns output columns [32*wave, 32*wave+32) of BOTH layers)
+    const int n0 = wave * 32;
+    float w0r[2][KQ0 * 4], w1r[2][KQ1 * 4], bias0[2], bias1[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int n = n0 + 16 * u + li;
+#pragma unroll
+        for (int q = 0; q < KQ0; q++) {
+            const int k = 16 * q + 4 * lg;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < h0)
+                v = load4_guard(W0 + (size_t)n * f0 + k, f0 - k, false);
+            w0r[u][q * 4 + 0] = v.x;
+            w0r[u][q * 4 + 1] = v.y;
+            w0r[u][q * 4 + 2] = v.z;
+            w0r[u][q * 4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < KQ1; q++) {
+            const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < h1)
+                v = *reinterpret_cast<const float4 *>(W1 + (size_t)n * h0 + k);
+            w1r[u][q * 4 + 0] = v.x;
+            w1r[u][q * 4 + 1] = v.y;
+            w1r[u][q * 4 + 2] = v.z;
+            w1r[u][q * 4 + 3] = v.w;
+        }
+        bias0[u] = (n < h0 && b0) ? b0[n] : 0.0f;
+        bias1[u] = (n < h1 && b1) ? b1[n] : 0.0f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto plan = [&](int ta) {
+        G2Stage st;
+        st.ta = ta;
+        st.tb = ta;
+        st.nb = 0;
+        st.rows = 0;
+        st.ga = 0;
+        st.gb = 0;
+        if (ta >= t1)
+            return st;
+        st.nb = stile[ta - t0];
+        int tb = ta + 1;
+        while (tb < t1 && stile[tb + 1 - t0] - st.nb <= G2_CAP)
+            tb++;
+        st.tb = tb;
+        st.rows = min(stile[tb - t0] - st.nb, G2_CAP); // (> CAP only if the max_graph_nodes promise is broken)
+        st.ga = sgraph[ta - t0];
+        // (empty graphs after the last node belong to the last stage: when N is a multiple of the tile
+        // size the first of them already owns tile_graph[num_tiles])
+        st.gb = tb == num_tiles ? num_graphs : sgraph[tb - t0];
+        return st;
+    };
+    auto issue = [&](const G2Stage &st, int bb) {
+        if (st.ta >= t1)
+            return;
+        // (a stage may have NO rows and still own graphs: empty graphs behind a graph that ends on the
+        // tile edge -- their boundaries are still needed by the pooling phase)
+        char *base = smem + (size_t)bb * in_b;
+        dma_dwords_u(x + (size_t)st.nb * f0, base, st.rows * f0, wave, lane, WG / 64);
+        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
+        const int rbytes = st.rows * 32;
+        for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
+            if (c + lane * 16 < rbytes)
+                dma16_to_lds_u(grec + c + lane * 16, base + xs_b + c);
+        dma_dwords_u(dinv + st.nb, base + xs_b + G2_CAP * 32, st.rows, wave, lane, WG / 64);
+        // graph boundaries of the stage for the pooling phase (first 64 graphs; more only if empty
+        // graphs pile up, those are read from global memory)
+        if (wave == 0) {
+            const int ng = min(st.gb - st.ga, 64) + 1;
+            if (lane < ng)
+                dma4_to_lds_u(node_ptr + st.ga + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4);
+            if (lane + 64 < ng)
+                dma4_to_lds_u(node_ptr + st.ga + 64 + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4 + 256);
+        }
+    };
+
+    const int P1 = 16 < (h0 >> 2) ? 16 : (h0 >> 2); // swizzle period of A1 (h0/4 chunks per row, power of two)
+    const int nv1 = h0 >> 2;                         // float4 chunks per H row consumed by layer 1
+    int glog2 = 2;
+    while ((1 << glog2) < nv1 && glog2 < 6)
+        glog2++;
+    const int Gl = 1 << glog2, groups = WG >> glog2, grp = tid >> glog2, gl = tid & (Gl - 1);
+    const int pools[3] = {p0, p1, p2};
+
+#ifdef GNNB_PROBE
+    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pt0 = clock64(), pw0 = wall_clock64(), pt_last = pt0;
+    int nst = 0;
+#define G2_PT(i) do { const unsigned long long _n = clock64(); pt[i] += _n - pt_last; pt_last = _n; } while (0)
+#else
+#define G2_PT(i) do { } while (0)
+#endif
+    G2Stage cur = plan(t0);
+    issue(cur, 0);
+    int b = 0;
+    while (cur.ta < t1) {
+        const G2Stage nxt = plan(cur.tb);
+        dma_wait_all();  // stage `cur` has landed (untracked DMA: the wait is ours)
+        __syncthreads(); // (1) ... for every wave; everyone is done with the previous stage
+        G2_PT(0);
+        issue(nxt, b ^ 1);
+        const char *ibase = smem + (size_t)b * in_b;
+        const float *xs = reinterpret_cast<const float *>(ibase);
+        const int4 *srec = reinterpret_cast<const int4 *>(ibase + xs_b);
+        const float *sdinv = reinterpret_cast<const float *>(ibase + xs_b + G2_CAP * 32);
+        const int32_t *sgp = reinterpret_cast<const int32_t *>(ibase + xs_b + G2_CAP * 32 + G2_CAP * 4);
+        const int rows = cur.rows, nb = cur.nb;
+        const int units = (rows + 15) >> 4;
+
+        // ---- P0: A0[i][f] = sum_j x_j[f] dinv_i dinv_j + x_i[f] dinv_i^2   (CSR order, self last)
+        // LD0 lanes per row (no division; lanes f >= F0 write the zero padding).  Every LDS load is
+        // unconditional -- unused neighbour slots alias the row itself -- and the degree only selects:
+        // a lane-divergent guard around a load makes the compiler wait at every join.
+        for (int i = tid / LD0; i < rows; i += WG / LD0) {
+            const int f = tid % LD0;
+            const int fc = f < f0 ? f : 0;
+            const int4 r0 = srec[2 * i], r1 = srec[2 * i + 1];
+            const int deg = r0.y;
+            const int jl[4] = {r0.z - nb, r0.w - nb, r1.x - nb, r1.y - nb};
+            const float di = sdinv[i];
+            float xv[4], sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                xv[q] = xs[jl[q] * f0 + fc];
+                sv[q] = sdinv[jl[q]];
+            }
+            const float xself = xs[i * f0 + fc];
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                acc += (deg > q) ? xv[q] * (di * sv[q]) : 0.0f;
+            for (int k = r0.x + 4; k < r0.x + deg; k++) { // degree > 4: rare in molecules
+                const int j = col[k] - nb;
+                acc += xs[j * f0 + fc] * (di * sdinv[j]);
+            }
+            acc += xself * (di * di);
+            A0[i * LD0 + f] = f < f0 ? acc : 0.0f;
+        }
+        G2_PT(1);
+        __syncthreads(); // (2)
+
+        // ---- M0: H = act(A0 . W0^T + b0)
+        if (n0 < h0) {
+#pragma unroll
+            for (int rt = 0; rt < G2_UNITS; rt++) {
+                if (rt < units) {
+                    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    const int row = rt * 16 + li;
+#pragma unroll
+                    for (int q = 0; q < KQ0; q++) {
+                        const float4 a4 = *reinterpret_cast<const float4 *>(A0 + row * LD0 + 16 * q + 4 * lg);
+                        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+#pragma unroll
+                            for (int u = 0; u < 2; u++)
+                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w0r[u][q * 4 + t], acc[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int n = n0 + 16 * u + li;
+                        if (n < h0) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
+                                H[(rt * 16 + lg * 4 + r) * ldh + n] = act_t<ACT>(acc[u][r] + bias0[u]);
+                        }
+                    }
+                }
+            }
+        }
+        G2_PT(2);
+        __syncthreads(); // (3)
+
+        // ---- P1: A1 = gcn-aggregate(H), one lane group per row (two rows in flight per group),
+        // destination XOR-swizzled for M1's fragment reads
+        for (int rA = grp; rA < rows; rA += 2 * groups) {
+            const int rB = rA + groups < rows ? rA + groups : rA; // odd tail: redo row A (same values)
+            const int4 a0 = srec[2 * rA], a1 = srec[2 * rA + 1], c0 = srec[2 * rB], c1 = srec[2 * rB + 1];
+            const int degA = a0.y, degB = c0.y;
+            const int jA[4] = {a0.z - nb, a0.w - nb, a1.x - nb, a1.y - nb};
+            const int jB[4] = {c0.z - nb, c0.w - nb, c1.x - nb, c1.y - nb};
+            const float dA = sdinv[rA], dB = sdinv[rB];
+            float sA_[4], sB_[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                sA_[q] = sdinv[jA[q]];
+                sB_[q] = sdinv[jB[q]];
+            }
+            for (int f = gl; f < nv1; f += Gl) {
+                typedef Vf<4> V;
+                V nA[4], nB[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    nA[q] = V::load(H + jA[q] * ldh + f * 4); // unused slots alias the row itself
+                    nB[q] = V::load(H + jB[q] * ldh + f * 4);
+                }
+                const V selfA = V::load(H + rA * ldh + f * 4), selfB = V::load(H + rB * ldh + f * 4);
+                V accA = V::splat(0.0f), accB = V::splat(0.0f);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    accA = vadd(accA, vmul(nA[q], V::splat(degA > q ? dA * sA_[q] : 0.0f)));
+                    accB = vadd(accB, vmul(nB[q], V::splat(degB > q ? dB * sB_[q] : 0.0f)));
+                }
+                for (int k = a0.x + 4; k < a0.x + degA; k++) {
+                    const int j = col[k] - nb;
+                    accA = vadd(accA, vmul(V::load(H + j * ldh + f * 4), V::splat(dA * sdinv[j])));
+                }
+                for (int k = c0.x + 4; k < c0.x + degB; k++) {
+                    const int j = col[k] - nb;
+                    accB = vadd(accB, vmul(V::load(H + j * ldh + f * 4), V::splat(dB * sdinv[j])));
+                }
+                accA = vadd(accA, vmul(selfA, V::splat(dA * dA)));
+                accB = vadd(accB, vmul(selfB, V::splat(dB * dB)));
+                accA.store(A1 + rA * h0 + ((f ^ (rA & (P1 - 1))) << 2));
+                accB.store(A1 + rB * h0 + ((f ^ (rB & (P1 - 1))) << 2));
+            }
+        }
+        G2_PT(3);
+        __syncthreads(); // (4)
+
+        // ---- M1: H = act(A1 . W1^T + b1)
+        if (n0 < h1) {
+#pragma unroll
+            for (int rt = 0; rt < G2_UNITS; rt++) {
+                if (rt < units) {
+                    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    const int row = rt * 16 + li;
+#pragma unroll
+                    for (int q = 0; q < KQ1; q++) {
+                        const int c = 4 * q + lg;
+                        const float4 a4 = *reinterpret_cast<const float4 *>(A1 + row * h0 + ((c ^ (row & (P1 - 1))) << 2));
+                        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+#pragma unroll
+                            for (int u = 0; u < 2; u++)
+                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w1r[u][q * 4 + t], acc[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int n = n0 + 16 * u + li;
+                        if (n < h1) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
+                                H[(rt * 16 + lg * 4 + r) * ldh + n] = act_t<ACT>(acc[u][r] + bias1[u]);
+                        }
+                    }
+                }
+            }
+        }
+        G2_PT(4);
+        __syncthreads(); // (5)
+
+        // ---- PL: per-graph add / mean / max over the stage's graphs (rows in order)
+        {
+            const int nvo = h1 >> 2;
+            int pl2 = 2;
+            while ((1 << pl2) < nvo && pl2 < 6)
+                pl2++;
+            const int PG = 1 << pl2, pgroups = WG >> pl2, pgrp = tid >> pl2, pgl = tid & (PG - 1);
+            for (int g = cur.ga + pgrp; g < cur.gb; g += pgroups) {
+                const int gi = g - cur.ga;
+                // (LDS value read unconditionally, the global one only past 64 graphs: selecting between an
+                // LDS and a global POINTER would become a flat load)
+                int r0g = sgp[gi < 64 ? gi : 0], r1g = sgp[gi < 64 ? gi + 1 : 0];
+                if (gi >= 64) {
+                    r0g = node_ptr[g];
+                    r1g = node_ptr[g + 1];
+                }
+                r0g -= nb;
+                r1g -= nb;
+                for (int f = pgl; f < nvo; f += PG) {
+                    typedef Vf<4> V;
+                    V sum = V::splat(0.0f), mx = V::splat(0.0f);
+                    const int rend = r1g < G2_CAP ? r1g : G2_CAP;
+                    int r = r0g;
+                    if (r < rend) {
+                        sum = V::load(H + r * ldh + f * 4);
+                        mx = sum;
+                        r++;
+                    }
+                    for (; r + 5 < rend; r += 6) { // six LDS reads in flight; added in row order
+                        V v6[6];
+#pragma unroll
+                        for (int u = 0; u < 6; u++)
+                            v6[u] = V::load(H + (r + u) * ldh + f * 4);
+#pragma unroll
+                        for (int u = 0; u < 6; u++) {
+                            sum = vadd(sum, v6[u]);
+                            mx = vmax(mx, v6[u]);
+                        }
+                    }
+                    for (; r < rend; r++) {
+                        const V v = V::load(H + r * ldh + f * 4);
+                        sum = vadd(sum, v);
+                        mx = vmax(mx, v);
+                    }
+                    const int n = r1g - r0g;
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) {
+                        if (kk >= np)
+                            break;
+                        V rr = sum;
+                        if (pools[kk] == GNNB_POOL_MEAN)
+                            rr = n > 0 ? vdiv(sum, V::splat((float)n)) : V::splat(0.0f);
+                        else if (pools[kk] == GNNB_POOL_MAX)
+                            rr = mx;
+                        rr.store(pooled + (size_t)g * np * h1 + (size_t)kk * h1 + f * 4);
+                    }
+                }
+            }
+        }
+        G2_PT(5);
+#ifdef GNNB_PROBE
+        nst++;
+#endif
+        cur = nxt;
+        b ^= 1;
+    }
+#ifdef GNNB_PROBE
+    if (tid == 0 && blockIdx.x < 1024) {
+        unsigned long long *o = g_probe + 8 * 8192 + blockIdx.x * 16; // second half: other kernels stamp the first
+        o[0] = pw0;
+        o[1] = wall_clock64();
+        for (int i = 0; i < 6; i++)
+            o[2 + i] = pt[i];
+        o[8] = clock64() - pt0;
+        o[9] = (unsigned long long)nst;
+    }
+#endif
+}
+
+hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
+                             int h0, const float *w1, const float *b1, int h1, int act,
+                             const int32_t *pools, int num_pools, float *pooled, hipStream_t s)
+{
+    const Options &o = options();
+    if (!o.fuse_gcn2 || t.num_nodes <= 0)
+        return hipErrorNotSupported;
+    if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > G2_CAP)
+        return hipErrorNotSupported; // no promise that whole graphs fit a stage
+    if (f0 < 1 || f0 > 32 || !(h0 == 32 || h0 == 64 || h0 == 128) || h1 < 4 || h1 > 128 || (h1 & 3))
+        return hipErrorNotSupported;
+    if ((((uintptr_t)w1) & 15) || (((uintptr_t)pooled) & 15) || (((uintptr_t)x) & 3))
+        return hipErrorNotSupported;
+    // every stage must hold at least one tile: workgroups need ceil(T / grid) + 1 <= G2_TCAP table entries
+    const int xs_b = ((G2_CAP * f0 * 4) + 15) & ~15;
+    const int in_b = xs_b + G2_CAP * 32 + G2_CAP * 4 + 272;
+    const int ldh = (h0 > h1 ? h0 : h1) + 4;
+    const size_t lds = 2 * (size_t)in_b + (size_t)G2_CAP * 16 * (f0 <= 16 ? 1 : 2) * 4 + (size_t)G2_CAP * ldh * 4 +
+                       (size_t)G2_CAP * h0 * 4 + 2 * (size_t)(G2_TCAP + 1) * 4;
+    const int kq0 = f0 <= 16 ? 1 : 2, kq1 = h0 / 16;
+    const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
+    hipError_t rc = hipErrorNotSupported;
+    auto go = [&](auto atag, auto q0tag, auto q1tag) {
+        constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
+        auto kern = k_gcn2_fused<ACT, KQ0, KQ1>;
+        static size_t lds_set = 0;
+        static int blocks = 0, cus = 256;
+        if (lds_set != lds) {
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                rc = hipErrorNotSupported;
+                return;
+            }
+            int nb = 0, devid = 0;
+            hipDeviceProp_t prop;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WG, lds) != hipSuccess || nb < 1)
+                nb = 1;
+            if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+                cus = prop.multiProcessorCount;
+            blocks = nb > 2 ? 2 : nb;
+            lds_set = lds;
+        }
+        long long grid = (long long)cus * blocks;
+        if (grid > t.num_tiles)
+            grid = t.num_tiles;
+        const long long min_grid = ((long long)t.num_tiles + G2_TCAP - 2) / (G2_TCAP - 1);
+        if (grid < min_grid) {
+            rc = hipErrorNotSupported;
+            return;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, x, f0, t.node_rec, t.col, t.dinv,
+                           t.tile_first, t.tile_graph, t.node_ptr, t.num_tiles, t.num_graphs, w0, b0, h0, w1, b1, h1, p0, p1, p2,
+                           num_pools, pooled);
+        rc = hipGetLastError();
+    };
+    auto go_q = [&](auto atag) {
+        if (kq0 == 1 && kq1 == 8) go(atag, IntTag<1>{}, IntTag<8>{});
+        else if (kq0 == 1 && kq1 == 4) go(atag, IntTag<1>{}, IntTag<4>{});
+        else if (kq0 == 1 && kq1 == 2) go(atag, IntTag<1>{}, IntTag<2>{});
+        else if (kq0 == 2 && kq1 == 8) go(atag, IntTag<2>{}, IntTag<8>{});
+        else if (kq0 == 2 && kq1 == 4) go(atag, IntTag<2>{}, IntTag<4>{});
+        else go(atag, IntTag<2>{}, IntTag<2>{});
+    };
+    GNNB_DISPATCH_ACT(act, go_q)
+    return rc;
 }
 
 #ifdef GNNB_PROBE

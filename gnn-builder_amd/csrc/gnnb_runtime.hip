@@ -56,7 +56,7 @@ Options &options()
                         env_int("GNNB_AGG_VARIANT", 0),      env_int("GNNB_AGG_ROWS_PER_WG", 48),
                         env_int("GNNB_AGG_XCD_REMAP", 1),    env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_FUSE_NARROW", 1),
-                        env_int("GNNB_FUSE_HEAD", 1)};
+                        env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1)};
     return o;
 }
 
@@ -152,6 +152,7 @@ struct gnnb_workspace {
     float *pooled = nullptr;            // [max_graphs, np*d]
     float *mlp[2] = {nullptr, nullptr}; // [max_graphs, max(mlp_hidden, mlp_out)]
     bool prepared = false;
+    int max_graph_nodes = 0; // caller's promise (0 = none)
     int device = 0;
 };
 
@@ -197,6 +198,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_xcd_remap = value;
     else if (!strcmp(name, "fuse_narrow") && value >= 0 && value <= 1)
         o.fuse_narrow = value;
+    else if (!strcmp(name, "fuse_gcn2") && value >= 0 && value <= 1)
+        o.fuse_gcn2 = value;
     else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
         o.fuse_head = value;
     else if (!strcmp(name, "gemm_variant") && value >= 0 && value <= 1)
@@ -365,7 +368,8 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     };
     const size_t N = max_nodes, E = std::max(max_edges, 1), B = max_graphs;
     const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
-                 o_att = carve(N * 4), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_err = carve(4),
+                 o_att = carve(N * 4), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4),
+                 o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4),
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
                  o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
                  o_pool = carve(B * pooledw * 4), o_m0 = carve(B * mlpw * 4),
@@ -386,6 +390,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->t.att = (float *)(b + o_att);
     ws->t.tile_first = (int32_t *)(b + o_tile);
     ws->t.tile_edge = (int32_t *)(b + o_tedge);
+    ws->t.tile_graph = (int32_t *)(b + o_tgraph);
     ws->t.err = (int32_t *)(b + o_err);
     ws->act[0] = (float *)(b + o_a0);
     ws->act[1] = (float *)(b + o_a1);
@@ -411,6 +416,14 @@ void gnnb_workspace_destroy(gnnb_workspace *ws)
 
 size_t gnnb_workspace_bytes(const gnnb_workspace *ws) { return ws ? ws->bytes : 0; }
 
+int gnnb_workspace_set_max_graph_nodes(gnnb_workspace *ws, int n)
+{
+    if (!ws || n < 0)
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_workspace_set_max_graph_nodes");
+    ws->max_graph_nodes = n;
+    return GNNB_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *node_ptr_dev,
                     const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges,
@@ -429,6 +442,7 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     t.num_graphs = num_graphs;
     t.num_nodes = num_nodes;
     t.num_edges = num_edges;
+    t.max_graph_nodes_hint = ws->max_graph_nodes;
     t.tile_rows = std::max(options().tile_rows, 4);
     t.num_tiles = (num_nodes + t.tile_rows - 1) / t.tile_rows;
     if (!(pna_delta > 0.0f))
@@ -575,6 +589,47 @@ int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const flo
     const gnnb_model_desc &d = model->desc;
     const int N = ws->t.num_nodes, B = ws->t.num_graphs;
     int rc;
+
+    // ---- fused path: 2-layer GCN stack + pooling in one persistent kernel, then the MLP head
+    if (d.conv_type == GNNB_CONV_GCN && d.num_layers == 2 && d.mlp_num_linear <= 8) {
+        hipError_t he = launch_gcn2_fused(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
+                                          model->conv[1][0], model->conv[1][1], d.out_dim, d.activation, d.pools,
+                                          d.num_pools, ws->pooled, (hipStream_t)stream);
+        if (he == hipSuccess) {
+            HeadArgs head;
+            memset(&head, 0, sizeof(head));
+            head.nlin = d.mlp_num_linear;
+            for (int i = 0; i < head.nlin; i++) {
+                int din, dout;
+                mlp_dims(d, i, &din, &dout);
+                head.w[i] = model->head_w[i];
+                head.b[i] = model->head_b[i];
+                head.dims[i] = din;
+                head.dims[i + 1] = dout;
+            }
+            he = launch_pool_mlp(nullptr, ws->t.node_ptr, B, d.out_dim, d.pools, d.num_pools, head, d.mlp_activation,
+                                 out_dev, (hipStream_t)stream, ws->pooled);
+            if (he == hipSuccess)
+                return GNNB_OK;
+            if (he != hipErrorNotSupported)
+                return fail(GNNB_ERR_HIP, "readout launch failed: %s", hipGetErrorString(he));
+            // head too large for the fused readout: plain GEMM chain on the pooled matrix
+            const float *h = ws->pooled;
+            for (int i = 0; i < d.mlp_num_linear; i++) {
+                int din, dout;
+                mlp_dims(d, i, &din, &dout);
+                const bool last = (i == d.mlp_num_linear - 1);
+                float *y = last ? out_dev : ws->mlp[i & 1];
+                if ((rc = linear1(h, din, din, model->head_w[i], din, model->head_b[i], nullptr, y, B, dout,
+                                  last ? GNNB_ACT_NONE : d.mlp_activation, stream)))
+                    return rc;
+                h = y;
+            }
+            return GNNB_OK;
+        }
+        if (he != hipErrorNotSupported)
+            return fail(GNNB_ERR_HIP, "fused GCN stack launch failed: %s", hipGetErrorString(he));
+    }
 
     const float *cur = x_dev;
     int which = 0;

@@ -66,7 +66,7 @@ class GemmSeg(C.Structure):
 EXPORTED_SYMBOLS = [
     "gnnb_version", "gnnb_last_error", "gnnb_device_count", "gnnb_stream_sync",
     "gnnb_model_num_params", "gnnb_model_create", "gnnb_model_destroy", "gnnb_model_get_desc",
-    "gnnb_workspace_create", "gnnb_workspace_destroy", "gnnb_workspace_bytes",
+    "gnnb_workspace_create", "gnnb_workspace_destroy", "gnnb_workspace_bytes", "gnnb_workspace_set_max_graph_nodes",
     "gnnb_forward_batched", "gnnb_forward_prepared", "gnnb_forward_batched_host", "gnnb_workspace_check",
     "gnnb_graph_prep", "gnnb_graph_tables_to_host", "gnnb_aggregate", "gnnb_linear", "gnnb_global_pool",
     "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
@@ -128,6 +128,7 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
         lib.gnnb_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         lib.gnnb_stream_sync.argtypes = [C.c_void_p]
         lib.gnnb_set_option.argtypes = [C.c_char_p, C.c_int]
+        lib.gnnb_workspace_set_max_graph_nodes.argtypes = [C.c_void_p, C.c_int]
         lib.gnnb_aggregate_timed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_int, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         lib.gnnb_linear_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
@@ -185,7 +186,8 @@ class CompiledModel:
     """Device-resident model: weights uploaded once (the reference's copy_parameters_flag=1 call),
     plus one workspace sized for the largest batch it will see."""
 
-    def __init__(self, spec: dict, params: Sequence, max_graphs: int, max_nodes: int, max_edges: int):
+    def __init__(self, spec: dict, params: Sequence, max_graphs: int, max_nodes: int, max_edges: int,
+                 max_graph_nodes: int = 0):
         self.lib = load_library(require_gpu=True)
         self.spec = dict(spec)
         self.desc = make_desc(spec)
@@ -207,11 +209,19 @@ class CompiledModel:
             self._model = C.c_void_p()
             _check(rc)
         self.max_graphs, self.max_nodes, self.max_edges = int(max_graphs), int(max_nodes), int(max_edges)
+        if max_graph_nodes:
+            self.set_max_graph_nodes(max_graph_nodes)
 
     @classmethod
-    def from_model(cls, model, max_graphs: int, max_nodes: int, max_edges: int) -> "CompiledModel":
-        """``model``: a ``gnnbuilder_amd.models.GNNModel``."""
-        return cls(model.spec(), model.canonical_params(), max_graphs, max_nodes, max_edges)
+    def from_model(cls, model, max_graphs: int, max_nodes: int, max_edges: int,
+                   max_graph_nodes: int = 0) -> "CompiledModel":
+        """``model``: a ``gnnbuilder_amd.models.GNNModel``.  ``max_graph_nodes``: promise on the largest
+        graph (0 = none); small molecules enable the LDS-resident fused kernels, and the promise is
+        validated on the device (``check()`` raises if a batch breaks it)."""
+        return cls(model.spec(), model.canonical_params(), max_graphs, max_nodes, max_edges, max_graph_nodes)
+
+    def set_max_graph_nodes(self, n: int) -> None:
+        _check(self.lib.gnnb_workspace_set_max_graph_nodes(self._ws, int(n)))
 
     @property
     def out_dim(self) -> int:

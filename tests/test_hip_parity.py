@@ -354,3 +354,57 @@ def test_fused_narrow_layer_equals_separate_kernels(dev, conv, fin):
         runtime.set_option("fuse_narrow", 1)
     assert np.abs(outs[0] - ref).max() < TOL and np.abs(outs[1] - ref).max() < TOL
     assert np.abs(outs[0] - outs[1]).max() < 1e-5
+
+
+@pytest.mark.parametrize("fin,h0,h1,act,pools", [(11, 128, 128, "relu", ("add", "mean", "max")), (9, 64, 64, "tanh", ("max", "add")),
+                                                 (11, 32, 128, "gelu", ("mean",)), (20, 128, 64, "sigmoid", ("add", "mean", "max")),
+                                                 (11, 64, 20, "relu", ("add",))])
+@pytest.mark.parametrize("pad_to_tile", [False, True])
+def test_fused_gcn_stack_equals_layerwise_and_oracle(dev, fin, h0, h1, act, pools, pad_to_tile):
+    """The persistent 2-layer GCN kernel (graphs staged once in LDS) vs the layer-by-layer path vs the
+    oracle, on molecule batches plus degenerate graphs (empty, isolated node, in-degree 8, self loop)."""
+    model = make_model("gcn", in_dim=fin, hidden=h0, layers=2, out_dim=h1, act=act, pools=pools, task_out=5)
+    rng = np.random.default_rng(h0 + h1)
+    star = np.array([[i, 0] for i in range(1, 9)] + [[0, i] for i in range(1, 9)] + [[3, 3]])
+    graphs = [(rng.uniform(-1, 1, (9, fin)), star), (rng.uniform(-1, 1, (0, fin)), np.zeros((0, 2))),
+              (rng.uniform(-1, 1, (1, fin)), np.zeros((0, 2))), (rng.uniform(-1, 1, (0, fin)), np.zeros((0, 2)))]
+    b0 = synthetic.make_batch("qm9", 300, seed=fin + h0)
+    graphs += [(rng.uniform(-1, 1, (b0.graph(g)[0].shape[0], fin)), b0.graph(g)[1]) for g in range(300)]
+    if pad_to_tile:  # N a multiple of the node-tile size: the trailing empty graphs sit exactly on the last tile edge
+        n_now = sum(g[0].shape[0] for g in graphs)
+        graphs.append((rng.uniform(-1, 1, ((-n_now) % 16 or 16, fin)), np.zeros((0, 2))))
+        graphs.append((rng.uniform(-1, 1, (0, fin)), np.zeros((0, 2))))
+    graphs.append((rng.uniform(-1, 1, (0, fin)), np.zeros((0, 2))))  # batch ends with an empty graph
+    batch = pack_graphs([(np.asarray(x, np.float32), np.asarray(c, np.int32)) for x, c in graphs])
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)
+    fused = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    cm.check()
+    cm.set_max_graph_nodes(0)  # no promise -> layer-by-layer path
+    layerwise = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    assert np.isfinite(fused).all()
+    assert np.abs(fused - ref).max() < TOL and np.abs(layerwise - ref).max() < TOL
+    assert np.abs(fused - layerwise).max() < 2e-5
+
+
+def test_broken_max_graph_nodes_promise_is_detected(dev):
+    model = make_model("gcn", hidden=64, layers=2)
+    batch = synthetic.make_batch("molhiv", 40, seed=3)  # graphs of up to 222 nodes
+    assert np.diff(batch.node_ptr).max() > 29
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)
+    cm.forward(*to_dev(batch, dev))
+    with pytest.raises(runtime.GnnbError, match="malformed batch"):
+        cm.check()
+
+
+def test_full_size_config2_fused_path(dev):
+    """BASELINE config 2 at full size through the fused stack: sampled graphs vs the oracle."""
+    model = make_model("gcn", in_dim=11, hidden=128, layers=2)
+    batch = synthetic.make_batch("qm9", 4096, seed=1)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)
+    out = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    cm.check()
+    idx = np.random.default_rng(1).choice(4096, 256, replace=False)
+    sub = pack_graphs([batch.graph(int(g)) for g in idx])
+    ref = O.forward_batched(model.spec(), canon(model), sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
+    assert np.abs(out[idx] - ref).max() < TOL

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Diagnostic: phase cycles of the fused 2-layer GCN kernel (probe build)."""
+import ctypes as C, os, sys
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("GNNB_HIP_LIB", str(ROOT / "gnn-builder_amd" / "libgnnb_hip_probe.so"))
+import bench
+from gnnbuilder_amd import runtime, synthetic
+w = bench.WORKLOADS["c2"]; dev = torch.device("cuda:0")
+model = bench.build_model(w)
+b = synthetic.make_batch(w["shape"], w["batch"], seed=0)
+cm = runtime.CompiledModel.from_model(model, b.num_graphs, b.num_nodes, b.num_edges, max_graph_nodes=29)
+bd = tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr))
+for _ in range(10):
+    cm.forward(*bd)
+torch.cuda.synchronize()
+lib = runtime.load_library(); n = 16 * 8192
+buf = (C.c_ulonglong * n)(); lib.gnnb_probe_read(buf, n)
+p = np.frombuffer(buf, dtype=np.uint64)[8 * 8192:8 * 8192 + 16 * 1024].reshape(1024, 16).astype(np.float64)
+p = p[p[:, 9] > 0]
+life = (p[:, 1] - p[:, 0]) / 100
+print(f"workgroups {len(p)}, stages/WG {p[:, 9].mean():.2f} (max {p[:, 9].max():.0f}); span {(p[:, 1].max() - p[:, 0].min()) / 100:.2f} us, lifetime mean {life.mean():.2f} max {life.max():.2f}, last start +{(p[:, 0].max() - p[:, 0].min()) / 100:.2f}")
+names = ["wait DMA + barrier(1)", "issue + P0 (agg F0)", "bar(2) + M0", "bar(3) + P1 (agg d)", "bar(4) + M1", "bar(5) + pooling"]
+for i, nm in enumerate(names):
+    print(f"  {nm:24s} {100 * (p[:, 2 + i] / p[:, 8]).mean():5.1f}%  {(p[:, 2 + i] / p[:, 9]).mean():8.0f} cycles/stage")
+print(f"  clock {np.median(p[:, 8] / life):.0f} MHz")
