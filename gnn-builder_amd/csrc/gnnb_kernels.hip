@@ -2764,13 +2764,87 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
 static constexpr int G2_UNITS = 3;
 static constexpr int G2_CAP = 16 * G2_UNITS; // rows per stage
 static constexpr int G2_TCAP = 256;          // tile-table entries a workgroup keeps in LDS
+static constexpr int G2_WG = 512;            // 8 waves; two workgroups per CU = 4 waves per SIMD
+static constexpr int G2_NW = G2_WG / 64;
 
 struct G2Stage {
     int ta, tb, nb, rows, ga, gb;
 };
 
+// Sum / max of a value over the four 16-lane rows of a wave (same lane index in each row) with the
+// gfx950 row-swap instructions -- two VALU operations per step instead of an LDS crossbar round trip.
+__device__ __forceinline__ float rows4_sum(float x)
+{
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows4_max(float x)
+{
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate
+__device__ __forceinline__ void vmcnt_wait_upto(int n)
+{
+    switch (__builtin_amdgcn_readfirstlane(n)) { // scalar branch
+
+#define GNNB_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    GNNB_VMW(1) GNNB_VMW(2) GNNB_VMW(3) GNNB_VMW(4) GNNB_VMW(5) GNNB_VMW(6) GNNB_VMW(7) GNNB_VMW(8) GNNB_VMW(9)
+    GNNB_VMW(10) GNNB_VMW(11) GNNB_VMW(12) GNNB_VMW(13) GNNB_VMW(14) GNNB_VMW(15) GNNB_VMW(16) GNNB_VMW(17) GNNB_VMW(18)
+#undef GNNB_VMW
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// Workgroup barrier of the fused kernel: LDS traffic drained, NO vector-memory drain.  __syncthreads()
+// carries a fence, for which the compiler emits s_waitcnt vmcnt(0) whenever it has stores of its own in
+// flight (the pooled outputs) -- and that would also wait for the untracked DMA of the next stage.
+__device__ __forceinline__ void g2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One MFMA phase of the fused stack: v[k][r] = act(A . Wslice^T + bias) for the wave's 16 columns and
+// the rows (rg + k nrg) * 16 + lg * 4 + r of its units k < NU (NU wave-uniform).  The units'
+// accumulators are interleaved so that dependent MFMAs are >= 2 issues apart (NU == 1: the k range
+// is split over two accumulators instead).
+template <int ACT, int KQ, int NU, bool SWZ>
+__device__ __forceinline__ void g2_mma(const float *__restrict__ Asrc, int lda, int P, const float (&wr)[KQ * 4],
+                                       float bias, int rg, int nrg, int li, int lg, float (&v)[NU][4])
+{
+    constexpr int NA = NU == 1 ? 2 : NU;
+    f32x4 acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++)
+        acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KQ; q++) {
+        float4 a4[NU];
+#pragma unroll
+        for (int k = 0; k < NU; k++) {
+            const int row = (rg + k * nrg) * 16 + li;
+            const int c = 4 * q + lg;
+            a4[k] = *reinterpret_cast<const float4 *>(Asrc + row * lda + ((SWZ ? (c ^ (row & (P - 1))) : c) << 2));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int k = 0; k < NU; k++) {
+                const float av = t == 0 ? a4[k].x : (t == 1 ? a4[k].y : (t == 2 ? a4[k].z : a4[k].w));
+                const int ai = NU == 1 ? (t & 1) : k;
+                acc[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[q * 4 + t], acc[ai], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            v[k][r] = act_t<ACT>((NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias);
+}
+
 template <int ACT, int KQ0, int KQ1>
-__global__ __launch_bounds__(WG, 2) void k_gcn2_fused(
+__global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_graph,
@@ -2799,43 +2873,58 @@ __global__ __launch_bounds__(WG, 2) void k_gcn2_fused(
     const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
     if (t1 <= t0)
         return;
-    for (int i = tid; i <= t1 - t0; i += WG) {
+    for (int i = tid; i <= t1 - t0; i += G2_WG) {
         stile[i] = tile_first[t0 + i];
         sgraph[i] = tile_graph[t0 + i];
     }
 
-    // ---- weight slices -> registers (this wave owns output columns [32*wave, 32*wave+32) of BOTH layers)
-    const int n0 = wave * 32;
-    float w0r[2][KQ0 * 4], w1r[2][KQ1 * 4], bias0[2], bias1[2];
+    // ---- wave roles: layer L has ncs_L = pow2ceil(h_L / 16) column slices of 16 and nrg_L = 8 / ncs_L
+    // row groups; wave w owns slice (w mod ncs) for the units rg, rg + nrg, ... with rg = w / ncs
+    int cs0l = 0, cs1l = 0;
+    while ((16 << cs0l) < h0)
+        cs0l++;
+    while ((16 << cs1l) < h1)
+        cs1l++; // h1 <= 128 -> <= 3
+    const int nrg0 = G2_NW >> cs0l, n0c = (wave & ((1 << cs0l) - 1)) * 16 + li;
+    const int n1c = (wave & ((1 << cs1l) - 1)) * 16 + li;
+
+    // ---- weight slices -> registers (16 output columns x K per layer and wave)
+    float w0r[KQ0 * 4], w1r[KQ1 * 4];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int n = n0 + 16 * u + li;
-#pragma unroll
-        for (int q = 0; q < KQ0; q++) {
-            const int k = 16 * q + 4 * lg;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < h0)
-                v = load4_guard(W0 + (size_t)n * f0 + k, f0 - k, false);
-            w0r[u][q * 4 + 0] = v.x;
-            w0r[u][q * 4 + 1] = v.y;
-            w0r[u][q * 4 + 2] = v.z;
-            w0r[u][q * 4 + 3] = v.w;
-        }
-#pragma unroll
-        for (int q = 0; q < KQ1; q++) {
-            const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < h1)
-                v = *reinterpret_cast<const float4 *>(W1 + (size_t)n * h0 + k);
-            w1r[u][q * 4 + 0] = v.x;
-            w1r[u][q * 4 + 1] = v.y;
-            w1r[u][q * 4 + 2] = v.z;
-            w1r[u][q * 4 + 3] = v.w;
-        }
-        bias0[u] = (n < h0 && b0) ? b0[n] : 0.0f;
-        bias1[u] = (n < h1 && b1) ? b1[n] : 0.0f;
+    for (int q = 0; q < KQ0; q++) {
+        const int k = 16 * q + 4 * lg;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0c < h0)
+            v = load4_guard(W0 + (size_t)n0c * f0 + k, f0 - k, false);
+        w0r[q * 4 + 0] = v.x;
+        w0r[q * 4 + 1] = v.y;
+        w0r[q * 4 + 2] = v.z;
+        w0r[q * 4 + 3] = v.w;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < KQ1; q++) {
+        const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n1c < h1)
+            v = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + k);
+        w1r[q * 4 + 0] = v.x;
+        w1r[q * 4 + 1] = v.y;
+        w1r[q * 4 + 2] = v.z;
+        w1r[q * 4 + 3] = v.w;
+    }
+    float bias0 = (n0c < h0 && b0) ? b0[n0c] : 0.0f;
+    float bias1 = (n1c < h1 && b1) ? b1[n1c] : 0.0f;
+    // Pin every weight register through an (empty) asm: the compiler must finish the loads HERE.  Left
+    // alone it keeps them "possibly in flight" around the stage loop's back edge and guards their first
+    // use in M0 / M1 with s_waitcnt vmcnt(0) -- which also waits for the next stage's DMA issued just
+    // before, i.e. exposes the full memory latency in every stage.
+#pragma unroll
+    for (int q = 0; q < KQ0 * 4; q++)
+        asm volatile("" : "+v"(w0r[q]));
+#pragma unroll
+    for (int q = 0; q < KQ1 * 4; q++)
+        asm volatile("" : "+v"(w1r[q]));
+    asm volatile("" : "+v"(bias0), "+v"(bias1));
     __syncthreads();
 
     auto plan = [&](int ta) {
@@ -2860,28 +2949,26 @@ __global__ __launch_bounds__(WG, 2) void k_gcn2_fused(
         st.gb = tb == num_tiles ? num_graphs : sgraph[tb - t0];
         return st;
     };
-    auto issue = [&](const G2Stage &st, int bb) {
+    auto issue = [&](const G2Stage &st, int bb, int lane, int wave) { // (lane, wave: see `tv` below)
         if (st.ta >= t1)
             return;
         // (a stage may have NO rows and still own graphs: empty graphs behind a graph that ends on the
         // tile edge -- their boundaries are still needed by the pooling phase)
         char *base = smem + (size_t)bb * in_b;
-        dma_dwords_u(x + (size_t)st.nb * f0, base, st.rows * f0, wave, lane, WG / 64);
+        dma_dwords_u(x + (size_t)st.nb * f0, base, st.rows * f0, wave, lane, G2_NW);
         const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
         const int rbytes = st.rows * 32;
-        for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
-            if (c + lane * 16 < rbytes)
-                dma16_to_lds_u(grec + c + lane * 16, base + xs_b + c);
-        dma_dwords_u(dinv + st.nb, base + xs_b + G2_CAP * 32, st.rows, wave, lane, WG / 64);
+        if (wave * 1024 + lane * 16 < rbytes) // <= 48 rows * 32 B = 1.5 KiB: waves 0 and 1
+            dma16_to_lds_u(grec + wave * 1024 + lane * 16, base + xs_b + wave * 1024);
+        if (wave == 2 && lane < st.rows)
+            dma4_to_lds_u(dinv + st.nb + lane, base + xs_b + G2_CAP * 32);
         // graph boundaries of the stage for the pooling phase (first 64 graphs; more only if empty
         // graphs pile up, those are read from global memory)
-        if (wave == 0) {
-            const int ng = min(st.gb - st.ga, 64) + 1;
-            if (lane < ng)
-                dma4_to_lds_u(node_ptr + st.ga + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4);
-            if (lane + 64 < ng)
-                dma4_to_lds_u(node_ptr + st.ga + 64 + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4 + 256);
-        }
+        const int ng = min(st.gb - st.ga, 64) + 1;
+        if (wave == 3 && lane < ng)
+            dma4_to_lds_u(node_ptr + st.ga + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4);
+        if (wave == 4 && lane + 64 < ng)
+            dma4_to_lds_u(node_ptr + st.ga + 64 + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4 + 256);
     };
 
     const int P1 = 16 < (h0 >> 2) ? 16 : (h0 >> 2); // swizzle period of A1 (h0/4 chunks per row, power of two)
@@ -2889,25 +2976,29 @@ __global__ __launch_bounds__(WG, 2) void k_gcn2_fused(
     int glog2 = 2;
     while ((1 << glog2) < nv1 && glog2 < 6)
         glog2++;
-    const int Gl = 1 << glog2, groups = WG >> glog2, grp = tid >> glog2, gl = tid & (Gl - 1);
+    const int Gl = 1 << glog2, groups = G2_WG >> glog2;
     const int pools[3] = {p0, p1, p2};
 
 #ifdef GNNB_PROBE
-    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pt0 = clock64(), pw0 = wall_clock64(), pt_last = pt0;
+    unsigned long long pt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = clock64(), pw0 = wall_clock64(), pt_last = pt0;
     int nst = 0;
 #define G2_PT(i) do { const unsigned long long _n = clock64(); pt[i] += _n - pt_last; pt_last = _n; } while (0)
 #else
 #define G2_PT(i) do { } while (0)
 #endif
     G2Stage cur = plan(t0);
-    issue(cur, 0);
+    issue(cur, 0, lane, wave);
     int b = 0;
+    int stores_behind_dma = 0; // wave-uniform: store INSTRUCTIONS this wave issued since its last DMA issue
     while (cur.ta < t1) {
         const G2Stage nxt = plan(cur.tb);
-        dma_wait_all();  // stage `cur` has landed (untracked DMA: the wait is ours)
-        __syncthreads(); // (1) ... for every wave; everyone is done with the previous stage
+        // Stage `cur` has landed (untracked DMA: the wait is ours).  Vector-memory operations retire in
+        // order and the previous stage's pooled stores were issued AFTER this DMA, so waiting for
+        // "at most <that many> outstanding" proves the DMA done and leaves the stores in flight.
+        vmcnt_wait_upto(stores_behind_dma);
+        stores_behind_dma = 0;
+        g2_barrier(); // (1) everyone's DMA is in; everyone is done with the previous stage
         G2_PT(0);
-        issue(nxt, b ^ 1);
         const char *ibase = smem + (size_t)b * in_b;
         const float *xs = reinterpret_cast<const float *>(ibase);
         const int4 *srec = reinterpret_cast<const int4 *>(ibase + xs_b);
@@ -2915,13 +3006,25 @@ __global__ __launch_bounds__(WG, 2) void k_gcn2_fused(
         const int32_t *sgp = reinterpret_cast<const int32_t *>(ibase + xs_b + G2_CAP * 32 + G2_CAP * 4);
         const int rows = cur.rows, nb = cur.nb;
         const int units = (rows + 15) >> 4;
+        // The thread index is re-made OPAQUE every stage and every per-lane quantity below is derived from
+        // it again (a dozen VALU ops).  Otherwise the compiler hoists ~50 loop-invariant LDS offsets out of
+        // the stage loop, runs out of its 128 registers and parks them in scratch -- whose reloads are
+        // vector-memory operations that queue behind the next stage's DMA.
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int li = tv & 15, lg = (tv >> 4) & 3, wv = tv >> 6;
+        const int n0c = (wv & ((1 << cs0l) - 1)) * 16 + li, n1c = (wv & ((1 << cs1l) - 1)) * 16 + li;
+        const int rg0 = wv >> cs0l;
+        const int grp = tv >> glog2, gl = tv & (Gl - 1);
+        issue(nxt, b ^ 1, tv & 63, wv);
+        G2_PT(1);
 
         // ---- P0: A0[i][f] = sum_j x_j[f] dinv_i dinv_j + x_i[f] dinv_i^2   (CSR order, self last)
         // LD0 lanes per row (no division; lanes f >= F0 write the zero padding).  Every LDS load is
         // unconditional -- unused neighbour slots alias the row itself -- and the degree only selects:
         // a lane-divergent guard around a load makes the compiler wait at every join.
-        for (int i = tid / LD0; i < rows; i += WG / LD0) {
-            const int f = tid % LD0;
+        for (int i = tv / LD0; i < rows; i += G2_WG / LD0) {
+            const int f = tv % LD0;
             const int fc = f < f0 ? f : 0;
             const int4 r0 = srec[2 * i], r1 = srec[2 * i + 1];
             const int deg = r0.y;
@@ -2945,181 +3048,139 @@ __global__ __launch_bounds__(WG, 2) void k_gcn2_fused(
             acc += xself * (di * di);
             A0[i * LD0 + f] = f < f0 ? acc : 0.0f;
         }
-        G2_PT(1);
-        __syncthreads(); // (2)
-
-        // ---- M0: H = act(A0 . W0^T + b0)
-        if (n0 < h0) {
-#pragma unroll
-            for (int rt = 0; rt < G2_UNITS; rt++) {
-                if (rt < units) {
-                    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                    const int row = rt * 16 + li;
-#pragma unroll
-                    for (int q = 0; q < KQ0; q++) {
-                        const float4 a4 = *reinterpret_cast<const float4 *>(A0 + row * LD0 + 16 * q + 4 * lg);
-                        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                        for (int t = 0; t < 4; t++)
-#pragma unroll
-                            for (int u = 0; u < 2; u++)
-                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w0r[u][q * 4 + t], acc[u], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int n = n0 + 16 * u + li;
-                        if (n < h0) {
-#pragma unroll
-                            for (int r = 0; r < 4; r++)
-                                H[(rt * 16 + lg * 4 + r) * ldh + n] = act_t<ACT>(acc[u][r] + bias0[u]);
-                        }
-                    }
-                }
-            }
-        }
         G2_PT(2);
-        __syncthreads(); // (3)
+        g2_barrier(); // (2)
+        G2_PT(3);
 
-        // ---- P1: A1 = gcn-aggregate(H), one lane group per row (two rows in flight per group),
-        // destination XOR-swizzled for M1's fragment reads
-        for (int rA = grp; rA < rows; rA += 2 * groups) {
-            const int rB = rA + groups < rows ? rA + groups : rA; // odd tail: redo row A (same values)
-            const int4 a0 = srec[2 * rA], a1 = srec[2 * rA + 1], c0 = srec[2 * rB], c1 = srec[2 * rB + 1];
-            const int degA = a0.y, degB = c0.y;
-            const int jA[4] = {a0.z - nb, a0.w - nb, a1.x - nb, a1.y - nb};
-            const int jB[4] = {c0.z - nb, c0.w - nb, c1.x - nb, c1.y - nb};
-            const float dA = sdinv[rA], dB = sdinv[rB];
-            float sA_[4], sB_[4];
+        // ---- M0: H = act(A0 . W0^T + b0)   (wave: column slice x row group)
+        {
+            const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
+            auto m0 = [&](auto nutag) {
+                constexpr int NU = decltype(nutag)::value;
+                float v[NU][4];
+                g2_mma<ACT, KQ0, NU, false>(A0, LD0, 1, w0r, bias0, rg0, nrg0, li, lg, v);
+                if (n0c < h0) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+                    for (int k = 0; k < NU; k++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            H[((rg0 + k * nrg0) * 16 + lg * 4 + r) * ldh + n0c] = v[k][r];
+                }
+            };
+            if (nu == 3)
+                m0(IntTag<3>{});
+            else if (nu == 2)
+                m0(IntTag<2>{});
+            else if (nu == 1)
+                m0(IntTag<1>{});
+        }
+        G2_PT(4);
+        g2_barrier(); // (3)
+        G2_PT(5);
+
+        // ---- P1: A1 = gcn-aggregate(H), one lane group per row, destination XOR-swizzled for M1's
+        // fragment reads.  (One row in flight per group: the register budget is 128 per lane so that two
+        // 8-wave workgroups share a CU, and the weight slices must not be spilled.)
+        for (int rA = grp; rA < rows; rA += groups) {
+            const int4 a0 = srec[2 * rA], a1 = srec[2 * rA + 1];
+            const int degA = a0.y;
+            const int jA[4] = {a0.z - nb, a0.w - nb, a1.x - nb, a1.y - nb};
+            const float dA = sdinv[rA];
+            float sA_[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
                 sA_[q] = sdinv[jA[q]];
-                sB_[q] = sdinv[jB[q]];
-            }
             for (int f = gl; f < nv1; f += Gl) {
                 typedef Vf<4> V;
-                V nA[4], nB[4];
+                V nA[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < 4; q++)
                     nA[q] = V::load(H + jA[q] * ldh + f * 4); // unused slots alias the row itself
-                    nB[q] = V::load(H + jB[q] * ldh + f * 4);
-                }
-                const V selfA = V::load(H + rA * ldh + f * 4), selfB = V::load(H + rB * ldh + f * 4);
-                V accA = V::splat(0.0f), accB = V::splat(0.0f);
+                const V selfA = V::load(H + rA * ldh + f * 4);
+                V accA = V::splat(0.0f);
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < 4; q++)
                     accA = vadd(accA, vmul(nA[q], V::splat(degA > q ? dA * sA_[q] : 0.0f)));
-                    accB = vadd(accB, vmul(nB[q], V::splat(degB > q ? dB * sB_[q] : 0.0f)));
-                }
                 for (int k = a0.x + 4; k < a0.x + degA; k++) {
                     const int j = col[k] - nb;
                     accA = vadd(accA, vmul(V::load(H + j * ldh + f * 4), V::splat(dA * sdinv[j])));
                 }
-                for (int k = c0.x + 4; k < c0.x + degB; k++) {
-                    const int j = col[k] - nb;
-                    accB = vadd(accB, vmul(V::load(H + j * ldh + f * 4), V::splat(dB * sdinv[j])));
-                }
                 accA = vadd(accA, vmul(selfA, V::splat(dA * dA)));
-                accB = vadd(accB, vmul(selfB, V::splat(dB * dB)));
                 accA.store(A1 + rA * h0 + ((f ^ (rA & (P1 - 1))) << 2));
-                accB.store(A1 + rB * h0 + ((f ^ (rB & (P1 - 1))) << 2));
             }
         }
-        G2_PT(3);
-        __syncthreads(); // (4)
+        G2_PT(6);
+        g2_barrier(); // (4)
+        G2_PT(7);
 
-        // ---- M1: H = act(A1 . W1^T + b1)
-        if (n0 < h1) {
+        // ---- M1 + pooling: out = act(A1 . W1^T + b1) stays in the accumulators (the wave owns its 16
+        // columns for ALL rows of the stage; waves beyond h1/16 slices idle) and is pooled per graph in
+        // registers: masked add / max over the lane's 4 rows per unit, then across the four 16-lane groups.
+        // (reference global_add/mean/max_pool, gnn_builder_lib.h:2709-2803; rows in order within a lane,
+        // lane groups combined pairwise)
+        if (wv < (1 << cs1l) && units > 0) {
+            auto m1 = [&](auto nutag) {
+                constexpr int NU = decltype(nutag)::value;
+                float v[NU][4];
+                g2_mma<ACT, KQ1, NU, true>(A1, h0, P1, w1r, bias1, 0, 1, li, lg, v);
+                const int ngr = cur.gb - cur.ga;
+                // (one store instruction per graph and pool; none if the whole slice is past h1; the rare
+                // paths below that read global memory only make the count conservative -- see the wait)
+                stores_behind_dma = wv * 16 < h1 ? ngr * np : 0;
+                auto pool_graph = [&](int gi, int r0g, int r1g) { // wave-uniform row range of graph ga + gi
+                    r0g = __builtin_amdgcn_readfirstlane(r0g) - nb;
+                    r1g = min(__builtin_amdgcn_readfirstlane(r1g) - nb, G2_CAP);
+                    float sum = 0.0f, mx = -INFINITY;
 #pragma unroll
-            for (int rt = 0; rt < G2_UNITS; rt++) {
-                if (rt < units) {
-                    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                    const int row = rt * 16 + li;
+                    for (int k = 0; k < NU; k++) {
+                        if (r1g > k * 16 && r0g < k * 16 + 16) { // uniform: the unit overlaps the graph
 #pragma unroll
-                    for (int q = 0; q < KQ1; q++) {
-                        const int c = 4 * q + lg;
-                        const float4 a4 = *reinterpret_cast<const float4 *>(A1 + row * h0 + ((c ^ (row & (P1 - 1))) << 2));
-                        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                        for (int t = 0; t < 4; t++)
-#pragma unroll
-                            for (int u = 0; u < 2; u++)
-                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w1r[u][q * 4 + t], acc[u], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int n = n0 + 16 * u + li;
-                        if (n < h1) {
-#pragma unroll
-                            for (int r = 0; r < 4; r++)
-                                H[(rt * 16 + lg * 4 + r) * ldh + n] = act_t<ACT>(acc[u][r] + bias1[u]);
+                            for (int r = 0; r < 4; r++) {
+                                const int row = k * 16 + lg * 4 + r;
+                                const bool in = row >= r0g && row < r1g;
+                                sum += in ? v[k][r] : 0.0f;
+                                mx = fmaxf(mx, in ? v[k][r] : -INFINITY);
+                            }
                         }
                     }
-                }
-            }
-        }
-        G2_PT(4);
-        __syncthreads(); // (5)
-
-        // ---- PL: per-graph add / mean / max over the stage's graphs (rows in order)
-        {
-            const int nvo = h1 >> 2;
-            int pl2 = 2;
-            while ((1 << pl2) < nvo && pl2 < 6)
-                pl2++;
-            const int PG = 1 << pl2, pgroups = WG >> pl2, pgrp = tid >> pl2, pgl = tid & (PG - 1);
-            for (int g = cur.ga + pgrp; g < cur.gb; g += pgroups) {
-                const int gi = g - cur.ga;
-                // (LDS value read unconditionally, the global one only past 64 graphs: selecting between an
-                // LDS and a global POINTER would become a flat load)
-                int r0g = sgp[gi < 64 ? gi : 0], r1g = sgp[gi < 64 ? gi + 1 : 0];
-                if (gi >= 64) {
-                    r0g = node_ptr[g];
-                    r1g = node_ptr[g + 1];
-                }
-                r0g -= nb;
-                r1g -= nb;
-                for (int f = pgl; f < nvo; f += PG) {
-                    typedef Vf<4> V;
-                    V sum = V::splat(0.0f), mx = V::splat(0.0f);
-                    const int rend = r1g < G2_CAP ? r1g : G2_CAP;
-                    int r = r0g;
-                    if (r < rend) {
-                        sum = V::load(H + r * ldh + f * 4);
-                        mx = sum;
-                        r++;
-                    }
-                    for (; r + 5 < rend; r += 6) { // six LDS reads in flight; added in row order
-                        V v6[6];
-#pragma unroll
-                        for (int u = 0; u < 6; u++)
-                            v6[u] = V::load(H + (r + u) * ldh + f * 4);
-#pragma unroll
-                        for (int u = 0; u < 6; u++) {
-                            sum = vadd(sum, v6[u]);
-                            mx = vmax(mx, v6[u]);
-                        }
-                    }
-                    for (; r < rend; r++) {
-                        const V v = V::load(H + r * ldh + f * 4);
-                        sum = vadd(sum, v);
-                        mx = vmax(mx, v);
-                    }
+                    sum = rows4_sum(sum);
+                    mx = rows4_max(mx);
                     const int n = r1g - r0g;
+                    if (lg == 0 && n1c < h1) {
 #pragma unroll
-                    for (int kk = 0; kk < 3; kk++) {
-                        if (kk >= np)
-                            break;
-                        V rr = sum;
-                        if (pools[kk] == GNNB_POOL_MEAN)
-                            rr = n > 0 ? vdiv(sum, V::splat((float)n)) : V::splat(0.0f);
-                        else if (pools[kk] == GNNB_POOL_MAX)
-                            rr = mx;
-                        rr.store(pooled + (size_t)g * np * h1 + (size_t)kk * h1 + f * 4);
+                        for (int kk = 0; kk < 3; kk++) {
+                            if (kk >= np)
+                                break;
+                            float rr = sum;
+                            if (pools[kk] == GNNB_POOL_MEAN)
+                                rr = n > 0 ? sum / (float)n : 0.0f;
+                            else if (pools[kk] == GNNB_POOL_MAX)
+                                rr = n > 0 ? mx : 0.0f;
+                            pooled[((size_t)(cur.ga + gi) * np + kk) * h1 + n1c] = rr;
+                        }
                     }
-                }
-            }
+                };
+                // two loops, not one with a choice inside: a select between the LDS table and global
+                // memory is if-converted into flat loads (+ a full vmcnt/lgkmcnt drain per graph)
+                const int nlds = min(ngr, 64);
+                for (int gi = 0; gi < nlds; gi++)
+                    pool_graph(gi, sgp[gi], sgp[gi + 1]);
+                for (int gi = nlds; gi < ngr; gi++) // a pile of empty graphs
+                    pool_graph(gi, node_ptr[cur.ga + gi], node_ptr[cur.ga + gi + 1]);
+            };
+            if (units == 3)
+                m1(IntTag<3>{});
+            else if (units == 2)
+                m1(IntTag<2>{});
+            else
+                m1(IntTag<1>{});
+        } else if (units == 0 && wv == 0) {
+            // a stage without rows (empty graphs behind the last node of a tile): zeros
+            stores_behind_dma = 1 << 20; // (full drain)
+            for (int e = tv; e < (cur.gb - cur.ga) * np * h1; e += 64)
+                pooled[(size_t)cur.ga * np * h1 + e] = 0.0f;
         }
-        G2_PT(5);
+        G2_PT(10);
 #ifdef GNNB_PROBE
         nst++;
 #endif
@@ -3131,10 +3192,10 @@ __global__ __launch_bounds__(WG, 2) void k_gcn2_fused(
         unsigned long long *o = g_probe + 8 * 8192 + blockIdx.x * 16; // second half: other kernels stamp the first
         o[0] = pw0;
         o[1] = wall_clock64();
-        for (int i = 0; i < 6; i++)
+        for (int i = 0; i < 11; i++)
             o[2 + i] = pt[i];
-        o[8] = clock64() - pt0;
-        o[9] = (unsigned long long)nst;
+        o[13] = clock64() - pt0;
+        o[14] = (unsigned long long)nst;
     }
 #endif
 }
@@ -3175,11 +3236,13 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
             }
             int nb = 0, devid = 0;
             hipDeviceProp_t prop;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WG, lds) != hipSuccess || nb < 1)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G2_WG, lds) != hipSuccess || nb < 1)
                 nb = 1;
             if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
                 cus = prop.multiProcessorCount;
             blocks = nb > 2 ? 2 : nb;
+            if (const char *e = getenv("GNNB_G2_WG_PER_CU")) // experiments only
+                blocks = atoi(e) >= 1 && atoi(e) <= blocks ? atoi(e) : blocks;
             lds_set = lds;
         }
         long long grid = (long long)cus * blocks;
@@ -3190,7 +3253,7 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
             rc = hipErrorNotSupported;
             return;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, x, f0, t.node_rec, t.col, t.dinv,
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_WG), lds, s, x, f0, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_graph, t.node_ptr, t.num_tiles, t.num_graphs, w0, b0, h0, w1, b1, h1, p0, p1, p2,
                            num_pools, pooled);
         rc = hipGetLastError();
