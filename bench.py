@@ -7,11 +7,17 @@ configs[1]: 2-layer GCN d=128, QM9-shaped graphs, batch 4096 per GPU.  One proce
 (torch.distributed / RCCL); graphs are independent, so ranks shard batches with no data-path
 collective and only the throughput counters are reduced (weak scaling).
 
-Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
-  roofline      -- the GCN gather-aggregate kernel at the full feature width: algorithmic bytes
-                    / measured launch duration (HIP events on the launch stream,
-                   rotating through distinct buffers > 256 MiB so the Infinity Cache cannot serve
-                   the reads) against 8 TB/s.
+Prints ONE JSON line on rank 0 (contract in the task prompt) with these extra objects:
+  roofline      -- the kernel that dominates the timed step.  Workload c2 (2-layer GCN with a
+                   max_graph_nodes promise) runs the fused stack kernel k_gcn2_fused (both conv layers +
+                   pooling, graphs staged in LDS, no HBM round trips): bound = fp32 MFMA, algorithmic
+                   flops 2 N (F0 h0 + h0 h1) / launch duration from HIP events on the launch stream.
+                   The other workloads run layer by layer and are dominated by the gather-aggregate
+                   kernel: bound = HBM (see next).
+  roofline_gather_aggregate -- the GCN gather-aggregate kernel at the full feature width (the
+                   north-star kernel; every layer-by-layer model runs it): algorithmic bytes (SURVEY.md
+                   8d) / measured launch duration (HIP events on the launch stream, rotating through
+                   distinct buffers > 256 MiB so the Infinity Cache cannot serve the reads) against 8 TB/s.
   cpu_baseline  -- the reference's own C++ kernel library (oracle/_ref, compiled in place from
                    /root/reference; falls back to the C oracle port when it is absent) running the
                    same model on a bounded sample of the same graphs on ONE host core, rank 0 only.
@@ -143,20 +149,38 @@ def cpu_baseline(model, batches, budget_s=12.0):
             "host_cpu": cpu_model, "host_cores_available": os.cpu_count()}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the gather-aggregate kernel from the latest committed rocprofv3 PMC
-    passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/profile_r.sh -> profiles/*_aggregate_pmc.json).
-    Counters cannot be read from inside this process; None when no profile is committed."""
+def pmc_traffic(kind="aggregate"):
+    """HBM bytes per launch of a kernel from the latest committed rocprofv3 PMC passes (FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE, tools/profile_r.sh -> profiles/*_<kind>_pmc.json).  Counters cannot be read from
+    inside this process; None when no profile is committed."""
     try:
-        files = sorted((ROOT / "profiles").glob("*_aggregate_pmc.json"))
+        files = sorted((ROOT / "profiles").glob(f"*_{kind}_pmc.json"))
         d = json.loads(files[-1].read_text())
-        return {"bytes_per_launch": d["hbm_traffic_bytes_per_launch"]["total"],
-                "read_bytes_fetch_size_x2": d["hbm_traffic_bytes_per_launch"]["read_corrected_x2"],
-                "write_bytes": d["hbm_traffic_bytes_per_launch"]["write"],
-                "over_algorithmic": d["hbm_traffic_bytes_per_launch"]["over_algorithmic"],
+        t = d["hbm_traffic_bytes_per_launch"]
+        return {"bytes_per_launch": t["total"], "read_bytes_fetch_size_x2": t["read_corrected_x2"],
+                "write_bytes": t["write"], "over_algorithmic": t["over_algorithmic"],
                 "source": f"profiles/{files[-1].name} (rocprofv3 --pmc, separate passes)"}
     except Exception:
         return None
+
+
+def measure_fused_stack(cm, batch_dev, model_dims, iters=200):
+    """The fused 2-layer GCN stack + pooling kernel on one prepared batch: launches issued back to back
+    from C, HIP events on the launch stream.  Returns None when the path is not eligible."""
+    from gnnbuilder_amd import runtime
+
+    x, coo, nptr, eptr = batch_dev
+    N, E, B = int(x.shape[0]), int(coo.shape[0]), int(nptr.numel()) - 1
+    f0, h0, h1, npool = model_dims
+    cm.graph_prep(coo, nptr, eptr, N)
+    try:
+        us = cm.gcn_stack_timed(x, iters)
+    except RuntimeError:
+        return None
+    flops = 2.0 * N * (f0 * h0 + h0 * h1)          # the two dense updates (MFMA); aggregation flops not counted
+    # HBM bytes the kernel has to move: x + node records + dinv + tile/graph tables in, pooled out
+    alg_bytes = 4 * N * f0 + 32 * N + 4 * N + 4 * (B + 1) + 4 * B * npool * h1
+    return dict(us=us, tflops=flops / (us * 1e-6) / 1e12, flops=flops, alg_bytes=alg_bytes)
 
 
 def copy_ceiling(N, width, dev, iters=200):
@@ -223,10 +247,14 @@ def main():
     model = build_model(w)
     if args.roofline_only:
         batch = synthetic.make_batch(w["shape"], w["batch"], seed=0)
-        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+        mg = int(np.diff(batch.node_ptr).max())
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=mg)
         bd = tuple(torch.from_numpy(a).to(dev) for a in (batch.x, batch.coo, batch.node_ptr, batch.edge_ptr))
         alg_bytes, agg = measure_aggregate_roofline(cm, bd, w["hidden"], dev, regimes=("hbm",))
-        print(json.dumps({"roofline_only": True, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"]}))
+        fused = measure_fused_stack(cm, bd, (int(batch.x.shape[1]), w["hidden"], w["hidden"], len(w["pools"]))) \
+            if w["conv"] == "gcn" and w["layers"] == 2 else None
+        print(json.dumps({"roofline_only": True, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"],
+                          "fused_stack": fused}))
         return
     # rank-distinct synthetic batches (weak scaling: every GPU gets its own `batch` graphs per step)
     batches = [synthetic.make_batch(w["shape"], w["batch"], seed=1000 * rank + i) for i in range(args.batches)]
@@ -316,17 +344,33 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         alg_bytes, agg = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev)
-        result["roofline"] = {
+        gather = {
             "kernel": "k_aggregate_stream<GCN> (gather-aggregate, width %d)" % w["hidden"],
             "bound": "hbm", "achieved": agg["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(),
+            "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic("aggregate"),
             "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": agg["hbm"]["us"],
             "regime": "inputs/outputs rotate over >256 MiB of distinct buffers (HBM-served); launches issued "
                       "back to back from C, HIP events on the launch stream",
             "in_pipeline_l3_resident": agg["l3_resident"],
             "copy_ceiling_same_bytes": copy_ceiling(batches[0].num_nodes, w["hidden"], dev),
         }
-        result["roofline_update"] = dict(kernel="k_linear (fp32 MFMA 32x32x2), full-width layer update",
+        fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w["hidden"],
+                                                        len(w["pools"]))) if w["conv"] == "gcn" and w["layers"] == 2 else None
+        if fused is not None:
+            # the step runs the fused stack: that kernel dominates it and is bound by the fp32 matrix rate
+            result["roofline"] = {
+                "kernel": "k_gcn2_fused (2 GCN layers + pooling in one persistent kernel, graphs staged in LDS)",
+                "bound": "mfma", "achieved": fused["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("gcn2"),
+                "algorithmic_flops_per_launch": fused["flops"], "algorithmic_hbm_bytes_per_launch": fused["alg_bytes"],
+                "us_per_launch": fused["us"], "share_of_step": fused["us"] / (ms_noprep * 1e3),
+                "note": "flops = 2 N (F0 h0 + h0 h1), the two dense updates on v_mfma_f32_16x16x4_f32; HIP events on "
+                        "the launch stream, launches issued back to back from C on one prepared batch",
+            }
+            result["roofline_gather_aggregate"] = gather
+        else:
+            result["roofline"] = gather
+        result["roofline_update"] = dict(kernel="k_linear_reg (fp32 MFMA 16x16x4), full-width layer update",
                                          bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                          **measure_update_mfma(w, batches[0].num_nodes, dev))
     if world > 1:

@@ -3188,8 +3188,8 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         b ^= 1;
     }
 #ifdef GNNB_PROBE
-    if (tid == 0 && blockIdx.x < 1024) {
-        unsigned long long *o = g_probe + 8 * 8192 + blockIdx.x * 16; // second half: other kernels stamp the first
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long *o = g_probe + 8 * 8192 + (blockIdx.x * 8 + wave) * 16; // second half: other kernels stamp the first
         o[0] = pw0;
         o[1] = wall_clock64();
         for (int i = 0; i < 11; i++)

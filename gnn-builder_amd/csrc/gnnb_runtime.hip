@@ -848,6 +848,49 @@ int gnnb_aggregate_timed(gnnb_workspace *ws, int agg_kind, const float *const *x
     return rc;
 }
 
+int gnnb_gcn_stack_timed(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, int iters,
+                         void *stream, float *out_us_per_launch)
+{
+    if (!model || !ws || !x_dev || iters < 1 || !out_us_per_launch)
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_gcn_stack_timed");
+    if (!ws->prepared)
+        return fail(GNNB_ERR_INVALID, "workspace has no prepared batch");
+    const gnnb_model_desc &d = model->desc;
+    if (d.conv_type != GNNB_CONV_GCN || d.num_layers != 2)
+        return fail(GNNB_ERR_INVALID, "the fused stack exists for 2-layer GCN models");
+    hipStream_t s = (hipStream_t)stream;
+    auto launch = [&]() {
+        return launch_gcn2_fused(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
+                                 model->conv[1][0], model->conv[1][1], d.out_dim, d.activation, d.pools,
+                                 d.num_pools, ws->pooled, s);
+    };
+    hipEvent_t e0, e1;
+    GNNB_HIP_TRY(hipEventCreate(&e0));
+    GNNB_HIP_TRY(hipEventCreate(&e1));
+    int rc = GNNB_OK;
+    hipError_t he = hipSuccess;
+    for (int i = 0; i < 3 && he == hipSuccess; i++)
+        he = launch();
+    if (he == hipErrorNotSupported)
+        rc = fail(GNNB_ERR_INVALID, "fused stack not eligible (shape, or no max_graph_nodes promise)");
+    else if (he != hipSuccess)
+        rc = fail(GNNB_ERR_HIP, "fused GCN stack launch failed: %s", hipGetErrorString(he));
+    if (rc == GNNB_OK) {
+        GNNB_HIP_TRY(hipStreamSynchronize(s));
+        GNNB_HIP_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; i++)
+            (void)launch();
+        GNNB_HIP_TRY(hipEventRecord(e1, s));
+        GNNB_HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        GNNB_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *out_us_per_launch = ms * 1000.0f / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int gnnb_linear_timed(const float *a_dev, int lda, int k, const float *w_dev, int ldw,
                       const float *bias_dev, float *y_dev, int M, int N, int act, int iters,
                       void *stream, float *out_us_per_launch)

@@ -71,7 +71,7 @@ EXPORTED_SYMBOLS = [
     "gnnb_graph_prep", "gnnb_graph_tables_to_host", "gnnb_aggregate", "gnnb_linear", "gnnb_global_pool",
     "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
     "gnnb_malloc", "gnnb_free", "gnnb_memcpy_h2d", "gnnb_memcpy_d2h", "gnnb_set_option",
-    "gnnb_aggregate_timed", "gnnb_linear_timed",
+    "gnnb_aggregate_timed", "gnnb_linear_timed", "gnnb_gcn_stack_timed",
 ]
 
 
@@ -134,6 +134,8 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
         lib.gnnb_linear_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.POINTER(C.c_float)]
+        lib.gnnb_gcn_stack_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                             C.POINTER(C.c_float)]
         _lib = lib
     if require_gpu and _lib.gnnb_device_count() <= 0:
         raise GnnbUnavailable("libgnnb_hip.so loaded but no MI355X (HIP device) is visible; "
@@ -319,6 +321,14 @@ class CompiledModel:
         us = C.c_float()
         _check(self.lib.gnnb_aggregate_timed(self._ws, AGG[kind], xa, _dptr(self_term) if self_term is not None else None,
                                              oa, n, int(xs[0].shape[1]), float(eps), int(iters), _stream_ptr(stream),
+                                             C.byref(us)))
+        return float(us.value)
+
+    def gcn_stack_timed(self, x, iters: int, stream=None) -> float:
+        """Mean microseconds per launch of the fused 2-layer GCN stack + pooling kernel on the prepared
+        batch (``graph_prep`` first); HIP events on the launch stream.  Raises if that path is not eligible."""
+        us = C.c_float()
+        _check(self.lib.gnnb_gcn_stack_timed(self._model, self._ws, _dptr(x), int(iters), _stream_ptr(stream),
                                              C.byref(us)))
         return float(us.value)
 

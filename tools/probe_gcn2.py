@@ -18,11 +18,17 @@ for _ in range(10):
 torch.cuda.synchronize()
 lib = runtime.load_library(); n = 16 * 8192
 buf = (C.c_ulonglong * n)(); lib.gnnb_probe_read(buf, n)
-p = np.frombuffer(buf, dtype=np.uint64)[8 * 8192:8 * 8192 + 16 * 1024].reshape(1024, 16).astype(np.float64)
+pall = np.frombuffer(buf, dtype=np.uint64)[8 * 8192:8 * 8192 + 16 * 4096].reshape(512, 8, 16).astype(np.float64)
+p = pall[:, 0, :]
 p = p[p[:, 14] > 0]
 life = (p[:, 1] - p[:, 0]) / 100
 print(f"workgroups {len(p)}, stages/WG {p[:, 14].mean():.2f} (max {p[:, 14].max():.0f}); span {(p[:, 1].max() - p[:, 0].min()) / 100:.2f} us, lifetime mean {life.mean():.2f} max {life.max():.2f}, last start +{(p[:, 0].max() - p[:, 0].min()) / 100:.2f}")
-names = ["wait DMA + barrier(1)", "issue next DMA", "P0 (agg F0)", "barrier(2)", "M0", "barrier(3)", "P1 (agg d)", "barrier(4)", "M1", "barrier(5)", "pooling"]
+names = ["wait DMA + barrier(1)", "issue next DMA", "P0 (agg F0)", "barrier(2)", "M0", "barrier(3)", "P1 (agg d)", "barrier(4)", "-", "-", "M1 + pooling"]
 for i, nm in enumerate(names):
     print(f"  {nm:24s} {100 * (p[:, 2 + i] / p[:, 13]).mean():5.1f}%  {(p[:, 2 + i] / p[:, 14]).mean():8.0f} cycles/stage")
 print(f"  clock {np.median(p[:, 13] / life):.0f} MHz")
+
+print("per-wave cycles/stage (mean over workgroups):")
+pa = pall[pall[:, 0, 14] > 0]
+for w in range(8):
+    print(f"  wave {w}: " + " ".join(f"{(pa[:, w, 2 + i] / pa[:, w, 14]).mean():7.0f}" for i in range(11)))

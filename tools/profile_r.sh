@@ -12,5 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/roofline" -o roofl
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 bench.py --roofline-only > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 bench.py --roofline-only > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -o l2 -- python3 bench.py --roofline-only > "$OUT/pmc_l2.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d "$OUT/pmc_inst" -o inst -- python3 bench.py --roofline-only > "$OUT/pmc_inst.log" 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d "$OUT/pmc_busy" -o busy -- python3 bench.py --roofline-only > "$OUT/pmc_busy.log" 2>&1
 find "$OUT" -name "*.csv" | xargs ls -la
 tail -2 "$OUT"/*.log

@@ -38,17 +38,23 @@ kernel_stats(src / "bench" / "bench_kernel_stats.csv", dst / f"{tag}_bench_kerne
 kernel_stats(src / "roofline" / "roofline_kernel_stats.csv", dst / f"{tag}_roofline_only_kernel_stats.csv",
              "python3 bench.py --roofline-only  (HBM-regime gather-aggregate loop only)")
 
-pmc = {}
-for sub, fname in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("pmc_l2", "l2")):
-    p = src / sub / f"{fname}_counter_collection.csv"
-    if not p.exists():
-        continue
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(p)):
-        if "k_aggregate" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        pmc[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+def collect(pattern):
+    pmc = {}
+    for sub, fname in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("pmc_l2", "l2"), ("pmc_inst", "inst"),
+                       ("pmc_busy", "busy")):
+        p = src / sub / f"{fname}_counter_collection.csv"
+        if not p.exists():
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(p)):
+            if pattern in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            pmc[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+    return pmc
+
+
+pmc = collect("k_aggregate")
 
 log = (src / "roofline.log").read_text().strip().splitlines()
 meas = json.loads([l for l in log if l.startswith("{")][-1])
@@ -67,3 +73,24 @@ if "TCC_HIT_sum" in pmc:
     summary["l2_hit_rate"] = h / (h + m)
 (dst / f"{tag}_aggregate_pmc.json").write_text(json.dumps(summary, indent=2) + "\n")
 print(json.dumps(summary, indent=2))
+
+# ---- the fused 2-layer GCN stack kernel (dominant kernel of workload c2)
+fs = meas.get("fused_stack")
+g2 = collect("k_gcn2_fused")
+if fs and g2:
+    s2 = {"command": "rocprofv3 --pmc <counters> -- python3 bench.py --roofline-only (one pass per counter group)",
+          "kernel": "gnnb::k_gcn2_fused<relu, KQ0=1, KQ1=8>, BASELINE config 2 batch",
+          "raw_counters_per_launch": g2, "algorithmic_flops_per_launch": fs["flops"],
+          "algorithmic_hbm_bytes_per_launch": fs["alg_bytes"], "events_us_per_launch": fs["us"]}
+    if "FETCH_SIZE" in g2 and "WRITE_SIZE" in g2:
+        fetch = g2["FETCH_SIZE"]["mean"] * 1024.0 * 2.0
+        write = g2["WRITE_SIZE"]["mean"] * 1024.0
+        s2["hbm_traffic_bytes_per_launch"] = {"read_corrected_x2": fetch, "write": write, "total": fetch + write,
+                                              "over_algorithmic": (fetch + write) / fs["alg_bytes"]}
+    if "SQ_INSTS_VALU" in g2 and "SQ_INSTS_MFMA" in g2:
+        s2["instruction_mix_per_launch"] = {"valu_non_mfma": g2["SQ_INSTS_VALU"]["mean"] - g2["SQ_INSTS_MFMA"]["mean"],
+                                            "mfma": g2["SQ_INSTS_MFMA"]["mean"],
+                                            "salu": g2.get("SQ_INSTS_SALU", {}).get("mean"),
+                                            "lds": g2.get("SQ_INSTS_LDS", {}).get("mean")}
+    (dst / f"{tag}_gcn2_pmc.json").write_text(json.dumps(s2, indent=2) + "\n")
+    print(json.dumps(s2, indent=2))
