@@ -2866,7 +2866,10 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     float *A0 = reinterpret_cast<float *>(smem + 2 * in_b);
     float *H = A0 + G2_CAP * LD0;
     float *A1 = H + G2_CAP * ldh;
-    int32_t *stile = reinterpret_cast<int32_t *>(A1 + G2_CAP * h0);
+    // per-row aggregation record written by P0, read by P1: {byte offsets of the 4 inline neighbour rows in H}
+    // {coefficients dinv_i dinv_j, 0 past the degree} {dinv_i^2, rp0, deg, dinv_i}
+    int4 *REC = reinterpret_cast<int4 *>(A1 + G2_CAP * h0);
+    int32_t *stile = reinterpret_cast<int32_t *>(REC + 3 * G2_CAP);
     int32_t *sgraph = stile + (G2_TCAP + 1);
 
     const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
@@ -3037,16 +3040,23 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 sv[q] = sdinv[jl[q]];
             }
             const float xself = xs[i * f0 + fc];
-            float acc = 0.0f;
+            float c[4], acc = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                acc += (deg > q) ? xv[q] * (di * sv[q]) : 0.0f;
+            for (int q = 0; q < 4; q++) {
+                c[q] = deg > q ? di * sv[q] : 0.0f;
+                acc += xv[q] * c[q];
+            }
             for (int k = r0.x + 4; k < r0.x + deg; k++) { // degree > 4: rare in molecules
                 const int j = col[k] - nb;
                 acc += xs[j * f0 + fc] * (di * sdinv[j]);
             }
             acc += xself * (di * di);
             A0[i * LD0 + f] = f < f0 ? acc : 0.0f;
+            if (f == 0) { // the row's scalars, computed once here instead of by every lane of P1's lane group
+                REC[3 * i] = make_int4(jl[0] * ldh * 4, jl[1] * ldh * 4, jl[2] * ldh * 4, jl[3] * ldh * 4);
+                REC[3 * i + 1] = make_int4(__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]), __float_as_int(c[3]));
+                REC[3 * i + 2] = make_int4(__float_as_int(di * di), r0.x, deg, __float_as_int(di));
+            }
         }
         G2_PT(2);
         g2_barrier(); // (2)
@@ -3078,35 +3088,48 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         g2_barrier(); // (3)
         G2_PT(5);
 
-        // ---- P1: A1 = gcn-aggregate(H), one lane group per row, destination XOR-swizzled for M1's
-        // fragment reads.  (One row in flight per group: the register budget is 128 per lane so that two
-        // 8-wave workgroups share a CU, and the weight slices must not be spilled.)
-        for (int rA = grp; rA < rows; rA += groups) {
-            const int4 a0 = srec[2 * rA], a1 = srec[2 * rA + 1];
-            const int degA = a0.y;
-            const int jA[4] = {a0.z - nb, a0.w - nb, a1.x - nb, a1.y - nb};
-            const float dA = sdinv[rA];
-            float sA_[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                sA_[q] = sdinv[jA[q]];
-            for (int f = gl; f < nv1; f += Gl) {
-                typedef Vf<4> V;
-                V nA[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    nA[q] = V::load(H + jA[q] * ldh + f * 4); // unused slots alias the row itself
-                const V selfA = V::load(H + rA * ldh + f * 4);
-                V accA = V::splat(0.0f);
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    accA = vadd(accA, vmul(nA[q], V::splat(degA > q ? dA * sA_[q] : 0.0f)));
-                for (int k = a0.x + 4; k < a0.x + degA; k++) {
-                    const int j = col[k] - nb;
-                    accA = vadd(accA, vmul(V::load(H + j * ldh + f * 4), V::splat(dA * sdinv[j])));
+        // ---- P1: A1 = gcn-aggregate(H), one lane group of h0/4 lanes per row (a float4 chunk each),
+        // destination XOR-swizzled for M1's fragment reads.  Offsets and coefficients come ready-made from
+        // REC; the next pass's record is fetched while this pass's rows are in flight.  (VALU instructions
+        // are what bounds this kernel: row-level scalars must not be recomputed by all lanes of a group.)
+        {
+            typedef Vf<4> V;
+            const char *Hl = reinterpret_cast<const char *>(H) + gl * 16; // this lane's chunk of row 0
+            int4 ra = make_int4(0, 0, 0, 0), rc = ra, rd = ra;
+            if (grp < rows) {
+                ra = REC[3 * grp];
+                rc = REC[3 * grp + 1];
+                rd = REC[3 * grp + 2];
+            }
+            // (at most 3 passes: groups >= 16 and rows <= 48; fixed-count loop, no derived trip count)
+#pragma unroll 1
+            for (int pass = 0; pass < G2_UNITS; pass++) {
+                const int rA = grp + pass * groups;
+                if (rA >= rows)
+                    break;
+                const int rN = rA + groups;
+                const int4 ja = ra, ca = rc, da = rd;
+                if (rN < rows) {
+                    ra = REC[3 * rN];
+                    rc = REC[3 * rN + 1];
+                    rd = REC[3 * rN + 2];
                 }
-                accA = vadd(accA, vmul(selfA, V::splat(dA * dA)));
-                accA.store(A1 + rA * h0 + ((f ^ (rA & (P1 - 1))) << 2));
+                const V n0 = V::load(reinterpret_cast<const float *>(Hl + ja.x)); // unused slots alias the row itself (coefficient 0)
+                const V n1 = V::load(reinterpret_cast<const float *>(Hl + ja.y));
+                const V n2 = V::load(reinterpret_cast<const float *>(Hl + ja.z));
+                const V n3 = V::load(reinterpret_cast<const float *>(Hl + ja.w));
+                const V selfA = V::load(reinterpret_cast<const float *>(Hl + rA * ldh * 4));
+                V accA = vmul(n0, V::splat(__int_as_float(ca.x)));
+                accA = vadd(accA, vmul(n1, V::splat(__int_as_float(ca.y))));
+                accA = vadd(accA, vmul(n2, V::splat(__int_as_float(ca.z))));
+                accA = vadd(accA, vmul(n3, V::splat(__int_as_float(ca.w))));
+                for (int k = da.y + 4; k < da.y + da.z; k++) { // degree > 4
+                    const int j = col[k] - nb;
+                    accA = vadd(accA, vmul(V::load(reinterpret_cast<const float *>(Hl + j * ldh * 4)),
+                                           V::splat(__int_as_float(da.w) * sdinv[j])));
+                }
+                accA = vadd(accA, vmul(selfA, V::splat(__int_as_float(da.x))));
+                accA.store(A1 + rA * h0 + ((gl ^ (rA & (P1 - 1))) << 2));
             }
         }
         G2_PT(6);
@@ -3218,7 +3241,7 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     const int in_b = xs_b + G2_CAP * 32 + G2_CAP * 4 + 272;
     const int ldh = (h0 > h1 ? h0 : h1) + 4;
     const size_t lds = 2 * (size_t)in_b + (size_t)G2_CAP * 16 * (f0 <= 16 ? 1 : 2) * 4 + (size_t)G2_CAP * ldh * 4 +
-                       (size_t)G2_CAP * h0 * 4 + 2 * (size_t)(G2_TCAP + 1) * 4;
+                       (size_t)G2_CAP * h0 * 4 + (size_t)G2_CAP * 48 + 2 * (size_t)(G2_TCAP + 1) * 4;
     const int kq0 = f0 <= 16 ? 1 : 2, kq1 = h0 / 16;
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
     hipError_t rc = hipErrorNotSupported;
