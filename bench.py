@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches rotated per rank")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: each on its own HIP stream and workspace, so the MFMA-bound "
                          "update of one batch overlaps the HBM-bound gather / readout of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")

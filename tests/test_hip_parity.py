@@ -408,3 +408,32 @@ def test_full_size_config2_fused_path(dev):
     sub = pack_graphs([batch.graph(int(g)) for g in idx])
     ref = O.forward_batched(model.spec(), canon(model), sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
     assert np.abs(out[idx] - ref).max() < TOL
+
+
+@pytest.mark.parametrize("conv,promise", [("gcn", 29), ("gcn", 0), ("sage", 0)])
+def test_forward_is_hip_graph_capturable(dev, conv, promise):
+    """gnnb_forward_batched does no allocation and no synchronisation, so a caller can capture it
+    (graph prep included) into a hipGraph and replay it with new features in the same buffers
+    (SURVEY 8e / DESIGN 3.6).  Both the fused GCN stack and the layer-by-layer path."""
+    model = make_model(conv, in_dim=11, hidden=128, layers=2, out_dim=128, act="relu", pools=("add", "mean", "max"), task_out=19)
+    batch = synthetic.make_batch("qm9", 256, seed=5)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise)
+    x, coo, nptr, eptr = to_dev(batch, dev)
+    out = torch.empty(batch.num_graphs, 19, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        cm.forward(x, coo, nptr, eptr, out=out, stream=side)  # warm-up: one-time function attributes, lazy module load
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        cm.forward(x, coo, nptr, eptr, out=out, stream=torch.cuda.current_stream())
+    rng = np.random.default_rng(0)
+    for _ in range(2):  # replay on fresh features written into the captured input buffer
+        xn = rng.uniform(-1, 1, batch.x.shape).astype(np.float32)
+        x.copy_(torch.from_numpy(xn))
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ref = O.forward_batched(model.spec(), canon(model), xn, batch.coo, batch.node_ptr, batch.edge_ptr)
+        assert np.abs(out.cpu().numpy() - ref).max() < TOL
+    cm.check()
