@@ -1859,11 +1859,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GNNB_LR_SR 2
 #endif
 // a full stage's vector epilogue issues 2*SR 16-B stores per wave
+#define GNNB_STR2(x) #x
+#define GNNB_STR(x) GNNB_STR2(x)
 #if GNNB_LR_SR == 1
-#define GNNB_LR_COUNTED_WAIT "s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier"
+#define GNNB_LR_NSTORES 2
+#elif GNNB_LR_SR == 2
+#define GNNB_LR_NSTORES 4
+#elif GNNB_LR_SR == 3
+#define GNNB_LR_NSTORES 6
 #else
-#define GNNB_LR_COUNTED_WAIT "s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier"
+#define GNNB_LR_NSTORES 8
 #endif
+#define GNNB_LR_COUNTED_WAIT "s_waitcnt vmcnt(" GNNB_STR(GNNB_LR_NSTORES) ") lgkmcnt(0)\n\ts_barrier"
+
 
 // Optional fused gather: when `rec` is set the A stage is not copied from memory but PRODUCED -- the
 // workgroup aggregates its destination rows (GCN / sum / mean semantics of k_aggregate_*) from the
@@ -1897,7 +1905,7 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
     const int unit_rows = 16 * RG;
     const int stage_rows = SR * unit_rows;
     const size_t buf_bytes = (((size_t)stage_rows * K * 4) + 15) & ~(size_t)15;
-    float *sC = reinterpret_cast<float *>(smem + 2 * buf_bytes) + (size_t)wave * 32 * EPI_LD;
+    float *sC = reinterpret_cast<float *>(smem + 2 * buf_bytes) + (size_t)wave * 16 * SR * EPI_LD;
 
     // ---- persistent range, balanced in UNITS of 16*RG rows (half a stage), so the remainder a
     // workgroup may carry is half a stage.  Local stage j covers units [u0+2j, min(u0+2j+2, u1)).
@@ -2211,7 +2219,7 @@ static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const floa
     const int stage_rows = (16 * GNNB_LR_SR) << rg_log2;
     const int gy = (N + cols_per_wg - 1) / cols_per_wg;
     const size_t buf = (((size_t)stage_rows * K * 4) + 15) & ~(size_t)15;
-    const size_t lds = 2 * buf + 4 * 32 * 36 * 4; // two stage buffers + per-wave epilogue scratch
+    const size_t lds = 2 * buf + 4 * 16 * GNNB_LR_SR * 36 * 4; // two stage buffers + per-wave epilogue scratch
     const int vec_out = (N % 4 == 0) && (((uintptr_t)Y & 15) == 0) && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
                         (skip == nullptr || ((uintptr_t)skip & 15) == 0);
     int P = 1;
@@ -2843,7 +2851,86 @@ __device__ __forceinline__ void g2_mma(const float *__restrict__ Asrc, int lda, 
             v[k][r] = act_t<ACT>((NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias);
 }
 
-template <int ACT, int KQ0, int KQ1>
+// ---- fp32 product through the bf16 matrix cores ("bf16x6").  x = h + m + l EXACTLY, each piece a bf16
+// (8 significant bits each: truncate, subtract, truncate, subtract -- every step is exact in fp32), so
+// a.b = sum of nine bf16 x bf16 products, each exact in fp32.  The six with i + j <= 2 are kept
+// (hh, hm, mh, hl, lh, mm); the three dropped ones are below 2^-24 |a||b|, i.e. below what fp32 resolves of
+// the product.  Accumulation is fp32 inside v_mfma_f32_16x16x32_bf16.  Cost: 6 MFMA of 4 passes per
+// 32-wide k block instead of 8 fp32 MFMA of 8 passes -- 2.4x fewer pipe cycles, and fp32 MFMA runs at
+// the vector-FMA rate on this chip (tools/micro/mfma_valu_overlap.hip).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m)); // <= 8 significant bits left: its upper half is exact
+}
+// two fp32 bit patterns -> their upper halves packed as {bf16(a) in bits 0..15, bf16(b) in bits 16..31}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v)
+{
+    union {
+        u32x4 u;
+        bf16x8 b;
+    } c;
+    c.u = v;
+    return c.b;
+}
+
+// M1 of the fused stack with bf16x6: A1 lives in LDS as three bf16 planes [rows][h0] (16-B chunks of
+// eight k values, XOR-swizzled by row), the wave's W1 slice as three register sets.  Lane (li, lg) of a
+// 16x16x32 MFMA holds k = 32 kb + 8 lg .. + 7 of row / column li for both operands.
+template <int ACT, int KB, int NU>
+__device__ __forceinline__ void g2_mma_bf6(const char *__restrict__ planes, int plane_bytes, int row_bytes, int Pb,
+                                           const u32x4 (&wh)[KB], const u32x4 (&wm)[KB], const u32x4 (&wl)[KB],
+                                           float bias, int li, int lg, float (&v)[NU][4])
+{
+    f32x4 acc[NU];
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+        acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        bf16x8 ah[NU], am[NU], al[NU];
+#pragma unroll
+        for (int k = 0; k < NU; k++) {
+            const int row = k * 16 + li;
+            const int off = row * row_bytes + (((4 * kb + lg) ^ (row & (Pb - 1))) << 4);
+            ah[k] = as_bf16x8(*reinterpret_cast<const u32x4 *>(planes + off));
+            am[k] = as_bf16x8(*reinterpret_cast<const u32x4 *>(planes + plane_bytes + off));
+            al[k] = as_bf16x8(*reinterpret_cast<const u32x4 *>(planes + 2 * plane_bytes + off));
+        }
+        const bf16x8 bh = as_bf16x8(wh[kb]), bm = as_bf16x8(wm[kb]), bl = as_bf16x8(wl[kb]);
+        // smallest terms first; the units' accumulators interleaved (dependent MFMAs three issues apart)
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k], bm, acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k], bh, acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k], bl, acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k], bh, acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k], bm, acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k], bh, acc[k], 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            v[k][r] = act_t<ACT>(acc[k][r] + bias);
+}
+
+template <int ACT, int KQ0, int KQ1, int MATH>
 __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
@@ -2868,7 +2955,10 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     float *A1 = H + G2_CAP * ldh;
     // per-row aggregation record written by P0, read by P1: {byte offsets of the 4 inline neighbour rows in H}
     // {coefficients dinv_i dinv_j, 0 past the degree} {dinv_i^2, rp0, deg, dinv_i}
-    int4 *REC = reinterpret_cast<int4 *>(A1 + G2_CAP * h0);
+    // (MATH 1: A1 is three bf16 planes [G2_CAP][h0] instead of one fp32 matrix: 1.5x the bytes)
+    constexpr int KB1 = KQ1 / 2 > 0 ? KQ1 / 2 : 1; // 32-wide k blocks of layer 1 (h0 = 32, 64, 128)
+    const int plane_b = G2_CAP * h0 * 2;
+    int4 *REC = reinterpret_cast<int4 *>(reinterpret_cast<char *>(A1) + (MATH ? 3 * plane_b : G2_CAP * h0 * 4));
     int32_t *stile = reinterpret_cast<int32_t *>(REC + 3 * G2_CAP);
     int32_t *sgraph = stile + (G2_TCAP + 1);
 
@@ -2908,7 +2998,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     for (int q = 0; q < KQ1; q++) {
         const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n1c < h1)
+        if (!MATH && n1c < h1)
             v = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + k);
         w1r[q * 4 + 0] = v.x;
         w1r[q * 4 + 1] = v.y;
@@ -2917,6 +3007,32 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     }
     float bias0 = (n0c < h0 && b0) ? b0[n0c] : 0.0f;
     float bias1 = (n1c < h1 && b1) ? b1[n1c] : 0.0f;
+    // MATH 1: the wave's W1 slice as three bf16 register sets, lane (li, lg) holding k = 32 kb + 8 lg .. + 7
+    u32x4 wh[KB1], wm[KB1], wl[KB1];
+    if (MATH) {
+#pragma unroll
+        for (int kb = 0; kb < KB1; kb++) {
+            float wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                wv[i] = 0.0f;
+            if (n1c < h1 && 32 * kb + 8 * lg < h0) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + 32 * kb + 8 * lg);
+                const float4 v1 = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + 32 * kb + 8 * lg + 4);
+                wv[0] = v0.x, wv[1] = v0.y, wv[2] = v0.z, wv[3] = v0.w;
+                wv[4] = v1.x, wv[5] = v1.y, wv[6] = v1.z, wv[7] = v1.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t h0_, m0_, l0_, h1_, m1_, l1_;
+                split3(wv[2 * i], h0_, m0_, l0_);
+                split3(wv[2 * i + 1], h1_, m1_, l1_);
+                wh[kb][i] = pack_hi16(h0_, h1_);
+                wm[kb][i] = pack_hi16(m0_, m1_);
+                wl[kb][i] = pack_hi16(l0_, l1_);
+            }
+        }
+    }
     // Pin every weight register through an (empty) asm: the compiler must finish the loads HERE.  Left
     // alone it keeps them "possibly in flight" around the stage loop's back edge and guards their first
     // use in M0 / M1 with s_waitcnt vmcnt(0) -- which also waits for the next stage's DMA issued just
@@ -2924,9 +3040,17 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 #pragma unroll
     for (int q = 0; q < KQ0 * 4; q++)
         asm volatile("" : "+v"(w0r[q]));
+    if (MATH) {
 #pragma unroll
-    for (int q = 0; q < KQ1 * 4; q++)
-        asm volatile("" : "+v"(w1r[q]));
+        for (int kb = 0; kb < KB1; kb++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                asm volatile("" : "+v"(wh[kb][i]), "+v"(wm[kb][i]), "+v"(wl[kb][i]));
+    } else {
+#pragma unroll
+        for (int q = 0; q < KQ1 * 4; q++)
+            asm volatile("" : "+v"(w1r[q]));
+    }
     asm volatile("" : "+v"(bias0), "+v"(bias1));
     __syncthreads();
 
@@ -2976,6 +3100,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 
     const int P1 = 16 < (h0 >> 2) ? 16 : (h0 >> 2); // swizzle period of A1 (h0/4 chunks per row, power of two)
     const int nv1 = h0 >> 2;                         // float4 chunks per H row consumed by layer 1
+    const int Pb1 = 16 < (h0 >> 3) ? 16 : (h0 >> 3); // swizzle period of the bf16 planes (h0/8 chunks per row)
     int glog2 = 2;
     while ((1 << glog2) < nv1 && glog2 < 6)
         glog2++;
@@ -3129,7 +3254,20 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                                            V::splat(__int_as_float(da.w) * sdinv[j])));
                 }
                 accA = vadd(accA, vmul(selfA, V::splat(__int_as_float(da.x))));
-                accA.store(A1 + rA * h0 + ((gl ^ (rA & (P1 - 1))) << 2));
+                if (MATH) {
+                    // split into the three bf16 planes: this lane's 4 values = half of a 16-B chunk of 8
+                    uint32_t hh[4], mm[4], ll[4];
+                    split3(accA.v.x, hh[0], mm[0], ll[0]);
+                    split3(accA.v.y, hh[1], mm[1], ll[1]);
+                    split3(accA.v.z, hh[2], mm[2], ll[2]);
+                    split3(accA.v.w, hh[3], mm[3], ll[3]);
+                    char *dstp = reinterpret_cast<char *>(A1) + rA * (h0 * 2) + (((gl >> 1) ^ (rA & (Pb1 - 1))) << 4) + (gl & 1) * 8;
+                    *reinterpret_cast<uint2 *>(dstp) = make_uint2(pack_hi16(hh[0], hh[1]), pack_hi16(hh[2], hh[3]));
+                    *reinterpret_cast<uint2 *>(dstp + plane_b) = make_uint2(pack_hi16(mm[0], mm[1]), pack_hi16(mm[2], mm[3]));
+                    *reinterpret_cast<uint2 *>(dstp + 2 * plane_b) = make_uint2(pack_hi16(ll[0], ll[1]), pack_hi16(ll[2], ll[3]));
+                } else {
+                    accA.store(A1 + rA * h0 + ((gl ^ (rA & (P1 - 1))) << 2));
+                }
             }
         }
         G2_PT(6);
@@ -3145,7 +3283,10 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
             auto m1 = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
                 float v[NU][4];
-                g2_mma<ACT, KQ1, NU, true>(A1, h0, P1, w1r, bias1, 0, 1, li, lg, v);
+                if (MATH)
+                    g2_mma_bf6<ACT, KB1, NU>(reinterpret_cast<const char *>(A1), plane_b, h0 * 2, Pb1, wh, wm, wl, bias1, li, lg, v);
+                else
+                    g2_mma<ACT, KQ1, NU, true>(A1, h0, P1, w1r, bias1, 0, 1, li, lg, v);
                 const int ngr = cur.gb - cur.ga;
                 // (one store instruction per graph and pool; none if the whole slice is past h1; the rare
                 // paths below that read global memory only make the count conservative -- see the wait)
@@ -3237,17 +3378,19 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     if ((((uintptr_t)w1) & 15) || (((uintptr_t)pooled) & 15) || (((uintptr_t)x) & 3))
         return hipErrorNotSupported;
     // every stage must hold at least one tile: workgroups need ceil(T / grid) + 1 <= G2_TCAP table entries
+    const int math = o.math ? 1 : 0;
     const int xs_b = ((G2_CAP * f0 * 4) + 15) & ~15;
     const int in_b = xs_b + G2_CAP * 32 + G2_CAP * 4 + 272;
     const int ldh = (h0 > h1 ? h0 : h1) + 4;
     const size_t lds = 2 * (size_t)in_b + (size_t)G2_CAP * 16 * (f0 <= 16 ? 1 : 2) * 4 + (size_t)G2_CAP * ldh * 4 +
-                       (size_t)G2_CAP * h0 * 4 + (size_t)G2_CAP * 48 + 2 * (size_t)(G2_TCAP + 1) * 4;
+                       (size_t)G2_CAP * h0 * (math ? 6 : 4) + (size_t)G2_CAP * 48 + 2 * (size_t)(G2_TCAP + 1) * 4;
     const int kq0 = f0 <= 16 ? 1 : 2, kq1 = h0 / 16;
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
     hipError_t rc = hipErrorNotSupported;
-    auto go = [&](auto atag, auto q0tag, auto q1tag) {
+    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto mtag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
-        auto kern = k_gcn2_fused<ACT, KQ0, KQ1>;
+        constexpr int MATH = decltype(mtag)::value;
+        auto kern = k_gcn2_fused<ACT, KQ0, KQ1, MATH>;
         static size_t lds_set = 0;
         static int blocks = 0, cus = 256;
         if (lds_set != lds) {
@@ -3280,6 +3423,12 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
                            t.tile_first, t.tile_graph, t.node_ptr, t.num_tiles, t.num_graphs, w0, b0, h0, w1, b1, h1, p0, p1, p2,
                            num_pools, pooled);
         rc = hipGetLastError();
+    };
+    auto go = [&](auto atag, auto q0tag, auto q1tag) {
+        if (math)
+            go2(atag, q0tag, q1tag, IntTag<1>{});
+        else
+            go2(atag, q0tag, q1tag, IntTag<0>{});
     };
     auto go_q = [&](auto atag) {
         if (kq0 == 1 && kq1 == 8) go(atag, IntTag<1>{}, IntTag<8>{});

@@ -437,3 +437,28 @@ def test_forward_is_hip_graph_capturable(dev, conv, promise):
         ref = O.forward_batched(model.spec(), canon(model), xn, batch.coo, batch.node_ptr, batch.edge_ptr)
         assert np.abs(out.cpu().numpy() - ref).max() < TOL
     cm.check()
+
+
+@pytest.mark.parametrize("fin,h0,h1,act", [(11, 128, 128, "relu"), (9, 64, 64, "tanh"), (20, 128, 64, "gelu"), (11, 32, 128, "relu")])
+def test_fused_gcn_stack_bf16x6_math_is_fp32_equivalent(dev, fin, h0, h1, act):
+    """Opt-in math mode 1: the wide update of the fused stack as six bf16 MFMA products of an exact 3-way
+    split of both operands.  Must agree with the oracle inside the north-star tolerance AND
+    sit at fp32 rounding level next to the fp32-MFMA path (the dropped partial products are < 2^-24 of a product)."""
+    model = make_model("gcn", in_dim=fin, hidden=h0, layers=2, out_dim=h1, act=act, pools=("add", "mean", "max"), task_out=7)
+    batch = synthetic.make_batch("qm9", 500, seed=h0 + fin)
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, (batch.num_nodes, fin)).astype(np.float32)
+    ref = O.forward_batched(model.spec(), canon(model), x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)
+    xd = torch.from_numpy(x).to(dev)
+    _, coo, nptr, eptr = to_dev(batch, dev)
+    try:
+        runtime.set_option("math", 1)
+        split = cm.forward(xd, coo, nptr, eptr).cpu().numpy()
+        cm.check()
+    finally:
+        runtime.set_option("math", 0)
+    exact = cm.forward(xd, coo, nptr, eptr).cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(split - ref).max() < TOL and np.abs(exact - ref).max() < TOL
+    assert np.abs(split - exact).max() < 4e-6 * scale, np.abs(split - exact).max()
