@@ -2970,6 +2970,57 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         stile[i] = tile_first[t0 + i];
         sgraph[i] = tile_graph[t0 + i];
     }
+    __syncthreads();
+
+    auto plan = [&](int ta) {
+        G2Stage st;
+        st.ta = ta;
+        st.tb = ta;
+        st.nb = 0;
+        st.rows = 0;
+        st.ga = 0;
+        st.gb = 0;
+        if (ta >= t1)
+            return st;
+        st.nb = stile[ta - t0];
+        int tb = ta + 1;
+        while (tb < t1 && stile[tb + 1 - t0] - st.nb <= G2_CAP)
+            tb++;
+        st.tb = tb;
+        st.rows = min(stile[tb - t0] - st.nb, G2_CAP); // (> CAP only if the max_graph_nodes promise is broken)
+        st.ga = sgraph[ta - t0];
+        // (empty graphs after the last node belong to the last stage: when N is a multiple of the tile
+        // size the first of them already owns tile_graph[num_tiles])
+        st.gb = tb == num_tiles ? num_graphs : sgraph[tb - t0];
+        return st;
+    };
+    auto issue = [&](const G2Stage &st, int bb, int lane, int wave) { // (lane, wave: see `tv` below)
+        if (st.ta >= t1)
+            return;
+        // (a stage may have NO rows and still own graphs: empty graphs behind a graph that ends on the
+        // tile edge -- their boundaries are still needed by the pooling phase)
+        char *base = smem + (size_t)bb * in_b;
+        dma_dwords_u(x + (size_t)st.nb * f0, base, st.rows * f0, wave, lane, G2_NW);
+        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
+        const int rbytes = st.rows * 32;
+        if (wave * 1024 + lane * 16 < rbytes) // <= 48 rows * 32 B = 1.5 KiB: waves 0 and 1
+            dma16_to_lds_u(grec + wave * 1024 + lane * 16, base + xs_b + wave * 1024);
+        if (wave == 2 && lane < st.rows)
+            dma4_to_lds_u(dinv + st.nb + lane, base + xs_b + G2_CAP * 32);
+        // graph boundaries of the stage for the pooling phase (first 64 graphs; more only if empty
+        // graphs pile up, those are read from global memory)
+        const int ng = min(st.gb - st.ga, 64) + 1;
+        if (wave == 3 && lane < ng)
+            dma4_to_lds_u(node_ptr + st.ga + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4);
+        if (wave == 4 && lane + 64 < ng)
+            dma4_to_lds_u(node_ptr + st.ga + 64 + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4 + 256);
+    };
+
+    // the first stage's inputs start their way to LDS before the weights are fetched (both are waited for
+    // together below), instead of after them
+    G2Stage cur = plan(t0);
+    issue(cur, 0, lane, wave);
+
 
     // ---- wave roles: layer L has ncs_L = pow2ceil(h_L / 16) column slices of 16 and nrg_L = 8 / ncs_L
     // row groups; wave w owns slice (w mod ncs) for the units rg, rg + nrg, ... with rg = w / ncs
@@ -3054,50 +3105,6 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     asm volatile("" : "+v"(bias0), "+v"(bias1));
     __syncthreads();
 
-    auto plan = [&](int ta) {
-        G2Stage st;
-        st.ta = ta;
-        st.tb = ta;
-        st.nb = 0;
-        st.rows = 0;
-        st.ga = 0;
-        st.gb = 0;
-        if (ta >= t1)
-            return st;
-        st.nb = stile[ta - t0];
-        int tb = ta + 1;
-        while (tb < t1 && stile[tb + 1 - t0] - st.nb <= G2_CAP)
-            tb++;
-        st.tb = tb;
-        st.rows = min(stile[tb - t0] - st.nb, G2_CAP); // (> CAP only if the max_graph_nodes promise is broken)
-        st.ga = sgraph[ta - t0];
-        // (empty graphs after the last node belong to the last stage: when N is a multiple of the tile
-        // size the first of them already owns tile_graph[num_tiles])
-        st.gb = tb == num_tiles ? num_graphs : sgraph[tb - t0];
-        return st;
-    };
-    auto issue = [&](const G2Stage &st, int bb, int lane, int wave) { // (lane, wave: see `tv` below)
-        if (st.ta >= t1)
-            return;
-        // (a stage may have NO rows and still own graphs: empty graphs behind a graph that ends on the
-        // tile edge -- their boundaries are still needed by the pooling phase)
-        char *base = smem + (size_t)bb * in_b;
-        dma_dwords_u(x + (size_t)st.nb * f0, base, st.rows * f0, wave, lane, G2_NW);
-        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
-        const int rbytes = st.rows * 32;
-        if (wave * 1024 + lane * 16 < rbytes) // <= 48 rows * 32 B = 1.5 KiB: waves 0 and 1
-            dma16_to_lds_u(grec + wave * 1024 + lane * 16, base + xs_b + wave * 1024);
-        if (wave == 2 && lane < st.rows)
-            dma4_to_lds_u(dinv + st.nb + lane, base + xs_b + G2_CAP * 32);
-        // graph boundaries of the stage for the pooling phase (first 64 graphs; more only if empty
-        // graphs pile up, those are read from global memory)
-        const int ng = min(st.gb - st.ga, 64) + 1;
-        if (wave == 3 && lane < ng)
-            dma4_to_lds_u(node_ptr + st.ga + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4);
-        if (wave == 4 && lane + 64 < ng)
-            dma4_to_lds_u(node_ptr + st.ga + 64 + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4 + 256);
-    };
-
     const int P1 = 16 < (h0 >> 2) ? 16 : (h0 >> 2); // swizzle period of A1 (h0/4 chunks per row, power of two)
     const int nv1 = h0 >> 2;                         // float4 chunks per H row consumed by layer 1
     const int Pb1 = 16 < (h0 >> 3) ? 16 : (h0 >> 3); // swizzle period of the bf16 planes (h0/8 chunks per row)
@@ -3114,8 +3121,6 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 #else
 #define G2_PT(i) do { } while (0)
 #endif
-    G2Stage cur = plan(t0);
-    issue(cur, 0, lane, wave);
     int b = 0;
     int stores_behind_dma = 0; // wave-uniform: store INSTRUCTIONS this wave issued since its last DMA issue
     while (cur.ta < t1) {
