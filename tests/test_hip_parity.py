@@ -462,3 +462,38 @@ def test_fused_gcn_stack_bf16x6_math_is_fp32_equivalent(dev, fin, h0, h1, act):
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.abs(split - ref).max() < TOL and np.abs(exact - ref).max() < TOL
     assert np.abs(split - exact).max() < 4e-6 * scale, np.abs(split - exact).max()
+
+
+def _random_graphs(rng, count, n_max, fin, dense):
+    """Arbitrary directed multigraphs: empty graphs, isolated nodes, self loops, repeated edges, hubs."""
+    graphs = []
+    for _ in range(count):
+        n = int(rng.integers(0, n_max + 1))
+        if n == 0:
+            graphs.append((np.zeros((0, fin), np.float32), np.zeros((0, 2), np.int32)))
+            continue
+        e = int(rng.integers(0, dense * n + 1))
+        src = rng.integers(0, n, e)
+        dst = rng.integers(0, n, e) if rng.random() < 0.7 else np.full(e, rng.integers(0, n))  # sometimes one hub takes it all
+        graphs.append((rng.uniform(-1, 1, (n, fin)).astype(np.float32), np.stack([src, dst], 1).astype(np.int32)))
+    return graphs
+
+
+@pytest.mark.parametrize("conv,layers,n_max,promise", [("gcn", 2, 33, 33), ("gcn", 2, 33, 0), ("gcn", 3, 90, 0), ("gin", 2, 70, 0),
+                                                       ("sage", 2, 70, 0), ("pna", 2, 40, 0)])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_multigraphs_match_oracle(dev, conv, layers, n_max, promise, seed):
+    """Randomised structure sweep (nothing molecule-like about it): in-degrees far above the four inline
+    neighbour slots, self loops, duplicate edges, empty graphs anywhere in the batch -- every conv family,
+    the fused GCN stack (promise = 33, its largest admissible graph) and the layer-by-layer path."""
+    rng = np.random.default_rng(100 * seed + layers + n_max)
+    fin = int(rng.integers(3, 20))
+    model = make_model(conv, in_dim=fin, hidden=64, layers=layers, out_dim=64, act="relu", pools=("add", "mean", "max"), task_out=5)
+    batch = pack_graphs(_random_graphs(rng, 120, n_max, fin, dense=4))
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
+    got = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    cm.check()
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < TOL * scale, (np.abs(got - ref).max(), scale)
