@@ -105,6 +105,53 @@ def pack_graphs(graphs: Sequence[Tuple[np.ndarray, np.ndarray]]) -> GraphBatch:
     )
 
 
+def from_pyg_batch(x, edge_index, batch=None, ptr=None, num_graphs=None) -> GraphBatch:
+    """Adapter for a PyG-style mini-batch (``torch_geometric.data.Batch`` attributes, passed as arrays
+    or tensors so that PyG itself is not needed): ``x`` [N, F], ``edge_index`` [2, E] with batch-global
+    node ids, and either ``batch`` [N] (graph id of every node, non-decreasing -- what ``Batch.batch``
+    holds) or ``ptr`` [B+1] (``Batch.ptr``).  Edges may come in any order; they are grouped by graph
+    with a STABLE sort, so the per-destination neighbour order -- hence the floating-point sum order
+    of the aggregation -- is the one the reference's per-graph ``edge_index`` would give
+    (reference code_gen.py:262 writes ``edge_index.T`` per graph)."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+    ei = np.asarray(edge_index)
+    if ei.ndim != 2 or ei.shape[0] != 2:
+        raise ValueError("edge_index must be [2, E]")
+    ei = ei.astype(np.int64)
+    N = x.shape[0]
+    if ptr is not None:
+        node_ptr = np.asarray(ptr, dtype=np.int64)
+        if node_ptr.ndim != 1 or node_ptr.size < 1 or node_ptr[0] != 0 or node_ptr[-1] != N or np.any(np.diff(node_ptr) < 0):
+            raise ValueError("ptr must be non-decreasing, start at 0 and end at the number of nodes")
+    else:
+        if batch is None:
+            batch = np.zeros(N, dtype=np.int64)
+        batch = np.asarray(batch, dtype=np.int64)
+        if batch.shape != (N,):
+            raise ValueError("batch must hold one graph id per node")
+        if N and (np.any(np.diff(batch) < 0) or batch[0] < 0):
+            raise ValueError("batch must be non-decreasing (nodes grouped by graph)")
+        B = int(num_graphs) if num_graphs is not None else (int(batch[-1]) + 1 if N else 0)
+        if N and int(batch[-1]) >= B:
+            raise ValueError("num_graphs is smaller than the largest graph id")
+        node_ptr = np.zeros(B + 1, dtype=np.int64)
+        np.add.at(node_ptr, batch + 1, 1)
+        np.cumsum(node_ptr, out=node_ptr)
+    B = node_ptr.size - 1
+    if ei.size and (ei.min() < 0 or ei.max() >= N):
+        raise ValueError("edge endpoint outside the batch")
+    g_src = np.searchsorted(node_ptr, ei[0], side="right") - 1
+    g_dst = np.searchsorted(node_ptr, ei[1], side="right") - 1
+    if np.any(g_src != g_dst):
+        raise ValueError("an edge joins two different graphs")
+    order = np.argsort(g_dst, kind="stable")
+    coo = np.ascontiguousarray(ei[:, order].T).astype(np.int32)
+    edge_ptr = np.zeros(B + 1, dtype=np.int64)
+    np.add.at(edge_ptr, g_dst + 1, 1)
+    np.cumsum(edge_ptr, out=edge_ptr)
+    return GraphBatch(x=x, coo=coo.reshape(-1, 2), node_ptr=node_ptr.astype(np.int32), edge_ptr=edge_ptr.astype(np.int32))
+
+
 def shard_bounds(node_ptr: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
     """Contiguous graph ranges per rank, cut on the cumulative NODE count so every GPU gets
     ~N_tot/world_size nodes; graphs are never split."""

@@ -72,3 +72,36 @@ def test_synthetic_shapes_follow_the_survey_recipe():
     fwd = set(map(tuple, b.coo.tolist()))
     assert all((t, s) in fwd for s, t in list(fwd)[:500])
     assert np.array_equal(synthetic.make_batch("qm9", 50, 7).coo, synthetic.make_batch("qm9", 50, 7).coo)
+
+
+def test_from_pyg_batch_groups_edges_stably_and_matches_pack_graphs():
+    """A PyG ``Batch`` (x, edge_index with global ids, batch vector or ptr) becomes the same GraphBatch
+    that packing the graphs one by one gives -- also when the edges arrive shuffled across graphs
+    (the stable grouping keeps each graph's own edge order, i.e. the aggregation's sum order)."""
+    from gnnbuilder_amd.batching import from_pyg_batch
+
+    ref = synthetic.make_batch("esol", 40, seed=4)
+    batch_vec = np.repeat(np.arange(ref.num_graphs), np.diff(ref.node_ptr))
+    got = from_pyg_batch(ref.x, ref.coo.T, batch=batch_vec)
+    for a, b in ((got.x, ref.x), (got.coo, ref.coo), (got.node_ptr, ref.node_ptr), (got.edge_ptr, ref.edge_ptr)):
+        assert np.array_equal(a, b)
+    got.validate()
+    # interleave the edges of different graphs, keeping every graph's internal order
+    rng = np.random.default_rng(0)
+    keys = np.repeat(np.arange(ref.num_graphs), np.diff(ref.edge_ptr)) + rng.uniform(0, 5, ref.num_edges)
+    perm = np.argsort(keys, kind="stable")
+    within = np.repeat(np.arange(ref.num_graphs), np.diff(ref.edge_ptr))[perm]
+    assert np.any(np.diff(within) < 0)  # really interleaved
+    again = from_pyg_batch(ref.x, ref.coo[perm].T, ptr=ref.node_ptr)
+    assert np.array_equal(again.edge_ptr, ref.edge_ptr)
+    for g in range(ref.num_graphs):  # same edges per graph, each graph's relative order preserved
+        assert np.array_equal(again.graph(g)[1], ref.coo[perm][within == g] - ref.node_ptr[g])
+    # trailing empty graphs need num_graphs; ptr carries them by itself
+    tail = from_pyg_batch(ref.x, ref.coo.T, batch=batch_vec, num_graphs=ref.num_graphs + 2)
+    assert tail.num_graphs == ref.num_graphs + 2 and tail.node_ptr[-1] == ref.num_nodes
+    with pytest.raises(ValueError):
+        bad = ref.coo.copy()
+        bad[0, 0] = ref.num_nodes - 1  # joins graph 0 and the last graph
+        from_pyg_batch(ref.x, bad.T, batch=batch_vec)
+    with pytest.raises(ValueError):
+        from_pyg_batch(ref.x, ref.coo.T, batch=batch_vec[::-1])

@@ -107,3 +107,19 @@ def test_constructor_validation_matches_the_reference():
         p.run_vitis_hls_synthesis()
     with pytest.raises(Exception, match="does not exist"):
         gnnb.Project("never_generated", model, "regression", None, "/tmp/gnnb_nowhere").build_and_run_testbench()
+
+
+def test_tb_data_reader_round_trips_what_the_writer_wrote(project):
+    """``load_tb_data`` reads the reference's on-disk layout back into the batched form
+    (graphs in dataset_info.txt order) together with the golden outputs."""
+    from gnnbuilder_amd.data import load_tb_data
+
+    batch, golden, indices = load_tb_data(project.model_dir / "tb_data", num_features=9, out_dim=1)
+    assert indices == [0, 1, 2, 3, 4] and batch.num_graphs == 5
+    batch.validate()
+    for k, idx in enumerate(indices):
+        g = project.dataset[idx]
+        x, coo = batch.graph(k)
+        assert np.array_equal(x, g.x.numpy()) and np.array_equal(coo, g.edge_index.T.numpy())
+        with torch.no_grad():
+            assert np.array_equal(golden[k], project.model(g.x, g.edge_index).view(-1).numpy())
