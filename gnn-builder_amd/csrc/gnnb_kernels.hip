@@ -2763,7 +2763,7 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
 //   DMA   raw x rows + node records + dinv of the NEXT stage -> LDS (global_load_lds, double-buffered)
 //   P0    A0 = gcn-aggregate(x)            LDS -> LDS   (width F0, all 256 threads)
 //   M0    H  = act(A0 . W0^T + b0)         MFMA 16x16x4, W0 slice in registers -> LDS
-//   P1    A1 = gcn-aggregate(H)            LDS -> LDS   (lane group per row, XOR-swizzled destination)
+//   P1    A1 = gcn-aggregate(H)            LDS -> LDS   (lane group per row, padded destination rows)
 //   M1    H  = act(A1 . W1^T + b1)         MFMA, W1 slice (32 cols x K) in registers -> LDS
 //   PL    pooled[g] = add|mean|max over the rows of each graph of the stage -> HBM
 // HBM traffic = x + tables in, [B, np*d] out: ~5 MB instead of ~270 MB at C2; the kernel is bound by
@@ -2883,7 +2883,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v)
 // eight k values, XOR-swizzled by row), the wave's W1 slice as three register sets.  Lane (li, lg) of a
 // 16x16x32 MFMA holds k = 32 kb + 8 lg .. + 7 of row / column li for both operands.
 template <int ACT, int KB, int NU>
-__device__ __forceinline__ void g2_mma_bf6(const char *__restrict__ planes, int plane_bytes, int row_bytes, int Pb,
+__device__ __forceinline__ void g2_mma_bf6(const char *__restrict__ planes, int plane_bytes, int row_bytes,
                                            const u32x4 (&wh)[KB], const u32x4 (&wm)[KB], const u32x4 (&wl)[KB],
                                            float bias, int li, int lg, float (&v)[NU][4])
 {
@@ -2897,7 +2897,7 @@ __device__ __forceinline__ void g2_mma_bf6(const char *__restrict__ planes, int 
 #pragma unroll
         for (int k = 0; k < NU; k++) {
             const int row = k * 16 + li;
-            const int off = row * row_bytes + (((4 * kb + lg) ^ (row & (Pb - 1))) << 4);
+            const int off = row * row_bytes + ((4 * kb + lg) << 4); // rows padded by 16 B: conflict-free without a swizzle
             ah[k] = as_bf16x8(*reinterpret_cast<const u32x4 *>(planes + off));
             am[k] = as_bf16x8(*reinterpret_cast<const u32x4 *>(planes + plane_bytes + off));
             al[k] = as_bf16x8(*reinterpret_cast<const u32x4 *>(planes + 2 * plane_bytes + off));
@@ -2957,8 +2957,13 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     // {coefficients dinv_i dinv_j, 0 past the degree} {dinv_i^2, rp0, deg, dinv_i}
     // (MATH 1: A1 is three bf16 planes [G2_CAP][h0] instead of one fp32 matrix: 1.5x the bytes)
     constexpr int KB1 = KQ1 / 2 > 0 ? KQ1 / 2 : 1; // 32-wide k blocks of layer 1 (h0 = 32, 64, 128)
-    const int plane_b = G2_CAP * h0 * 2;
-    int4 *REC = reinterpret_cast<int4 *>(reinterpret_cast<char *>(A1) + (MATH ? 3 * plane_b : G2_CAP * h0 * 4));
+    // A1 rows are padded (fp32: +4 floats, bf16 planes: +16 B) instead of XOR-swizzled: M1's fragment reads
+    // (8 lanes x 16 B per cycle, consecutive rows) then fall into distinct bank groups AND their addresses are
+    // base + immediate -- the swizzle cost two VALU operations per read, and VALU issue is what this kernel
+    // runs out of
+    const int lda1 = h0 + 4, prow_b = h0 * 2 + 16;
+    const int plane_b = G2_CAP * prow_b;
+    int4 *REC = reinterpret_cast<int4 *>(reinterpret_cast<char *>(A1) + (MATH ? 3 * plane_b : G2_CAP * lda1 * 4));
     int32_t *stile = reinterpret_cast<int32_t *>(REC + 3 * G2_CAP);
     int32_t *sgraph = stile + (G2_TCAP + 1);
 
@@ -3105,9 +3110,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     asm volatile("" : "+v"(bias0), "+v"(bias1));
     __syncthreads();
 
-    const int P1 = 16 < (h0 >> 2) ? 16 : (h0 >> 2); // swizzle period of A1 (h0/4 chunks per row, power of two)
     const int nv1 = h0 >> 2;                         // float4 chunks per H row consumed by layer 1
-    const int Pb1 = 16 < (h0 >> 3) ? 16 : (h0 >> 3); // swizzle period of the bf16 planes (h0/8 chunks per row)
     int glog2 = 2;
     while ((1 << glog2) < nv1 && glog2 < 6)
         glog2++;
@@ -3219,7 +3222,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         G2_PT(5);
 
         // ---- P1: A1 = gcn-aggregate(H), one lane group of h0/4 lanes per row (a float4 chunk each),
-        // destination XOR-swizzled for M1's fragment reads.  Offsets and coefficients come ready-made from
+        // destination rows padded for M1's fragment reads.  Offsets and coefficients come ready-made from
         // REC; the next pass's record is fetched while this pass's rows are in flight.  (VALU instructions
         // are what bounds this kernel: row-level scalars must not be recomputed by all lanes of a group.)
         {
@@ -3266,12 +3269,12 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                     split3(accA.v.y, hh[1], mm[1], ll[1]);
                     split3(accA.v.z, hh[2], mm[2], ll[2]);
                     split3(accA.v.w, hh[3], mm[3], ll[3]);
-                    char *dstp = reinterpret_cast<char *>(A1) + rA * (h0 * 2) + (((gl >> 1) ^ (rA & (Pb1 - 1))) << 4) + (gl & 1) * 8;
+                    char *dstp = reinterpret_cast<char *>(A1) + rA * prow_b + gl * 8;
                     *reinterpret_cast<uint2 *>(dstp) = make_uint2(pack_hi16(hh[0], hh[1]), pack_hi16(hh[2], hh[3]));
                     *reinterpret_cast<uint2 *>(dstp + plane_b) = make_uint2(pack_hi16(mm[0], mm[1]), pack_hi16(mm[2], mm[3]));
                     *reinterpret_cast<uint2 *>(dstp + 2 * plane_b) = make_uint2(pack_hi16(ll[0], ll[1]), pack_hi16(ll[2], ll[3]));
                 } else {
-                    accA.store(A1 + rA * h0 + ((gl ^ (rA & (P1 - 1))) << 2));
+                    accA.store(A1 + rA * lda1 + gl * 4);
                 }
             }
         }
@@ -3289,9 +3292,9 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 constexpr int NU = decltype(nutag)::value;
                 float v[NU][4];
                 if (MATH)
-                    g2_mma_bf6<ACT, KB1, NU>(reinterpret_cast<const char *>(A1), plane_b, h0 * 2, Pb1, wh, wm, wl, bias1, li, lg, v);
+                    g2_mma_bf6<ACT, KB1, NU>(reinterpret_cast<const char *>(A1), plane_b, prow_b, wh, wm, wl, bias1, li, lg, v);
                 else
-                    g2_mma<ACT, KQ1, NU, true>(A1, h0, P1, w1r, bias1, 0, 1, li, lg, v);
+                    g2_mma<ACT, KQ1, NU, false>(A1, lda1, 1, w1r, bias1, 0, 1, li, lg, v);
                 const int ngr = cur.gb - cur.ga;
                 // (one store instruction per graph and pool; none if the whole slice is past h1; the rare
                 // paths below that read global memory only make the count conservative -- see the wait)
@@ -3388,7 +3391,7 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     const int in_b = xs_b + G2_CAP * 32 + G2_CAP * 4 + 272;
     const int ldh = (h0 > h1 ? h0 : h1) + 4;
     const size_t lds = 2 * (size_t)in_b + (size_t)G2_CAP * 16 * (f0 <= 16 ? 1 : 2) * 4 + (size_t)G2_CAP * ldh * 4 +
-                       (size_t)G2_CAP * h0 * (math ? 6 : 4) + (size_t)G2_CAP * 48 + 2 * (size_t)(G2_TCAP + 1) * 4;
+                       (size_t)G2_CAP * (math ? 3 * (h0 * 2 + 16) : (h0 + 4) * 4) + (size_t)G2_CAP * 48 + 2 * (size_t)(G2_TCAP + 1) * 4;
     const int kq0 = f0 <= 16 ? 1 : 2, kq1 = h0 / 16;
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
     hipError_t rc = hipErrorNotSupported;
