@@ -2826,14 +2826,23 @@ __device__ __forceinline__ void g2_mma(const float *__restrict__ Asrc, int lda, 
 #pragma unroll
     for (int a = 0; a < NA; a++)
         acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto frag = [&](int q, int k) {
+        const int row = (rg + k * nrg) * 16 + li;
+        const int c = 4 * q + lg;
+        return *reinterpret_cast<const float4 *>(Asrc + row * lda + ((SWZ ? (c ^ (row & (P - 1))) : c) << 2));
+    };
+    // software pipeline: the fragments of k block q+1 are requested before the MFMAs of block q are issued,
+    // so a wave's own LDS latency hides behind its own matrix work
+    float4 a4[NU], an[NU];
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+        a4[k] = frag(0, k);
 #pragma unroll
     for (int q = 0; q < KQ; q++) {
-        float4 a4[NU];
+        if (q + 1 < KQ) {
 #pragma unroll
-        for (int k = 0; k < NU; k++) {
-            const int row = (rg + k * nrg) * 16 + li;
-            const int c = 4 * q + lg;
-            a4[k] = *reinterpret_cast<const float4 *>(Asrc + row * lda + ((SWZ ? (c ^ (row & (P - 1))) : c) << 2));
+            for (int k = 0; k < NU; k++)
+                an[k] = frag(q + 1, k);
         }
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -2843,6 +2852,11 @@ __device__ __forceinline__ void g2_mma(const float *__restrict__ Asrc, int lda, 
                 const int ai = NU == 1 ? (t & 1) : k;
                 acc[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[q * 4 + t], acc[ai], 0, 0, 0);
             }
+        if (q + 1 < KQ) {
+#pragma unroll
+            for (int k = 0; k < NU; k++)
+                a4[k] = an[k];
+        }
     }
 #pragma unroll
     for (int k = 0; k < NU; k++)
