@@ -376,7 +376,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         alg_bytes, agg = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev)
         gather = {
-            "kernel": "k_aggregate_stream<GCN> (gather-aggregate, width %d)" % w["hidden"],
+            "kernel": "k_aggregate_shot<GCN> (gather-aggregate, width %d)" % w["hidden"],
             "bound": "hbm", "achieved": agg["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic("aggregate"),
             "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": agg["hbm"]["us"],

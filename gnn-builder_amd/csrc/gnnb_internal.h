@@ -34,8 +34,9 @@ struct Options {
     int agg_lds_kb;   // LDS budget per aggregate workgroup
     int agg_tiles_per_wg;
     int agg_overshoot; // LDS rows reserved for the graph that straddles a tile's end
-    int agg_variant;   // 0 = CSR-streamed gather (default), 1 = LDS-staged small tiles,
-                       // 2 = pipelined LDS-DMA, 3 = record-streamed, 4 = LDS-DMA single burst
+    int agg_variant;   // 0 = CSR-streamed gather, 1 = LDS-staged small tiles, 2 = pipelined LDS-DMA (loader wave),
+                       // 3 = record-streamed, 4 = LDS-DMA single burst, 5 = pipelined LDS-DMA (untracked, counted
+                       // waits), 6 = one-shot LDS-DMA per tile group + node records (default)
     int agg_rows_per_wg; // streaming variant: destination rows per workgroup
     int agg_xcd_remap; // remap block ids so each XCD owns a contiguous run of row chunks
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel

@@ -1084,6 +1084,19 @@ __device__ inline void dma_dwords_u(const void *g, void *l, int count, int wave,
             dma4_to_lds_u(gs + (size_t)(c + lane) * 4, ls + (size_t)c * 4);
 }
 __device__ inline void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate
+__device__ __forceinline__ void vmcnt_wait_upto(int n)
+{
+    switch (__builtin_amdgcn_readfirstlane(n)) { // scalar branch
+
+#define GNNB_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    GNNB_VMW(1) GNNB_VMW(2) GNNB_VMW(3) GNNB_VMW(4) GNNB_VMW(5) GNNB_VMW(6) GNNB_VMW(7) GNNB_VMW(8) GNNB_VMW(9)
+    GNNB_VMW(10) GNNB_VMW(11) GNNB_VMW(12) GNNB_VMW(13) GNNB_VMW(14) GNNB_VMW(15) GNNB_VMW(16) GNNB_VMW(17) GNNB_VMW(18)
+#undef GNNB_VMW
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 
 template <int MODE, int VEC>
 __global__ __launch_bounds__(WG) void k_aggregate_dma(
@@ -1575,6 +1588,355 @@ static hipError_t launch_aggregate_pipe_t(const BatchTables &t, const float *x, 
     return hipGetLastError();
 }
 
+// -------------------------------------------------------------------------------------
+// LDS-staged pipelined variant, second take (variant 5).  Same idea as variant 2 -- persistent
+// workgroups, every feature row crosses the CU's memory port ONCE (LDS-DMA), neighbours are gathered
+// from LDS -- rebuilt on what the fused GCN kernel taught: the DMA is issued from inline
+// asm by ALL waves (the builtin makes the compiler put s_waitcnt vmcnt(0) in front of every later
+// ds_read, which is why variant 2 needed a dedicated loader wave), one raw barrier per stage, and a
+// COUNTED vmcnt wait at the stage top so that the previous stage's output stores stay in flight.
+template <int MODE, int VEC>
+__global__ __launch_bounds__(WG) void k_aggregate_lds(
+    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
+    const int4 *__restrict__ node_rec, const int32_t *__restrict__ row_ptr,
+    const int32_t *__restrict__ col, const float *__restrict__ dinv,
+    const int32_t *__restrict__ tile_first, int num_tiles, int w, int glog2, int rows_cap, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // one buffer = [rows_cap*w floats | rows_cap*2 int4 | rows_cap floats]
+    const size_t buf_bytes = ((size_t)rows_cap * w * 4 + (size_t)rows_cap * 32 + (size_t)rows_cap * 4 + 15) & ~(size_t)15;
+    int32_t *stile = reinterpret_cast<int32_t *>(smem + 2 * buf_bytes); // [PIPE_TCAP + 1]
+    typedef Vf<VEC> V;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
+    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    if (t1 <= t0)
+        return;
+    for (int i = tid; i <= t1 - t0; i += WG)
+        stile[i] = tile_first[t0 + i];
+    __syncthreads();
+
+    auto plan = [&](int ta) {
+        PipeStage st;
+        st.ta = ta;
+        st.tb = ta;
+        st.nb = 0;
+        st.rows = 0;
+        st.staged = true;
+        if (ta >= t1)
+            return st;
+        st.nb = stile[ta - t0];
+        int tb = ta + 1;
+        while (tb < t1 && stile[tb + 1 - t0] - st.nb <= rows_cap) // whole tiles while they fit one buffer
+            tb++;
+        st.tb = tb;
+        st.rows = stile[tb - t0] - st.nb;
+        st.staged = st.rows <= rows_cap; // a single tile larger than the buffer: direct path
+        return st;
+    };
+    auto issue = [&](const PipeStage &st, int b) {
+        if (!st.staged || st.rows <= 0)
+            return;
+        char *base = smem + (size_t)b * buf_bytes;
+        char *lrec = base + (size_t)rows_cap * w * 4;
+        char *ldinv = lrec + (size_t)rows_cap * 32;
+        const char *gx = reinterpret_cast<const char *>(x + (size_t)st.nb * w);
+        const int bytes = st.rows * w * 4;
+        if (VEC == 4) {
+            for (int c = wave * 1024; c < bytes; c += (WG / 64) * 1024)
+                if (c + lane * 16 < bytes)
+                    dma16_to_lds_u(gx + c + lane * 16, base + c);
+        } else {
+            dma_dwords_u(gx, base, st.rows * w, wave, lane, WG / 64);
+        }
+        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
+        const int rbytes = st.rows * 32;
+        for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
+            if (c + lane * 16 < rbytes)
+                dma16_to_lds_u(grec + c + lane * 16, lrec + c);
+        if (MODE == GNNB_AGG_GCN)
+            dma_dwords_u(dinv + st.nb, ldinv, st.rows, wave, lane, WG / 64);
+    };
+
+    const int nvec = w / VEC;
+    const int G = 1 << glog2;
+    const int groups = WG >> glog2;
+    const int grp = tid >> glog2;
+    const int gl = tid & (G - 1);
+    const int gpw = 64 >> glog2 > 0 ? 64 >> glog2 : 1; // lane groups per wave
+    const int stores_per_row = (MODE == GNNB_AGG_PNA ? 4 : 1) * ((nvec + G - 1) / G);
+
+    PipeStage cur = plan(t0);
+    issue(cur, 0);
+    int b = 0, stores_behind_dma = 0;
+    while (cur.ta < t1) {
+        const PipeStage nxt = plan(cur.tb);
+        // stage `cur` has landed; the output stores issued after its DMA may stay in flight
+        vmcnt_wait_upto(stores_behind_dma);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // ... for everyone; the other buffer is free
+        issue(nxt, b ^ 1);
+        stores_behind_dma = 0;
+        if (cur.staged) {
+            const char *base = smem + (size_t)b * buf_bytes;
+            const float *sx = reinterpret_cast<const float *>(base);
+            const int4 *srec = reinterpret_cast<const int4 *>(base + (size_t)rows_cap * w * 4);
+            const float *sdinv = reinterpret_cast<const float *>(base + (size_t)rows_cap * w * 4 + (size_t)rows_cap * 32);
+            for (int r = grp; r < cur.rows; r += 2 * groups) {
+                for (int f = gl; f < nvec; f += G) {
+                    const int fo = f * VEC;
+                    LdsRow<MODE, VEC> A, B;
+                    A.begin(true, cur.nb, r, sx, srec, sdinv, selfq, w, fo);
+                    B.begin(r + groups < cur.rows, cur.nb, r + groups, sx, srec, sdinv, selfq, w, fo);
+                    A.finish(cur.nb, sx, sdinv, col, out, w, fo, eps);
+                    B.finish(cur.nb, sx, sdinv, col, out, w, fo, eps);
+                }
+            }
+            // store instructions this WAVE issued (exact, or the counted wait above would be unsafe): its
+            // first lane group makes the most loop trips; row A stores in every trip, row B when it exists
+            const int g0 = wave * gpw;
+            int cnt = 0;
+            for (int r = g0; r < cur.rows; r += 2 * groups)
+                cnt += stores_per_row * (1 + (r + groups < cur.rows ? 1 : 0));
+            stores_behind_dma = (MODE == GNNB_AGG_PNA || VEC != 4) ? (1 << 20) : cnt; // (PNA reads q_i from global memory in between)
+        } else {
+            stores_behind_dma = 1 << 20;
+            // a graph larger than the LDS buffer: same arithmetic straight from global memory
+            for (int r = grp; r < cur.rows; r += groups) {
+                const int node = cur.nb + r;
+                const int rp0 = row_ptr[node], rp1 = row_ptr[node + 1];
+                const int deg = rp1 - rp0;
+                const float di = (MODE == GNNB_AGG_GCN) ? dinv[node] : 0.0f;
+                for (int f = gl; f < nvec; f += G) {
+                    const int fo = f * VEC;
+                    const V xi = V::load((MODE == GNNB_AGG_PNA ? selfq : x) + (size_t)node * w + fo);
+                    V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
+                    for (int k = rp0; k < rp1; k++) {
+                        const int j = col[k];
+                        const V xj = V::load(x + (size_t)j * w + fo);
+                        if (MODE == GNNB_AGG_GCN) {
+                            acc = vadd(acc, vmul(xj, V::splat(di * dinv[j])));
+                        } else if (MODE == GNNB_AGG_PNA) {
+                            const V h = vadd(xi, xj);
+                            vmx = (k == rp0) ? h : vmax(vmx, h);
+                            vmn = (k == rp0) ? h : vmin(vmn, h);
+                            acc = vadd(acc, h);
+                            s2 = vadd(s2, vmul(h, h));
+                        } else {
+                            acc = vadd(acc, xj);
+                        }
+                    }
+                    if (MODE == GNNB_AGG_GCN) {
+                        vadd(acc, vmul(xi, V::splat(di * di))).store(out + (size_t)node * w + fo);
+                    } else if (MODE == GNNB_AGG_SUM) {
+                        vadd(acc, vmul(xi, V::splat(1.0f + eps))).store(out + (size_t)node * w + fo);
+                    } else if (MODE == GNNB_AGG_MEAN) {
+                        (deg > 0 ? vdiv(acc, V::splat((float)deg)) : acc).store(out + (size_t)node * w + fo);
+                    } else {
+                        V mean = V::splat(0.0f), sd = V::splat(0.0f);
+                        if (deg > 0) {
+                            mean = vdiv(acc, V::splat((float)deg));
+                            sd = pyg_std(vdiv(s2, V::splat((float)deg)), mean);
+                        }
+                        float *o = out + (size_t)node * 4 * w + fo;
+                        vmx.store(o);
+                        vmn.store(o + w);
+                        mean.store(o + 2 * (size_t)w);
+                        sd.store(o + 3 * (size_t)w);
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        b ^= 1;
+    }
+}
+
+template <int MODE, int VEC>
+static hipError_t launch_aggregate_lds_t(const BatchTables &t, const float *x, const float *selfq,
+                                         float *out, int w, float eps, hipStream_t s)
+{
+    const Options &o = options();
+    const int nvec = w / VEC;
+    int glog2 = 2;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    if (t.num_tiles <= 0)
+        return hipSuccess;
+    const size_t budget = (size_t)o.agg_lds_kb * 1024;
+    const size_t per_row = (size_t)w * 4 + 32 + 4;
+    int rows_cap = (int)((budget - (PIPE_TCAP + 1) * 4 - 64) / 2 / per_row) & ~3;
+    if (rows_cap < 8)
+        rows_cap = 8;
+    const size_t buf_bytes = ((size_t)rows_cap * per_row + 15) & ~(size_t)15;
+    const size_t lds = 2 * buf_bytes + (PIPE_TCAP + 1) * 4;
+    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
+    long long grid = 256LL * wg_per_cu; // persistent: everything resident
+    if (grid > t.num_tiles)
+        grid = t.num_tiles;
+    const long long min_grid = ((long long)t.num_tiles + PIPE_TCAP - 2) / (PIPE_TCAP - 1);
+    if (grid < min_grid)
+        grid = min_grid; // a workgroup's tile table must fit its LDS copy
+    auto kern = k_aggregate_lds<MODE, VEC>;
+    static size_t lds_allowed = 64 * 1024; // per instantiation
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, x, selfq, out, t.node_rec, t.row_ptr, t.col,
+                       t.dinv, t.tile_first, t.num_tiles, w, glog2, rows_cap, eps);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------
+// One-shot LDS-staged variant (variant 6).  A workgroup owns `tpw` consecutive node tiles (whole graphs):
+// LDS-DMA of their feature rows + node records + dinv, one barrier, reduce from LDS with two rows in
+// flight per lane group, stream the result out, exit.  No pipeline inside the workgroup: the overlap
+// comes from several short-lived workgroups per CU (LDS ~ 0.55 KB per row).  Rows that do not fit the
+// buffer (a very large graph) take the same arithmetic straight from global memory.
+template <int MODE, int VEC>
+__global__ __launch_bounds__(WG) void k_aggregate_shot(
+    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
+    const int4 *__restrict__ node_rec, const int32_t *__restrict__ row_ptr,
+    const int32_t *__restrict__ col, const float *__restrict__ dinv,
+    const int32_t *__restrict__ tile_first, int num_tiles, int tpw, int w, int glog2, int rows_cap, float eps,
+    int xcd_remap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Vf<VEC> V;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int ta = chunk * tpw, tb = min(ta + tpw, num_tiles);
+    const int nb = tile_first[ta], rows = tile_first[tb] - nb;
+    if (rows <= 0)
+        return;
+    const int nvec = w / VEC;
+    const int G = 1 << glog2;
+    const int groups = WG >> glog2;
+    const int grp = tid >> glog2;
+    const int gl = tid & (G - 1);
+    if (rows <= rows_cap) { // workgroup-uniform
+        char *lrec = smem + (size_t)rows_cap * w * 4;
+        char *ldinv = lrec + (size_t)rows_cap * 32;
+        const char *gx = reinterpret_cast<const char *>(x + (size_t)nb * w);
+        const int bytes = rows * w * 4;
+        if (VEC == 4) {
+            for (int c = wave * 1024; c < bytes; c += (WG / 64) * 1024)
+                if (c + lane * 16 < bytes)
+                    dma16_to_lds_u(gx + c + lane * 16, smem + c);
+        } else {
+            dma_dwords_u(gx, smem, rows * w, wave, lane, WG / 64);
+        }
+        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)nb);
+        const int rbytes = rows * 32;
+        for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
+            if (c + lane * 16 < rbytes)
+                dma16_to_lds_u(grec + c + lane * 16, lrec + c);
+        if (MODE == GNNB_AGG_GCN)
+            dma_dwords_u(dinv + nb, ldinv, rows, wave, lane, WG / 64);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const float *sx = reinterpret_cast<const float *>(smem);
+        const int4 *srec = reinterpret_cast<const int4 *>(lrec);
+        const float *sdinv = reinterpret_cast<const float *>(ldinv);
+        for (int r = grp; r < rows; r += 2 * groups) {
+            for (int f = gl; f < nvec; f += G) {
+                const int fo = f * VEC;
+                LdsRow<MODE, VEC> A, B;
+                A.begin(true, nb, r, sx, srec, sdinv, selfq, w, fo);
+                B.begin(r + groups < rows, nb, r + groups, sx, srec, sdinv, selfq, w, fo);
+                A.finish(nb, sx, sdinv, col, out, w, fo, eps);
+                B.finish(nb, sx, sdinv, col, out, w, fo, eps);
+            }
+        }
+        return;
+    }
+    // a graph larger than the LDS buffer: straight from global memory
+    for (int r = grp; r < rows; r += groups) {
+        const int node = nb + r;
+        const int rp0 = row_ptr[node], rp1 = row_ptr[node + 1];
+        const int deg = rp1 - rp0;
+        const float di = (MODE == GNNB_AGG_GCN) ? dinv[node] : 0.0f;
+        for (int f = gl; f < nvec; f += G) {
+            const int fo = f * VEC;
+            const V xi = V::load((MODE == GNNB_AGG_PNA ? selfq : x) + (size_t)node * w + fo);
+            V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
+            for (int k = rp0; k < rp1; k++) {
+                const int j = col[k];
+                const V xj = V::load(x + (size_t)j * w + fo);
+                if (MODE == GNNB_AGG_GCN) {
+                    acc = vadd(acc, vmul(xj, V::splat(di * dinv[j])));
+                } else if (MODE == GNNB_AGG_PNA) {
+                    const V h = vadd(xi, xj);
+                    vmx = (k == rp0) ? h : vmax(vmx, h);
+                    vmn = (k == rp0) ? h : vmin(vmn, h);
+                    acc = vadd(acc, h);
+                    s2 = vadd(s2, vmul(h, h));
+                } else {
+                    acc = vadd(acc, xj);
+                }
+            }
+            if (MODE == GNNB_AGG_GCN) {
+                vadd(acc, vmul(xi, V::splat(di * di))).store(out + (size_t)node * w + fo);
+            } else if (MODE == GNNB_AGG_SUM) {
+                vadd(acc, vmul(xi, V::splat(1.0f + eps))).store(out + (size_t)node * w + fo);
+            } else if (MODE == GNNB_AGG_MEAN) {
+                (deg > 0 ? vdiv(acc, V::splat((float)deg)) : acc).store(out + (size_t)node * w + fo);
+            } else {
+                V mean = V::splat(0.0f), sd = V::splat(0.0f);
+                if (deg > 0) {
+                    mean = vdiv(acc, V::splat((float)deg));
+                    sd = pyg_std(vdiv(s2, V::splat((float)deg)), mean);
+                }
+                float *o = out + (size_t)node * 4 * w + fo;
+                vmx.store(o);
+                vmn.store(o + w);
+                mean.store(o + 2 * (size_t)w);
+                sd.store(o + 3 * (size_t)w);
+            }
+        }
+    }
+}
+
+template <int MODE, int VEC>
+static hipError_t launch_aggregate_shot_t(const BatchTables &t, const float *x, const float *selfq,
+                                          float *out, int w, float eps, hipStream_t s)
+{
+    const Options &o = options();
+    const int nvec = w / VEC;
+    int glog2 = 2;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    if (t.num_tiles <= 0)
+        return hipSuccess;
+    const int tpw = o.agg_tiles_per_wg > 0 ? o.agg_tiles_per_wg : 1;
+    const size_t per_row = (size_t)w * 4 + 32 + 4;
+    // rows of tpw tiles: <= tpw * tile_rows + (largest graph - 1); sized for molecule-scale graphs inside the
+    // LDS budget, anything larger takes the direct path
+    int rows_cap = (int)(((size_t)o.agg_lds_kb * 1024) / per_row) & ~3;
+    // with the caller's promise on the largest graph the buffer is sized exactly (more workgroups per CU)
+    if (t.max_graph_nodes_hint > 0)
+        rows_cap = std::min(rows_cap, (tpw * t.tile_rows + t.max_graph_nodes_hint - 1 + 3) & ~3);
+    if (rows_cap < 8)
+        rows_cap = 8;
+    const size_t lds = (((size_t)rows_cap * per_row) + 15) & ~(size_t)15;
+    const int grid = (t.num_tiles + tpw - 1) / tpw;
+    auto kern = k_aggregate_shot<MODE, VEC>;
+    static size_t lds_allowed = 64 * 1024; // per instantiation
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), lds, s, x, selfq, out, t.node_rec, t.row_ptr, t.col, t.dinv,
+                       t.tile_first, t.num_tiles, tpw, w, glog2, rows_cap, eps, 0 /* every row is fetched once: nothing to gain from an XCD remap */);
+    return hipGetLastError();
+}
+
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s)
 {
@@ -1584,8 +1946,16 @@ hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, cons
     const bool rec = options().agg_variant == 3;
     const bool dma = options().agg_variant == 4;
     const bool pipe = options().agg_variant == 2;
+    const bool lds5 = options().agg_variant == 5;
+    const bool shot = options().agg_variant == 6;
 #define GNNB_AGG_CASE(K)                                                                         \
     case K:                                                                                      \
+        if (shot)                                                                                \
+            return v4 ? launch_aggregate_shot_t<K, 4>(t, x, selfq, out, width, eps, s)           \
+                      : launch_aggregate_shot_t<K, 1>(t, x, selfq, out, width, eps, s);          \
+        if (lds5)                                                                                \
+            return v4 ? launch_aggregate_lds_t<K, 4>(t, x, selfq, out, width, eps, s)            \
+                      : launch_aggregate_lds_t<K, 1>(t, x, selfq, out, width, eps, s);           \
         if (pipe)                                                                                \
             return v4 ? launch_aggregate_pipe_t<K, 4>(t, x, selfq, out, width, eps, s)           \
                       : launch_aggregate_pipe_t<K, 1>(t, x, selfq, out, width, eps, s);          \
@@ -2795,19 +3165,6 @@ __device__ __forceinline__ float rows4_max(float x)
     auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
-// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate
-__device__ __forceinline__ void vmcnt_wait_upto(int n)
-{
-    switch (__builtin_amdgcn_readfirstlane(n)) { // scalar branch
-
-#define GNNB_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    GNNB_VMW(1) GNNB_VMW(2) GNNB_VMW(3) GNNB_VMW(4) GNNB_VMW(5) GNNB_VMW(6) GNNB_VMW(7) GNNB_VMW(8) GNNB_VMW(9)
-    GNNB_VMW(10) GNNB_VMW(11) GNNB_VMW(12) GNNB_VMW(13) GNNB_VMW(14) GNNB_VMW(15) GNNB_VMW(16) GNNB_VMW(17) GNNB_VMW(18)
-#undef GNNB_VMW
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 // Workgroup barrier of the fused kernel: LDS traffic drained, NO vector-memory drain.  __syncthreads()
 // carries a fence, for which the compiler emits s_waitcnt vmcnt(0) whenever it has stores of its own in
 // flight (the pooled outputs) -- and that would also wait for the untracked DMA of the next stage.

@@ -53,7 +53,7 @@ Options &options()
 {
     static Options o = {env_int("GNNB_TILE_ROWS", 16), env_int("GNNB_AGG_LDS_KB", 39),
                         env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32),
-                        env_int("GNNB_AGG_VARIANT", 0),      env_int("GNNB_AGG_ROWS_PER_WG", 48),
+                        env_int("GNNB_AGG_VARIANT", 6),      env_int("GNNB_AGG_ROWS_PER_WG", 48),
                         env_int("GNNB_AGG_XCD_REMAP", 1),    env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_FUSE_NARROW", 1),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
@@ -191,7 +191,7 @@ int gnnb_set_option(const char *name, int value)
         o.agg_tiles_per_wg = value;
     else if (!strcmp(name, "agg_overshoot") && value >= 0)
         o.agg_overshoot = value;
-    else if (!strcmp(name, "agg_variant") && value >= 0 && value <= 4)
+    else if (!strcmp(name, "agg_variant") && value >= 0 && value <= 6)
         o.agg_variant = value;
     else if (!strcmp(name, "agg_rows_per_wg") && value >= 8 && value <= 4096)
         o.agg_rows_per_wg = value;

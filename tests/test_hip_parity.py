@@ -288,6 +288,10 @@ AGG_OPTION_SETS = [
     dict(agg_variant=2, agg_lds_kb=150), dict(agg_variant=2, tile_rows=4),                      # pipelined LDS-DMA
     dict(agg_variant=3), dict(agg_variant=3, agg_rows_per_wg=16),                               # record-streamed
     dict(agg_variant=4), dict(agg_variant=4, agg_lds_kb=8),                                     # single-burst LDS-DMA
+    dict(agg_variant=5), dict(agg_variant=5, agg_lds_kb=8), dict(agg_variant=5, tile_rows=64),
+    dict(agg_variant=5, agg_lds_kb=150), dict(agg_variant=5, tile_rows=4),                      # LDS-staged, untracked DMA
+    dict(agg_variant=6), dict(agg_variant=6, agg_lds_kb=8), dict(agg_variant=6, tile_rows=64, agg_tiles_per_wg=2),
+    dict(agg_variant=6, agg_lds_kb=150, agg_tiles_per_wg=3), dict(agg_variant=6, tile_rows=4),  # one-shot LDS-staged
 ]
 
 
@@ -298,7 +302,7 @@ def test_tiling_options_do_not_change_results(dev, opt):
     model = make_model("pna", in_dim=9, hidden=32, layers=2, task_out=1)
     batch = synthetic.make_batch("molhiv", 64, seed=11)
     ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
-    defaults = dict(tile_rows=16, agg_tiles_per_wg=1, agg_lds_kb=39, agg_overshoot=32, agg_variant=0,
+    defaults = dict(tile_rows=16, agg_tiles_per_wg=1, agg_lds_kb=39, agg_overshoot=32, agg_variant=6,
                     agg_rows_per_wg=48)
     try:
         for k, v in opt.items():
