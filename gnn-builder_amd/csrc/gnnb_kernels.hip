@@ -2243,6 +2243,49 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GNNB_LR_COUNTED_WAIT "s_waitcnt vmcnt(" GNNB_STR(GNNB_LR_NSTORES) ") lgkmcnt(0)\n\ts_barrier"
 
 
+// ---- fp32 product through the bf16 matrix cores ("bf16x6").  x = h + m + l EXACTLY, each piece a bf16
+// (8 significant bits each: truncate, subtract, truncate, subtract -- every step is exact in fp32), so
+// a.b = sum of nine bf16 x bf16 products, each exact in fp32.  The six with i + j <= 2 are kept
+// (hh, hm, mh, hl, lh, mm); the three dropped ones are below 2^-24 |a||b|, i.e. below what fp32 resolves of
+// the product.  Accumulation is fp32 inside v_mfma_f32_16x16x32_bf16.  Cost: 6 MFMA of 4 passes per
+// 32-wide k block instead of 8 fp32 MFMA of 8 passes -- 2.4x fewer pipe cycles, and fp32 MFMA runs at
+// the vector-FMA rate on this chip (tools/micro/mfma_valu_overlap.hip).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m)); // <= 8 significant bits left: its upper half is exact
+}
+// two fp32 bit patterns -> their upper halves packed as {bf16(a) in bits 0..15, bf16(b) in bits 16..31}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v)
+{
+    union {
+        u32x4 u;
+        bf16x8 b;
+    } c;
+    c.u = v;
+    return c.b;
+}
+
+// split 8 consecutive fp32 values (two float4) into the three bf16x8 pieces of an MFMA operand
+__device__ __forceinline__ void split3x8(const float4 &f0, const float4 &f1, u32x4 &h, u32x4 &m, u32x4 &l)
+{
+    const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split3(v[2 * i], h0, m0, l0);
+        split3(v[2 * i + 1], h1, m1, l1);
+        h[i] = pack_hi16(h0, h1);
+        m[i] = pack_hi16(m0, m1);
+        l[i] = pack_hi16(l0, l1);
+    }
+}
+
 // Optional fused gather: when `rec` is set the A stage is not copied from memory but PRODUCED -- the
 // workgroup aggregates its destination rows (GCN / sum / mean semantics of k_aggregate_*) from the
 // raw feature matrix straight into the LDS stage.  Used for narrow first layers (F_in = 9, 11):
@@ -2257,8 +2300,10 @@ struct GatherDesc {
     float eps;
 };
 
-template <int KQ, bool VEC_A> // KQ = ceil(K/16) in {1,2,4,8}; VEC_A: K % 4 == 0 and 16-B aligned rows
-__global__ __launch_bounds__(WG, 3) void k_linear_reg(
+// MATH 1 (opt-in, K % 32 == 0, N % 32 == 0, plain A copy): the products go through the bf16 matrix cores as six
+// partial products of an exact 3-way split (see split3); A fragments are split in the wave after the LDS read.
+template <int KQ, bool VEC_A, int MATH = 0> // KQ = ceil(K/16) in {1,2,4,8}; VEC_A: K % 4 == 0 and 16-B aligned rows
+__global__ __launch_bounds__(WG, MATH ? 2 : 3) void k_linear_reg(
     const float *__restrict__ A, int lda, int K, const float *__restrict__ W, int ldw,
     const float *__restrict__ bias, const float *__restrict__ skip, float *__restrict__ Y, int M, int N,
     int act, int rg_log2, int P, int vec_out, GatherDesc gd)
@@ -2291,6 +2336,8 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
 
     // ---- this wave's weight slice -> registers
     float breg[2][KQ * 4];
+    constexpr int KB = KQ / 2 > 0 ? KQ / 2 : 1; // 32-wide k blocks (MATH 1)
+    u32x4 wh[2][KB], wm[2][KB], wl_[2][KB];
     // fast path (wave-uniform): the 32 x K slice is in range and 16-B aligned.  Its rows are read
     // whole (coalesced LDS-DMA) into this wave's share of the not-yet-used stage buffers and picked
     // apart into fragments from LDS; fragment-shaped global loads (16 rows x 64 B per instruction)
@@ -2310,13 +2357,22 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // own DMA, wave-private region: no barrier
+            if (MATH) { // lane (li, lg) of a 16x16x32 MFMA holds k = 32 kb + 8 lg .. + 7 of column li
 #pragma unroll
-            for (int q = 0; q < KQ; q++) {
-                const float4 v = *reinterpret_cast<const float4 *>(wl + (size_t)li * K + 16 * q + 4 * lg);
-                breg[u][q * 4 + 0] = v.x;
-                breg[u][q * 4 + 1] = v.y;
-                breg[u][q * 4 + 2] = v.z;
-                breg[u][q * 4 + 3] = v.w;
+                for (int kb = 0; kb < KB; kb++) {
+                    const float4 f0 = *reinterpret_cast<const float4 *>(wl + (size_t)li * K + 32 * kb + 8 * lg);
+                    const float4 f1 = *reinterpret_cast<const float4 *>(wl + (size_t)li * K + 32 * kb + 8 * lg + 4);
+                    split3x8(f0, f1, wh[u][kb], wm[u][kb], wl_[u][kb]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < KQ; q++) {
+                    const float4 v = *reinterpret_cast<const float4 *>(wl + (size_t)li * K + 16 * q + 4 * lg);
+                    breg[u][q * 4 + 0] = v.x;
+                    breg[u][q * 4 + 1] = v.y;
+                    breg[u][q * 4 + 2] = v.z;
+                    breg[u][q * 4 + 3] = v.w;
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // fragments read before the region is reused
         }
@@ -2458,43 +2514,69 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
             for (int u = 0; u < 2; u++)
                 acc[rt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        if (MATH) {
 #pragma unroll
-        for (int q = 0; q < KQ; q++) {
-            float4 a[SR];
+            for (int kb = 0; kb < KB; kb++) {
+                u32x4 ah[SR], am[SR], al[SR];
 #pragma unroll
-            for (int rt = 0; rt < SR; rt++) {
-                const int row = (rt * RG + rgi) * 16 + li; // row inside the stage: unit rt, row group rgi
-                if (VEC_A) {
-                    const int c = 4 * q + lg;
-                    a[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c < C)
-                        a[rt] = *reinterpret_cast<const float4 *>(sA + (size_t)row * K + ((c ^ (row & (P - 1))) << 2));
-                } else {
-                    const int k = 16 * q + 4 * lg;
-                    const float *pr = sA + (size_t)row * K + k;
-                    a[rt].x = (k + 0 < K) ? pr[0] : 0.f;
-                    a[rt].y = (k + 1 < K) ? pr[1] : 0.f;
-                    a[rt].z = (k + 2 < K) ? pr[2] : 0.f;
-                    a[rt].w = (k + 3 < K) ? pr[3] : 0.f;
+                for (int rt = 0; rt < SR; rt++) {
+                    const int row = (rt * RG + rgi) * 16 + li;
+                    const int c0 = 8 * kb + 2 * lg; // float4 chunks 8 kb + 2 lg, + 1 of the row
+                    const float4 f0 = *reinterpret_cast<const float4 *>(sA + (size_t)row * K + ((c0 ^ (row & (P - 1))) << 2));
+                    const float4 f1 = *reinterpret_cast<const float4 *>(sA + (size_t)row * K + (((c0 + 1) ^ (row & (P - 1))) << 2));
+                    split3x8(f0, f1, ah[rt], am[rt], al[rt]);
                 }
+                // six partial products, smallest first; the four accumulators interleaved
+#define GNNB_BF6(APIECE, BPIECE)                                                                                  \
+    _Pragma("unroll") for (int rt = 0; rt < SR; rt++) _Pragma("unroll") for (int u = 0; u < 2; u++)                \
+        acc[rt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(APIECE[rt]), as_bf16x8(BPIECE[u][kb]), acc[rt][u], 0, 0, 0);
+                GNNB_BF6(am, wm)
+                GNNB_BF6(al, wh)
+                GNNB_BF6(ah, wl_)
+                GNNB_BF6(am, wh)
+                GNNB_BF6(ah, wm)
+                GNNB_BF6(ah, wh)
+#undef GNNB_BF6
             }
-            // k-step outermost: consecutive MFMAs hit the four different accumulators, so the 40-cycle
-            // dependent latency of v_mfma_f32_16x16x4_f32 hides behind its 32-cycle issue interval
-            float as[SR][4];
+        } else {
 #pragma unroll
-            for (int rt = 0; rt < SR; rt++) {
-                as[rt][0] = a[rt].x;
-                as[rt][1] = a[rt].y;
-                as[rt][2] = a[rt].z;
-                as[rt][3] = a[rt].w;
+            for (int q = 0; q < KQ; q++) {
+                float4 a[SR];
+    #pragma unroll
+                for (int rt = 0; rt < SR; rt++) {
+                    const int row = (rt * RG + rgi) * 16 + li; // row inside the stage: unit rt, row group rgi
+                    if (VEC_A) {
+                        const int c = 4 * q + lg;
+                        a[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (c < C)
+                            a[rt] = *reinterpret_cast<const float4 *>(sA + (size_t)row * K + ((c ^ (row & (P - 1))) << 2));
+                    } else {
+                        const int k = 16 * q + 4 * lg;
+                        const float *pr = sA + (size_t)row * K + k;
+                        a[rt].x = (k + 0 < K) ? pr[0] : 0.f;
+                        a[rt].y = (k + 1 < K) ? pr[1] : 0.f;
+                        a[rt].z = (k + 2 < K) ? pr[2] : 0.f;
+                        a[rt].w = (k + 3 < K) ? pr[3] : 0.f;
+                    }
+                }
+                // k-step outermost: consecutive MFMAs hit the four different accumulators, so the 40-cycle
+                // dependent latency of v_mfma_f32_16x16x4_f32 hides behind its 32-cycle issue interval
+                float as[SR][4];
+    #pragma unroll
+                for (int rt = 0; rt < SR; rt++) {
+                    as[rt][0] = a[rt].x;
+                    as[rt][1] = a[rt].y;
+                    as[rt][2] = a[rt].z;
+                    as[rt][3] = a[rt].w;
+                }
+    #pragma unroll
+                for (int sk = 0; sk < 4; sk++)
+    #pragma unroll
+                    for (int rt = 0; rt < SR; rt++)
+    #pragma unroll
+                        for (int u = 0; u < 2; u++)
+                            acc[rt][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[rt][sk], breg[u][q * 4 + sk], acc[rt][u], 0, 0, 0);
             }
-#pragma unroll
-            for (int sk = 0; sk < 4; sk++)
-#pragma unroll
-                for (int rt = 0; rt < SR; rt++)
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-                        acc[rt][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[rt][sk], breg[u][q * 4 + sk], acc[rt][u], 0, 0, 0);
         }
 #ifdef GNNB_PROBE
         asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[SR - 1][1][3]));
@@ -2578,11 +2660,14 @@ __global__ __launch_bounds__(WG, 3) void k_linear_reg(
 #endif
 }
 
-template <int KQ, bool VEC_A>
+template <int KQ, bool VEC_A, int MATH = 0>
 static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const float *W, int ldw,
                                       const float *bias, const float *skip, float *Y, int M, int N,
                                       int act, hipStream_t s, const GatherDesc &gd = GatherDesc{})
 {
+    if (MATH == 0 && VEC_A && KQ >= 2 && options().math == 1 && K == 16 * KQ && N % 32 == 0 && ldw % 4 == 0 &&
+        (((uintptr_t)W & 15) == 0) && gd.rec == nullptr)
+        return launch_linear_reg_t<KQ, VEC_A, 1>(A, lda, K, W, ldw, bias, skip, Y, M, N, act, s, gd);
     // waves: N <= 32 -> 4 row groups x 1 column slice; N <= 64 -> 2 x 2; else 1 x 4 (128 cols / WG)
     const int rg_log2 = N <= 32 ? 2 : (N <= 64 ? 1 : 0);
     const int cols_per_wg = 128 >> rg_log2;
@@ -2599,7 +2684,7 @@ static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const floa
             P *= 2;
     }
     const int num_stages = (M + stage_rows - 1) / stage_rows;
-    auto kern = k_linear_reg<KQ, VEC_A>;
+    auto kern = k_linear_reg<KQ, VEC_A, MATH>;
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -3220,34 +3305,6 @@ __device__ __forceinline__ void g2_mma(const float *__restrict__ Asrc, int lda, 
 #pragma unroll
         for (int r = 0; r < 4; r++)
             v[k][r] = act_t<ACT>((NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias);
-}
-
-// ---- fp32 product through the bf16 matrix cores ("bf16x6").  x = h + m + l EXACTLY, each piece a bf16
-// (8 significant bits each: truncate, subtract, truncate, subtract -- every step is exact in fp32), so
-// a.b = sum of nine bf16 x bf16 products, each exact in fp32.  The six with i + j <= 2 are kept
-// (hh, hm, mh, hl, lh, mm); the three dropped ones are below 2^-24 |a||b|, i.e. below what fp32 resolves of
-// the product.  Accumulation is fp32 inside v_mfma_f32_16x16x32_bf16.  Cost: 6 MFMA of 4 passes per
-// 32-wide k block instead of 8 fp32 MFMA of 8 passes -- 2.4x fewer pipe cycles, and fp32 MFMA runs at
-// the vector-FMA rate on this chip (tools/micro/mfma_valu_overlap.hip).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l)
-{
-    h = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xffff0000u;
-    l = __float_as_uint(r1 - __uint_as_float(m)); // <= 8 significant bits left: its upper half is exact
-}
-// two fp32 bit patterns -> their upper halves packed as {bf16(a) in bits 0..15, bf16(b) in bits 16..31}
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v)
-{
-    union {
-        u32x4 u;
-        bf16x8 b;
-    } c;
-    c.u = v;
-    return c.b;
 }
 
 // M1 of the fused stack with bf16x6: A1 lives in LDS as three bf16 planes [rows][h0] (16-B chunks of

@@ -219,9 +219,9 @@ int gnnb_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
 int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
 
 /* tuning knobs (also read from the environment at load: GNNB_TILE_ROWS, GNNB_AGG_LDS_KB, ...).
- * "math": 0 (default) = native fp32 MFMA everywhere; 1 = the wide update of the fused GCN stack as six
- * bf16 MFMA products of an exact 3-way bf16 split of both fp32 operands, fp32 accumulate (results at fp32
- * rounding level; GNNB_MATH=1). */
+ * "math": 0 (default) = native fp32 MFMA everywhere; 1 = the wide update of the fused GCN stack and the
+ * K <= 128 GEMMs as six bf16 MFMA products of an exact 3-way bf16 split of both fp32 operands, fp32
+ * accumulate (results at fp32 rounding level; GNNB_MATH=1). */
 int gnnb_set_option(const char *name, int value);
 
 #ifdef __cplusplus

@@ -501,3 +501,23 @@ def test_random_multigraphs_match_oracle(dev, conv, layers, n_max, promise, seed
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() < TOL * scale, (np.abs(got - ref).max(), scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 128, 128), (777, 64, 64), (1000, 32, 32), (513, 64, 128)])
+def test_linear_bf16x6_math_is_fp32_equivalent(dev, M, N, K):
+    """Opt-in math mode 1 in the register-resident-weight GEMM: six bf16 MFMA products of an exact 3-way
+    split of both operands.  Against a float64 product it must be as good as the native fp32-MFMA kernel."""
+    torch.manual_seed(M + N)
+    a = torch.rand(M, K, device=dev) - 0.5
+    w = (torch.rand(N, K, device=dev) - 0.5) / K ** 0.5
+    b = torch.rand(N, device=dev)
+    ref = torch.tanh(a.double() @ w.double().T + b.double())
+    try:
+        runtime.set_option("math", 1)
+        split = runtime.linear([(a, None)], w, b, act="tanh")
+    finally:
+        runtime.set_option("math", 0)
+    exact = runtime.linear([(a, None)], w, b, act="tanh")
+    e_split = (split.double() - ref).abs().max().item()
+    e_exact = (exact.double() - ref).abs().max().item()
+    assert e_split < 2e-6 and e_split < 2.0 * e_exact + 1e-7, (e_split, e_exact)
