@@ -3584,39 +3584,65 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         G2_PT(1);
 
         // ---- P0: A0[i][f] = sum_j x_j[f] dinv_i dinv_j + x_i[f] dinv_i^2   (CSR order, self last)
-        // LD0 lanes per row (no division; lanes f >= F0 write the zero padding).  Every LDS load is
-        // unconditional -- unused neighbour slots alias the row itself -- and the degree only selects:
-        // a lane-divergent guard around a load makes the compiler wait at every join.
-        for (int i = tv / LD0; i < rows; i += G2_WG / LD0) {
-            const int f = tv % LD0;
-            const int fc = f < f0 ? f : 0;
-            const int4 r0 = srec[2 * i], r1 = srec[2 * i + 1];
+        // Eight lanes per row, lane l8 takes features l8, l8 + 8, ...: all <= 48 rows in ONE pass of the 512
+        // threads (lanes f >= F0 write the zero padding).  Every LDS load is unconditional -- unused neighbour
+        // slots alias the row itself, inactive threads read row 0 -- and the degree only selects: a
+        // lane-divergent guard around a load makes the compiler wait at every join.
+        {
+            constexpr int T0 = LD0 / 8;
+            const int i = tv >> 3, l8 = tv & 7;
+            const bool active = i < rows;
+            const int ic = active ? i : 0;
+            const int4 r0 = srec[2 * ic], r1 = srec[2 * ic + 1];
             const int deg = r0.y;
             const int jl[4] = {r0.z - nb, r0.w - nb, r1.x - nb, r1.y - nb};
-            const float di = sdinv[i];
-            float xv[4], sv[4];
+            const float di = sdinv[ic];
+            float xv[T0][4], xself[T0], sv[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                xv[q] = xs[jl[q] * f0 + fc];
                 sv[q] = sdinv[jl[q]];
-            }
-            const float xself = xs[i * f0 + fc];
-            float c[4], acc = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+                for (int t = 0; t < T0; t++) {
+                    const int f = l8 + 8 * t;
+                    xv[t][q] = xs[jl[q] * f0 + (f < f0 ? f : 0)];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T0; t++) {
+                const int f = l8 + 8 * t;
+                xself[t] = xs[ic * f0 + (f < f0 ? f : 0)];
+            }
+            float c[4], acc[T0];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
                 c[q] = deg > q ? di * sv[q] : 0.0f;
-                acc += xv[q] * c[q];
+#pragma unroll
+            for (int t = 0; t < T0; t++) {
+                acc[t] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    acc[t] += xv[t][q] * c[q];
             }
-            for (int k = r0.x + 4; k < r0.x + deg; k++) { // degree > 4: rare in molecules
-                const int j = col[k] - nb;
-                acc += xs[j * f0 + fc] * (di * sdinv[j]);
-            }
-            acc += xself * (di * di);
-            A0[i * LD0 + f] = f < f0 ? acc : 0.0f;
-            if (f == 0) { // the row's scalars, computed once here instead of by every lane of P1's lane group
-                REC[3 * i] = make_int4(jl[0] * ldh * 4, jl[1] * ldh * 4, jl[2] * ldh * 4, jl[3] * ldh * 4);
-                REC[3 * i + 1] = make_int4(__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]), __float_as_int(c[3]));
-                REC[3 * i + 2] = make_int4(__float_as_int(di * di), r0.x, deg, __float_as_int(di));
+            if (active) {
+                for (int k = r0.x + 4; k < r0.x + deg; k++) { // degree > 4: rare in molecules
+                    const int j = col[k] - nb;
+                    const float cj = di * sdinv[j];
+#pragma unroll
+                    for (int t = 0; t < T0; t++) {
+                        const int f = l8 + 8 * t;
+                        acc[t] += xs[j * f0 + (f < f0 ? f : 0)] * cj;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < T0; t++) {
+                    const int f = l8 + 8 * t;
+                    A0[i * LD0 + f] = f < f0 ? acc[t] + xself[t] * (di * di) : 0.0f;
+                }
+                if (l8 == 0) { // the row's scalars, computed once here instead of by every lane of P1's lane group
+                    REC[3 * i] = make_int4(jl[0] * ldh * 4, jl[1] * ldh * 4, jl[2] * ldh * 4, jl[3] * ldh * 4);
+                    REC[3 * i + 1] = make_int4(__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]), __float_as_int(c[3]));
+                    REC[3 * i + 2] = make_int4(__float_as_int(di * di), r0.x, deg, __float_as_int(di));
+                }
             }
         }
         G2_PT(2);
