@@ -194,9 +194,12 @@ __device__ void prep_graph_scan(
 // lower lanes) -- stable, because lanes are in COO order.  Starts come from a wave prefix sum over
 // node lanes, and `col` is then written by ONE scatter per 64 edges instead of a divergent
 // store per edge.  n iterations of ~8 instructions replace 2e iterations of a dependent chain.
-static constexpr int PREP_FAST_NODES = 256; // 4 node chunks of 64 lanes
 static constexpr int PREP_FAST_EDGES = 256; // 4 edge chunks
 
+// PREP_FAST_NODES: 256 (4 node chunks of 64 lanes) in general, 64 when the caller promises graphs of <= 64
+// nodes -- 4 KB of LDS per workgroup instead of 16 KB, so that graph prep of the next batch fits on a CU
+// beside two workgroups of the conv-stack kernel and the readout of the previous one.
+template <int PREP_FAST_NODES>
 __global__ __launch_bounds__(WG) void k_graph_prep(
     const int2 *__restrict__ coo, const int32_t *__restrict__ node_ptr,
     const int32_t *__restrict__ edge_ptr, int B, int N, int E, int32_t *__restrict__ row_ptr,
@@ -384,10 +387,16 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
     // (gnnb_workspace_check), so no per-batch memset node sits in front of this launch
     const int waves = t.num_graphs + 1;
     const int grid = (waves + (WG / 64) - 1) / (WG / 64);
-    hipLaunchKernelGGL(k_graph_prep, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
-                       edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.node_rec,
-                       t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.tile_rows,
-                       t.num_tiles, t.max_graph_nodes_hint, t.err);
+    if (t.max_graph_nodes_hint > 0 && t.max_graph_nodes_hint <= 64)
+        hipLaunchKernelGGL(k_graph_prep<64>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
+                           edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.node_rec,
+                           t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.tile_rows,
+                           t.num_tiles, t.max_graph_nodes_hint, t.err);
+    else
+        hipLaunchKernelGGL(k_graph_prep<256>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
+                           edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.node_rec,
+                           t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.tile_rows,
+                           t.num_tiles, t.max_graph_nodes_hint, t.err);
     return hipGetLastError();
 }
 
@@ -3152,12 +3161,136 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_pool_mlp(const float *__restri
 #endif
 }
 
+// -------------------------------------------------------------------------------------
+// Readout on a pooled matrix, small-footprint form.  k_pool_mlp keeps every weight in LDS (119 KB at the
+// BASELINE configs): fast on an idle chip, but when batches are in flight on several streams it cannot
+// start on a CU until BOTH resident workgroups of the next batch's conv-stack kernel have left, and while
+// it runs nothing else fits -- measured cost 12.5 us per step at C2 for 10.5 us of kernel.  This form
+// needs ~9 KB of LDS and < 96 registers, so its 4-wave workgroups slot in BESIDE the conv-stack kernel
+// (31 KB of LDS and one wave slot of 96 registers per SIMD are left over there): weights and the pooled
+// rows are MFMA operands fetched straight from L2 (the pooled matrix was just written, the head's weights
+// are shared by all workgroups), only the 16 x width activations between layers live in LDS.
+// One workgroup = 16 graphs; wave w takes the 16-column output slices w, w + 4, ...
+static constexpr int HS_THREADS = 256;
+static constexpr int HS_MAXW = 128; // widest hidden layer this form takes
+
+template <int ACT>
+__global__ __launch_bounds__(HS_THREADS, 5) void k_head_small(const float *__restrict__ pooled, int B, HeadArgs head,
+                                                             float *__restrict__ out, int ldact)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sact = reinterpret_cast<float *>(smem); // [2][16][ldact]: ldact = widest hidden layer + 4 (padded rows)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int g0 = blockIdx.x * 16;
+    const int grow = min(g0 + li, B - 1); // (rows past the batch re-read the last graph and are dropped at the store)
+    int cur = 0;
+#pragma unroll 1
+    for (int l = 0; l < head.nlin; l++) {
+        const int k = head.dims[l], n = head.dims[l + 1];
+        const bool last = (l == head.nlin - 1);
+        const float *__restrict__ W = head.w[l];
+        const float *__restrict__ bias = head.b[l];
+        for (int sl = wave; sl * 16 < n; sl += HS_THREADS / 64) {
+            const int nn = sl * 16 + li;
+            const int nnc = nn < n ? nn : n - 1;
+            const float *wrow = W + (size_t)nnc * k + 4 * lg;
+            const float *arow_g = pooled + (size_t)grow * k + 4 * lg; // layer 0: A straight from the pooled matrix
+            const float *arow_l = sact + (cur * 16 + li) * ldact + 4 * lg; // later layers: from LDS
+            // four accumulator chains over interleaved 16-wide k blocks, 64 k values per step
+            f32x4 accs[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                accs[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            auto loadf = [&](int kb, float4 (&a)[4], float4 (&w)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int kk = kb + 16 * u; // (+ 4 lg inside the row pointers)
+                    const bool ok = kk + 4 * lg < k; // k % 4 == 0: a float4 is whole or absent
+                    const int kc = ok ? kk : 0;
+                    w[u] = *reinterpret_cast<const float4 *>(wrow + kc);
+                    a[u] = l == 0 ? *reinterpret_cast<const float4 *>(arow_g + kc)
+                                  : *reinterpret_cast<const float4 *>(arow_l + kc);
+                    if (!ok)
+                        a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            // (no operand double-buffering: the register budget is what lets this kernel share a SIMD with
+            // the conv-stack kernel, and it runs in that kernel's shadow anyway)
+            for (int kb = 0; kb < k; kb += 64) {
+                float4 a[4], w[4];
+                loadf(kb, a, w);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, w[u].x, accs[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, w[u].y, accs[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, w[u].z, accs[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, w[u].w, accs[u], 0, 0, 0);
+            }
+            // C/D: col = lane&15 (output column nn), row = (lane>>4)*4 + r (graph inside the tile)
+            if (nn < n) {
+                const float bvv = bias ? bias[nn] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int gi = lg * 4 + r;
+                    const float v = (accs[0][r] + accs[1][r]) + (accs[2][r] + accs[3][r]) + bvv;
+                    if (last) {
+                        if (g0 + gi < B)
+                            out[(size_t)(g0 + gi) * n + nn] = v;
+                    } else {
+                        sact[((cur ^ 1) * 16 + gi) * ldact + nn] = act_t<ACT>(v);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// hipErrorNotSupported when the head's shape does not suit the small form (caller takes k_pool_mlp)
+static hipError_t launch_head_small(int num_graphs, const HeadArgs &head, int act, float *out, hipStream_t s,
+                                    const float *prepooled)
+{
+    if (!prepooled || head.nlin < 1 || head.nlin > 8 || (((uintptr_t)prepooled) & 15))
+        return hipErrorNotSupported;
+    for (int l = 0; l < head.nlin; l++) {
+        if ((head.dims[l] & 3) || (((uintptr_t)head.w[l]) & 15))
+            return hipErrorNotSupported; // float4 operand fetches
+        if (l > 0 && head.dims[l] > HS_MAXW)
+            return hipErrorNotSupported; // hidden activations live in the fixed LDS tile
+    }
+    int maxw = 4;
+    for (int l = 1; l < head.nlin; l++)
+        maxw = std::max(maxw, (int)head.dims[l]);
+    const int ldact = ((maxw + 3) & ~3) + 4;
+    const size_t lds = (size_t)2 * 16 * ldact * 4;
+    const int grid = (num_graphs + 15) / 16;
+    auto go = [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
+        hipLaunchKernelGGL(k_head_small<ACT>, dim3(grid), dim3(HS_THREADS), lds, s, prepooled, num_graphs, head, out, ldact);
+    };
+    GNNB_DISPATCH_ACT(act, go)
+    return hipGetLastError();
+}
+
 hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_graphs, int d,
                            const int32_t *pools, int num_pools, const HeadArgs &head, int act,
                            float *out, hipStream_t s, const float *prepooled)
 {
     if (num_graphs <= 0)
         return hipSuccess;
+    if (prepooled && options().fuse_head && options().head_small) {
+        const hipError_t e = launch_head_small(num_graphs, head, act, out, s, prepooled);
+        if (e != hipErrorNotSupported)
+            return e;
+    }
     const float *src = prepooled ? prepooled : x;
     if (!options().fuse_head || head.nlin < 1 || head.nlin > 8 || (d & 3) || (((uintptr_t)src & 15) != 0))
         return hipErrorNotSupported;

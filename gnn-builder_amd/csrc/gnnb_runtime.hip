@@ -57,7 +57,7 @@ Options &options()
                         env_int("GNNB_AGG_XCD_REMAP", 1),    env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_FUSE_NARROW", 1),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
-                        env_int("GNNB_MATH", 0)};
+                        env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_MATH", 0)};
     return o;
 }
 
@@ -203,6 +203,8 @@ int gnnb_set_option(const char *name, int value)
         o.fuse_gcn2 = value;
     else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
         o.fuse_head = value;
+    else if (!strcmp(name, "head_small") && value >= 0 && value <= 1)
+        o.head_small = value;
     else if (!strcmp(name, "math") && value >= 0 && value <= 1)
         o.math = value;
     else if (!strcmp(name, "gemm_variant") && value >= 0 && value <= 1)
