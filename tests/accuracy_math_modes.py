@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Accuracy of the two math modes of the fused GCN stack against a float64 evaluation of the same model
+"""(Kept under tests/: it calls the CPU oracle, which only test infrastructure may do.)
+Accuracy of the two math modes of the fused GCN stack against a float64 evaluation of the same model
 (BASELINE config 2 shape): fp32 C oracle, HIP fp32-MFMA path (math 0), HIP bf16x6 path (math 1)."""
 import sys
 from pathlib import Path
@@ -9,7 +10,7 @@ import torch
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "tests"))  # helpers
 import bench  # noqa: E402
 from gnnbuilder_amd import runtime, synthetic  # noqa: E402
 from helpers import canon  # noqa: E402
