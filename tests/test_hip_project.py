@@ -55,3 +55,34 @@ def test_generated_top_symbol_via_ctypes(tmp_path):
         ref = model(g.x, g.edge_index).view(-1).numpy()
     assert np.abs(out - ref).max() < 1e-5
     lib.abi_sage_release()
+
+
+@pytest.mark.gpu
+def test_bench_line_keeps_the_contract(tmp_path):
+    """bench.py prints ONE JSON line with the contract's keys plus the roofline / cpu_baseline objects
+    (short run, bounded CPU sample)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--batches", "4"],
+                       capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "graphs/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] == 1
+    assert d["value"] > 1e6 and 0.0 < d["roofline"]["frac"] < 1.0
