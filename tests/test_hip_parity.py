@@ -521,3 +521,28 @@ def test_linear_bf16x6_math_is_fp32_equivalent(dev, M, N, K):
     e_split = (split.double() - ref).abs().max().item()
     e_exact = (exact.double() - ref).abs().max().item()
     assert e_split < 2e-6 and e_split < 2.0 * e_exact + 1e-7, (e_split, e_exact)
+
+
+@pytest.mark.parametrize("mlp_hidden,mlp_layers,task_out,pools,h1", [
+    (64, 2, 19, ("add", "mean", "max"), 128), (16, 1, 1, ("max",), 64), (128, 3, 33, ("add", "max"), 32),
+    (50, 2, 7, ("mean",), 64), (64, 0, 5, ("add", "mean", "max"), 20), (100, 2, 3, ("add",), 128)])
+def test_small_readout_kernel_equals_lds_kernel_and_oracle(dev, mlp_hidden, mlp_layers, task_out, pools, h1):
+    """The readout behind the fused GCN stack: small-footprint kernel (operands straight from L2, co-resident
+    with the next batch's conv kernel) vs the weights-in-LDS kernel vs the oracle, over head shapes incl. a
+    single linear, widths that are not multiples of 16 and one the small form must decline (hidden 50)."""
+    model = make_model("gcn", in_dim=11, hidden=64, layers=2, out_dim=h1, act="relu", pools=pools, mlp_hidden=mlp_hidden,
+                       mlp_layers=mlp_layers, task_out=task_out, mlp_act="tanh")
+    batch = synthetic.make_batch("qm9", 203, seed=mlp_hidden + task_out)  # 203: the last 16-graph tile is ragged
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)
+    outs = []
+    try:
+        for small in (1, 0):
+            runtime.set_option("head_small", small)
+            outs.append(cm.forward(*to_dev(batch, dev)).cpu().numpy())
+    finally:
+        runtime.set_option("head_small", 1)
+    cm.check()
+    for o in outs:
+        assert np.abs(o - ref).max() < TOL
+    assert np.abs(outs[0] - outs[1]).max() < 1e-5
