@@ -46,6 +46,7 @@ struct Options {
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
     int head_small;    // 1 = readout on a pooled matrix with the small-footprint kernel that co-resides with the
                        //     conv-stack kernel of the next batch in flight (default); 0 = weights-in-LDS kernel
+    int head_split;    // 1 = layer-wise models: pooling pass + small readout instead of the one-launch pooling+MLP kernel
     int math;          // 0 = fp32 MFMA everywhere (default); 1 = the wide update of the fused GCN stack and the
                        //     K <= 128 GEMMs as six bf16 MFMA products of an exact 3-way split of both operands
                        //     (fp32-equivalent, opt-in)

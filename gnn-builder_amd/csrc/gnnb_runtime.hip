@@ -57,7 +57,8 @@ Options &options()
                         env_int("GNNB_AGG_XCD_REMAP", 1),    env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_FUSE_NARROW", 1),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
-                        env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_MATH", 0)};
+                        env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
+                        env_int("GNNB_MATH", 0)};
     return o;
 }
 
@@ -203,6 +204,8 @@ int gnnb_set_option(const char *name, int value)
         o.fuse_gcn2 = value;
     else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
         o.fuse_head = value;
+    else if (!strcmp(name, "head_split") && value >= 0 && value <= 1)
+        o.head_split = value;
     else if (!strcmp(name, "head_small") && value >= 0 && value <= 1)
         o.head_small = value;
     else if (!strcmp(name, "math") && value >= 0 && value <= 1)
@@ -734,8 +737,18 @@ int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const flo
                 head.dims[i] = din;
                 head.dims[i + 1] = dout;
             }
-            hipError_t he = launch_pool_mlp(cur, ws->t.node_ptr, B, gw, d.pools, d.num_pools, head,
-                                            d.mlp_activation, out_dev, (hipStream_t)stream);
+            hipError_t he = hipErrorNotSupported;
+            if (options().head_split) {
+                // pooling pass (HBM-bound, every CU) + the small readout on the pooled matrix: neither needs the
+                // 119 KB of LDS of the one-launch form, so both share CUs with other batches' kernels
+                if ((rc = gnnb_global_pool(ws, cur, gw, d.pools, d.num_pools, ws->pooled, stream)))
+                    return rc;
+                he = launch_pool_mlp(nullptr, ws->t.node_ptr, B, gw, d.pools, d.num_pools, head, d.mlp_activation, out_dev,
+                                     (hipStream_t)stream, ws->pooled);
+            } else {
+                he = launch_pool_mlp(cur, ws->t.node_ptr, B, gw, d.pools, d.num_pools, head, d.mlp_activation, out_dev,
+                                     (hipStream_t)stream);
+            }
             if (he == hipSuccess)
                 return GNNB_OK;
             if (he != hipErrorNotSupported)
