@@ -136,8 +136,12 @@ __device__ void prep_graph_scan(
             dinv[v] = 1.0f / sqrtf(1.0f + (float)cnt);
             const int dcl = cnt < 1 ? 1 : cnt; // gnn_builder_lib.h:1972-1982
             const float logd = logf((float)(dcl + 1));
-            amp[v] = logd / delta;
-            att[v] = delta / logd;
+            if (delta > 0.0f) { // (delta <= 0: the model has no PNA layer, the scalers are not needed)
+                if (delta > 0.0f) { // (delta <= 0: the model has no PNA layer, the scalers are not needed)
+                    amp[v] = logd / delta;
+                    att[v] = delta / logd;
+                }
+            }
         }
         // ---- stable fill: edges are visited in COO order; the first four sources also go into
         // the node record
@@ -334,8 +338,10 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
                 dinv[v] = 1.0f / sqrtf(1.0f + (float)deg[q]);
                 const int dcl = deg[q] < 1 ? 1 : deg[q]; // gnn_builder_lib.h:1972-1982
                 const float logd = logf((float)(dcl + 1));
-                amp[v] = logd / delta;
-                att[v] = delta / logd;
+                if (delta > 0.0f) { // (delta <= 0: the model has no PNA layer, the scalers are not needed)
+                    amp[v] = logd / delta;
+                    att[v] = delta / logd;
+                }
                 // default record: unused source slots alias the node itself
                 int32_t *f = s_first[wave] + vl * 4;
                 f[0] = v;

@@ -455,7 +455,10 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     t.num_tiles = (num_nodes + t.tile_rows - 1) / t.tile_rows;
     if (!(pna_delta > 0.0f))
         pna_delta = 1.0f;
-    GNNB_HIP_TRY(launch_graph_prep(coo_dev, node_ptr_dev, edge_ptr_dev, t, pna_delta,
+    // the degree scalers (amp / att) are only read by PNA layers: a model-bound workspace of another conv type
+    // skips their computation and their 8 B/node of writes (delta <= 0 tells the kernel)
+    const float prep_delta = ws->desc.conv_type == GNNB_CONV_PNA ? pna_delta : -1.0f;
+    GNNB_HIP_TRY(launch_graph_prep(coo_dev, node_ptr_dev, edge_ptr_dev, t, prep_delta,
                                    (hipStream_t)stream));
     ws->prepared = true;
     return GNNB_OK;
