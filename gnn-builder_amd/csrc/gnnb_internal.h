@@ -74,7 +74,7 @@ struct GemmArgs {
 // runs launch_aggregate + launch_linear
 hipError_t launch_conv_gather(const BatchTables &t, int agg_kind, float eps, const float *x, int lda,
                               int K, const float *w, int ldw, const float *bias, const float *skip,
-                              float *y, int N, int act, hipStream_t s);
+                              float *y, int N, int act, hipStream_t s, int cat = 0);
 
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
                          const float *skip, float *y, int M, int N, int act, hipStream_t s);

@@ -2313,6 +2313,7 @@ struct GatherDesc {
     const float *dinv;   // GCN normaliser
     int32_t mode;        // gnnb_agg (GCN, SUM, MEAN)
     float eps;
+    int32_t cat;         // > 0: the stage row is [aggregate(x)(cat wide) | x_i (cat wide)]  (GraphSAGE: [mean | x], K = 2 cat)
 };
 
 // MATH 1 (opt-in, K % 32 == 0, N % 32 == 0, plain A copy): the products go through the bf16 matrix cores as six
@@ -2469,8 +2470,11 @@ __global__ __launch_bounds__(WG, MATH ? 2 : 3) void k_linear_reg(
         const int m0i = row_begin(j);
         const int rows = rows_of(j);
         for (int e = tid; e < rows * K; e += WG) {
-            const int i = e / K, f = e - i * K;
+            const int i = e / K, fk = e - i * K;
             const int node = m0i + i;
+            // (GraphSAGE form: columns [0, cat) hold the aggregate, columns [cat, 2 cat) the node's own row)
+            const bool own = gd.cat > 0 && fk >= gd.cat;
+            const int f = own ? fk - gd.cat : fk;
             const int4 r0 = gd.rec[2 * (size_t)node], r1 = gd.rec[2 * (size_t)node + 1];
             const int deg = r0.y;
             const int jn[4] = {r0.z, r0.w, r1.x, r1.y};
@@ -2497,6 +2501,8 @@ __global__ __launch_bounds__(WG, MATH ? 2 : 3) void k_linear_reg(
                 acc += xs * (1.0f + gd.eps);
             else if (deg > 0)
                 acc = acc / (float)deg;
+            if (own)
+                acc = xs;
             dst[e] = acc;
         }
     };
@@ -2763,9 +2769,10 @@ static hipError_t launch_linear_reg(const GemmArgs &g, const float *w, int ldw, 
 // Fused narrow-input conv: Y = act(aggregate(x) . W^T + b (+ skip)) in one launch (K <= 32).
 hipError_t launch_conv_gather(const BatchTables &t, int agg_kind, float eps, const float *x, int lda,
                               int K, const float *w, int ldw, const float *bias, const float *skip,
-                              float *y, int N, int act, hipStream_t s)
+                              float *y, int N, int act, hipStream_t s, int cat)
 {
-    if (K > 32 || agg_kind == GNNB_AGG_PNA || t.num_nodes <= 0)
+    // K = width of the stage row the GEMM contracts over: F_in, or 2 F_in in the [aggregate | own row] form
+    if (K > 32 || agg_kind == GNNB_AGG_PNA || t.num_nodes <= 0 || (cat > 0 && K != 2 * cat))
         return hipErrorNotSupported;
     GatherDesc gd;
     gd.rec = t.node_rec;
@@ -2773,6 +2780,7 @@ hipError_t launch_conv_gather(const BatchTables &t, int agg_kind, float eps, con
     gd.dinv = t.dinv;
     gd.mode = agg_kind;
     gd.eps = eps;
+    gd.cat = cat;
     if (K <= 16)
         return launch_linear_reg_t<1, false>(x, lda, K, w, ldw, bias, skip, y, t.num_nodes, N, act, s, gd);
     return launch_linear_reg_t<2, false>(x, lda, K, w, ldw, bias, skip, y, t.num_nodes, N, act, s, gd);

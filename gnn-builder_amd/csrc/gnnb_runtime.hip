@@ -692,6 +692,15 @@ int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const flo
             break;
         }
         case GNNB_CONV_SAGE: {
+            if (options().fuse_narrow && 2 * fi <= 32) {
+                // narrow input: [mean_j x_j | x_i] is produced inside the GEMM's A stage (K = 2 F_in)
+                hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_MEAN, 0.f, cur, fi, 2 * fi, p[0], 2 * fi, p[1], skip, nxt,
+                                                   fo, d.activation, (hipStream_t)stream, fi);
+                if (he == hipSuccess)
+                    break;
+                if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
+            }
             if ((rc = gnnb_aggregate(ws, GNNB_AGG_MEAN, cur, nullptr, ws->agg, fi, 0.f, stream)))
                 return rc;
             gnnb_gemm_seg segs[2] = {{ws->agg, nullptr, fi, fi}, {cur, nullptr, fi, fi}};

@@ -336,7 +336,7 @@ def test_fused_readout_equals_separate_kernels(dev, mlp_hidden, mlp_layers, task
     assert np.abs(outs[0] - outs[1]).max() < 1e-5
 
 
-@pytest.mark.parametrize("conv,fin", [("gcn", 11), ("gin", 9), ("gcn", 17), ("gin", 32), ("gcn", 4)])
+@pytest.mark.parametrize("conv,fin", [("gcn", 11), ("gin", 9), ("gcn", 17), ("gin", 32), ("gcn", 4), ("sage", 9), ("sage", 16), ("sage", 3)])
 def test_fused_narrow_layer_equals_separate_kernels(dev, conv, fin):
     """First layer with aggregate + update in one kernel vs the two-kernel path vs the oracle
     (incl. degree > 4 nodes and empty graphs)."""
