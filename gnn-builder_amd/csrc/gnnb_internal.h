@@ -41,6 +41,7 @@ struct Options {
     int agg_xcd_remap; // remap block ids so each XCD owns a contiguous run of row chunks
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
     int gemm_max_wg_per_cu;
+    int gemm_dma;      // 1 = large-K GEMM through LDS-DMA when every segment is plain (default)
     int fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
     int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)

@@ -2228,6 +2228,151 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 
 
 // -------------------------------------------------------------------------------------
+// LDS-DMA form of the tiled GEMM above for the regular case -- rows 16-B aligned, segment widths whole
+// 32-wide chunks (GraphSAGE at d = 256: [mean | x] . [Wl | Wr]^T, K = 2 x 256; PNA at d = 128: 13 x 128 with
+// two row-scaled segments, the scaler applied to the A fragments).
+// Same 128 x 128 workgroup tile and 32x32x2 MFMA schedule, but the A and W chunks go global -> LDS
+// directly (untracked global_load_lds, no VGPR staging, no ds_write): each wave issues eight 1-KB
+// DMA instructions per chunk, the next chunk's while the matrix cores work on the current one.  LDS rows are
+// unpadded [row][32 floats]; 16-B pieces are XOR-swizzled through the DMA *source* address
+// (slot = piece ^ (row & 7)), which keeps the ds_read_b128 fragment reads conflict-free.
+__global__ __launch_bounds__(WG) void k_linear_dma(GemmArgs g, const float *__restrict__ W, int ldw,
+                                                   const float *__restrict__ bias,
+                                                   const float *__restrict__ skip, float *__restrict__ Y, int M,
+                                                   int N, int act)
+{
+    constexpr int NT = 2, BN = 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_B = BM * BK * 4; // 16 KB: one operand chunk
+    // [2 buffers][A chunk | W chunk]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int total = g.cpre[g.nseg];
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                acc[mi][ni][i] = 0.0f;
+
+    // per-row scalers of the scaled segments (PNA: amp . A, att . A), fetched ONCE for the lane's two A rows:
+    // a load inside the chunk loop would queue behind the DMA in flight
+    const int li = lane & 31, lh = lane >> 5;
+    float sc[4][2];
+#pragma unroll
+    for (int sgm = 0; sgm < 4; sgm++)
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+            const int row = min(m0 + wm * 64 + mi * 32 + li, M - 1);
+            sc[sgm][mi] = (sgm < g.nseg && g.rs[sgm] != nullptr) ? g.rs[sgm][row] : 1.0f;
+        }
+
+    auto issue = [&](int c, int buf) {
+        // segment lookup with static indexing only (keeps the kernarg struct out of scratch)
+        const float *ap = g.a[0];
+        int lda = g.lda[0], koff = g.koff[0], cbase = 0;
+#pragma unroll
+        for (int sgm = 1; sgm < 4; sgm++) {
+            if (sgm < g.nseg && c >= g.cpre[sgm]) {
+                ap = g.a[sgm];
+                lda = g.lda[sgm];
+                koff = g.koff[sgm];
+                cbase = g.cpre[sgm];
+            }
+        }
+        const int kk = (c - cbase) * BK;
+        char *abase = smem + (size_t)buf * 2 * TILE_B, *wbase = abase + TILE_B;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int L0 = (wave * 4 + i) * 64; // piece index of lane 0: 8 rows x 8 pieces per instruction
+            const int L = L0 + lane, row = L >> 3, piece = (L & 7) ^ (row & 7);
+            // rows past M / N re-read the last valid row (never stored)
+            const int ra = min(m0 + row, M - 1), rw = min(n0 + row, N - 1);
+            dma16_to_lds_u(ap + (size_t)ra * lda + kk + piece * 4, abase + (size_t)L0 * 16);
+            dma16_to_lds_u(W + (size_t)rw * ldw + koff + kk + piece * 4, wbase + (size_t)L0 * 16);
+        }
+    };
+
+    issue(0, 0);
+    dma_wait_all();
+    __syncthreads();
+    for (int c = 0; c < total; c++) {
+        const int buf = c & 1;
+        if (c + 1 < total)
+            issue(c + 1, buf ^ 1);
+        float s0 = sc[0][0], s1 = sc[0][1]; // this chunk's segment (uniform), static indexing
+        bool scaled = g.rs[0] != nullptr;
+#pragma unroll
+        for (int sgm = 1; sgm < 4; sgm++)
+            if (sgm < g.nseg && c >= g.cpre[sgm]) {
+                s0 = sc[sgm][0];
+                s1 = sc[sgm][1];
+                scaled = g.rs[sgm] != nullptr;
+            }
+        const float *a = reinterpret_cast<const float *>(smem + (size_t)buf * 2 * TILE_B);
+        const float *b = reinterpret_cast<const float *>(smem + (size_t)buf * 2 * TILE_B + TILE_B);
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 8) {
+            float4 fa[2], fb[NT];
+            const int piece = (kb >> 2) + lh; // 16-B piece holding k = kb + 4 lh .. + 3
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+                const int r = wm * 64 + mi * 32 + li;
+                fa[mi] = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
+            }
+            if (scaled) { // the row scaler multiplies the A operand, as in the register-staged kernel
+                fa[0].x *= s0, fa[0].y *= s0, fa[0].z *= s0, fa[0].w *= s0;
+                fa[1].x *= s1, fa[1].y *= s1, fa[1].z *= s1, fa[1].w *= s1;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++) {
+                const int r = wn * 32 * NT + ni * 32 + li;
+                fb[ni] = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NT; ni++) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].x, fb[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].y, fb[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].z, fb[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+        dma_wait_all(); // the next chunk has landed (issued a whole chunk of MFMAs ago)
+        __syncthreads(); // ... for everyone, and everyone is done reading this one
+    }
+
+    auto epilogue = [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++) {
+                const int colg = n0 + wn * 32 * NT + ni * 32 + li;
+                if (colg >= N)
+                    continue;
+                const float bv = bias ? bias[colg] : 0.0f;
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const int rowg = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    if (rowg < M) {
+                        float v = acc[mi][ni][reg] + bv;
+                        if (skip)
+                            v += skip[(size_t)rowg * N + colg];
+                        Y[(size_t)rowg * N + colg] = act_t<ACT>(v);
+                    }
+                }
+            }
+    };
+    GNNB_DISPATCH_ACT(act, epilogue)
+}
+
+// -------------------------------------------------------------------------------------
 // Register-resident-weight variant for K <= 128 (every full-width layer of the d<=128 models, the
 // first layer, the MLP head's 64-wide linears).  The weight matrix is tiny next to the activation
 // stream, so each wave keeps ITS 32 output columns x K of W in VGPRs for the whole kernel (K/2
@@ -2794,6 +2939,25 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
     if (linear_reg_eligible(g))
         return launch_linear_reg(g, w, ldw, bias, skip, y, M, N, act, s);
     const int gm = (M + BM - 1) / BM;
+    if (N > 64 && options().gemm_dma) {
+        bool plain = (ldw % 4 == 0) && (((uintptr_t)w & 15) == 0);
+        for (int sg = 0; sg < g.nseg && plain; sg++)
+            plain = g.avec[sg] && g.wvec[sg] && (g.k[sg] % BK == 0) && (g.koff[sg] % 4 == 0);
+        if (plain) {
+            const size_t lds = 2 * 2 * (size_t)BM * BK * 4;
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess)
+                    return e;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_linear_dma, dim3(gm, (N + 127) / 128), dim3(WG), lds, s, g, w, ldw, bias, skip, y, M, N,
+                               act);
+            return hipGetLastError();
+        }
+    }
     if (N > 64) {
         constexpr int NT = 2;
         const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * 64 * NT * LDS_LD) * 4;

@@ -55,7 +55,8 @@ Options &options()
                         env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32),
                         env_int("GNNB_AGG_VARIANT", 6),      env_int("GNNB_AGG_ROWS_PER_WG", 48),
                         env_int("GNNB_AGG_XCD_REMAP", 1),    env_int("GNNB_GEMM_VARIANT", 0),
-                        env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_FUSE_NARROW", 1),
+                        env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_GEMM_DMA", 1),
+                        env_int("GNNB_FUSE_NARROW", 1),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
                         env_int("GNNB_MATH", 0)};
@@ -212,6 +213,8 @@ int gnnb_set_option(const char *name, int value)
         o.math = value;
     else if (!strcmp(name, "gemm_variant") && value >= 0 && value <= 1)
         o.gemm_variant = value;
+    else if (!strcmp(name, "gemm_dma") && value >= 0 && value <= 1)
+        o.gemm_dma = value;
     else if (!strcmp(name, "gemm_max_wg_per_cu") && value >= 1 && value <= 8)
         o.gemm_max_wg_per_cu = value;
     else

@@ -546,3 +546,29 @@ def test_small_readout_kernel_equals_lds_kernel_and_oracle(dev, mlp_hidden, mlp_
     for o in outs:
         assert np.abs(o - ref).max() < TOL
     assert np.abs(outs[0] - outs[1]).max() < 1e-5
+
+
+@pytest.mark.parametrize("M,N,F", [(1000, 128, 64), (333, 200, 32), (4097, 256, 128)])
+def test_linear_dma_path_segments_rowscale_and_ragged_edges(dev, M, N, F):
+    """The LDS-DMA form of the tiled GEMM (segment widths whole 32-wide chunks, N > 64): four segments with two
+    row-scaled ones (the PNA shape), M and N that are not multiples of the tile, skip + activation -- against
+    a float64 product, and bit-for-bit against the register-staged kernel (same MFMA order)."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.rand(M, F, generator=g) - 0.5
+    A = torch.rand(M, 4 * F, generator=g) - 0.5
+    amp, att = torch.rand(M, generator=g) + 0.5, torch.rand(M, generator=g) + 0.5
+    w = (torch.rand(N, 13 * F, generator=g) - 0.5) / (13 * F) ** 0.5
+    b, skip = torch.rand(N, generator=g), torch.rand(M, N, generator=g) - 0.5
+    cat = torch.cat([x, A, A * amp[:, None], A * att[:, None]], 1).double()
+    ref = torch.tanh(cat @ w.double().T + b.double() + skip.double())
+    Ad, segs = A.to(dev), None
+    segs = [(x.to(dev), None), (Ad, None), (Ad, amp.to(dev)), (Ad, att.to(dev))]
+    outs = []
+    try:
+        for dma in (1, 0):
+            runtime.set_option("gemm_dma", dma)
+            outs.append(runtime.linear(segs, w.to(dev), b.to(dev), skip=skip.to(dev), act="tanh").cpu())
+    finally:
+        runtime.set_option("gemm_dma", 1)
+    assert (outs[0].double() - ref).abs().max().item() < 2e-5
+    assert torch.equal(outs[0], outs[1])
