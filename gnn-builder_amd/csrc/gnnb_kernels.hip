@@ -4180,8 +4180,6 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
             if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
                 cus = prop.multiProcessorCount;
             blocks = nb > 2 ? 2 : nb;
-            if (const char *e = getenv("GNNB_G2_WG_PER_CU")) // experiments only
-                blocks = atoi(e) >= 1 && atoi(e) <= blocks ? atoi(e) : blocks;
             lds_set = lds;
         }
         long long grid = (long long)cus * blocks;
