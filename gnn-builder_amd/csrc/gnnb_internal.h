@@ -29,6 +29,8 @@ struct BatchTables {
     int32_t num_tiles;
 };
 
+constexpr int GNNB_G2_STAGE_ROWS = 48; // rows per stage of the fused 2-layer GCN kernel (3 MFMA units)
+
 struct Options {
     int tile_rows;    // node-tile granularity of the gather-aggregate kernel
     int agg_lds_kb;   // LDS budget per aggregate workgroup

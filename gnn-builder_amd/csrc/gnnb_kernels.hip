@@ -3537,6 +3537,7 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
 // and the caller's promise max_graph_nodes <= 48 - (tile_rows - 1) (validated by graph prep).
 static constexpr int G2_UNITS = 3;
 static constexpr int G2_CAP = 16 * G2_UNITS; // rows per stage
+static_assert(G2_CAP == GNNB_G2_STAGE_ROWS, "graph prep picks the tile size against this");
 static constexpr int G2_TCAP = 256;          // tile-table entries a workgroup keeps in LDS
 static constexpr int G2_WG = 512;            // 8 waves; two workgroups per CU = 4 waves per SIMD
 static constexpr int G2_NW = G2_WG / 64;

@@ -455,6 +455,11 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     t.num_edges = num_edges;
     t.max_graph_nodes_hint = ws->max_graph_nodes;
     t.tile_rows = std::max(options().tile_rows, 4);
+    // A 2-layer GCN with a promise takes the fused stack only if a whole tile (tile_rows - 1 + largest graph) fits
+    // one 48-row stage: for graphs of 34..45 nodes finer tiles (8, 4) keep that path open
+    if (options().fuse_gcn2 && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && ws->max_graph_nodes > 0)
+        while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > GNNB_G2_STAGE_ROWS)
+            t.tile_rows >>= 1;
     t.num_tiles = (num_nodes + t.tile_rows - 1) / t.tile_rows;
     if (!(pna_delta > 0.0f))
         pna_delta = 1.0f;

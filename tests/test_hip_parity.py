@@ -572,3 +572,31 @@ def test_linear_dma_path_segments_rowscale_and_ragged_edges(dev, M, N, F):
         runtime.set_option("gemm_dma", 1)
     assert (outs[0].double() - ref).abs().max().item() < 2e-5
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("promise", [34, 40, 45, 46])
+def test_fused_gcn_stack_takes_graphs_up_to_45_nodes(dev, promise):
+    """Graphs of 34..45 nodes still fit one 48-row stage when the node tiles are finer (8 or 4 rows): graph prep
+    picks the tile size from the promise.  46 is past the limit: the layer-by-layer path answers, same numbers."""
+    model = make_model("gcn", in_dim=9, hidden=128, layers=2, out_dim=128, act="relu", pools=("add", "mean", "max"), task_out=4)
+    rng = np.random.default_rng(promise)
+    graphs = []
+    for _ in range(150):
+        n = int(rng.integers(1, promise + 1))
+        e = int(rng.integers(0, 3 * n))
+        graphs.append((rng.uniform(-1, 1, (n, 9)).astype(np.float32),
+                       np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int32)))
+    graphs.append((rng.uniform(-1, 1, (promise, 9)).astype(np.float32), np.zeros((0, 2), np.int32)))  # one of the largest size
+    batch = pack_graphs(graphs)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
+    got = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    cm.check()
+    assert np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
+    # which path ran: the fused stack's timed entry refuses when it is not eligible
+    xd = torch.from_numpy(batch.x).to(dev)
+    if promise <= 45:
+        assert cm.gcn_stack_timed(xd, 2) > 0.0
+    else:
+        with pytest.raises(runtime.GnnbError):
+            cm.gcn_stack_timed(xd, 2)
