@@ -7,26 +7,36 @@ configs[1]: 2-layer GCN d=128, QM9-shaped graphs, batch 4096 per GPU.  One proce
 (torch.distributed / RCCL); graphs are independent, so ranks shard batches with no data-path
 collective and only the throughput counters are reduced (weak scaling).
 
+Launching: `python bench.py --gpus N` starts its own N rank processes (the parent never touches the
+GPU: it only spawns children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON
+line and exits non-zero if any rank fails); under `python -m torch.distributed.run --nproc-per-node N`
+the ranks are the launcher's.  WORLD_SIZE != --gpus is an error.
+
+The timed region (K steps between barrier + synchronize on both sides, MAX over ranks) is repeated
+`--repeats` times; `value` is computed from the MEDIAN repeat, min / max are reported beside it.
+
 Prints ONE JSON line on rank 0 (contract in the task prompt) with these extra objects:
-  roofline      -- the kernel that dominates the timed step.  Workload c2 (2-layer GCN with a
-                   max_graph_nodes promise) runs the fused stack kernel k_gcn2_fused (both conv layers +
-                   pooling, graphs staged in LDS, no HBM round trips): bound = fp32 MFMA, algorithmic
-                   flops 2 N (F0 h0 + h0 h1) / launch duration from HIP events on the launch stream.
-                   The other workloads run layer by layer and are dominated by the gather-aggregate
-                   kernel: bound = HBM (see next).
+  roofline      -- the kernel that dominates the timed step.  c2 (2-layer GCN with a max_graph_nodes
+                   promise) runs the fused stack kernel k_gcn2_fused: bound = fp32 MFMA.  c3: the
+                   K=N=128 update GEMM (k_linear_reg); c4 / c5: the large-K segmented GEMM (k_linear_dma);
+                   all bound = fp32 MFMA, flops / launch duration from HIP events on the launch stream.
   roofline_gather_aggregate -- the GCN gather-aggregate kernel at the full feature width (the
                    north-star kernel; every layer-by-layer model runs it): algorithmic bytes (SURVEY.md
                    8d) / measured launch duration (HIP events on the launch stream, rotating through
                    distinct buffers > 256 MiB so the Infinity Cache cannot serve the reads) against 8 TB/s.
   cpu_baseline  -- the reference's own C++ kernel library (oracle/_ref, compiled in place from
-                   /root/reference; falls back to the C oracle port when it is absent) running the
-                   same model on a bounded sample of the same graphs on ONE host core, rank 0 only.
+                   /root/reference; the C oracle port when it is absent) running the same model on a
+                   bounded sample of the same graphs on ONE host core, rank 0 only, at every N; beside it
+                   (SURVEY 8d protocol, reference experiments/build_base_benchmarks.py:158-239) the
+                   package's own PyTorch forward per graph on one pinned core and batched on all cores.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -50,6 +60,9 @@ WORKLOADS = {
                hidden=128, layers=3, pools=("add", "mean", "max"), batch=8192),
     "c5": dict(desc="2-layer GraphSAGE d=256, ogbg-molhiv-shaped graphs, batch=8192 per GPU (65536 over 8)",
                conv="sage", shape="molhiv", hidden=256, layers=2, pools=("add", "mean", "max"), batch=8192),
+    # plumbing-sized workload of the launcher test (--dry-launch); never a bench line
+    "tiny": dict(desc="launcher test: 2-layer GCN d=16, 64 QM9-shaped graphs", conv="gcn", shape="qm9",
+                 hidden=16, layers=2, pools=("add", "mean", "max"), batch=64),
 }
 
 
@@ -66,12 +79,12 @@ def build_model(w, seed=0):
                          gnnb.MLP(len(w["pools"]) * w["hidden"], shp["out"], 64, 2), None).eval()
 
 
+# --------------------------------------------------------------------------------------- roofline legs
 def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("hbm", "l3_resident")):
     """GCN gather-aggregate at `width`, timed with HIP events on the launch stream.  Returns both
     the HBM regime (inputs/outputs rotate over > 256 MiB of distinct buffers) and the regime the
     kernel sees inside the pipeline (same buffers every launch: Infinity-Cache resident)."""
     import torch
-    from gnnbuilder_amd import runtime
 
     x, coo, nptr, eptr = batch_dev
     N, E, B = int(x.shape[0]), int(coo.shape[0]), int(nptr.numel()) - 1
@@ -88,6 +101,12 @@ def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("h
             continue
         us = cm.aggregate_timed("gcn", ins[:n], outs[:n], iters)  # launches issued from C
         res[regime] = dict(us=us, gbps=alg_bytes / (us * 1e-6) / 1e9)
+    # calibration with the SAME launch shape and bytes: the library's own float4 row copy (no gather, no CSR)
+    try:
+        us = cm.aggregate_timed("copy", ins, outs, iters)
+        res["copy_same_launch_shape"] = dict(us=us, gbps=per_pair / (us * 1e-6) / 1e9)
+    except Exception:
+        pass
     del ins, outs
     return alg_bytes, res
 
@@ -104,49 +123,44 @@ def measure_update_mfma(w, N, dev, iters=100):
     y = torch.empty(N, d, device=dev)
     us = runtime.linear_timed(a, wt, b, y, "relu", iters)
     flops = 2.0 * N * d * d
-    return dict(us=us, tflops=flops / (us * 1e-6) / 1e12, frac=flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+    return dict(us=us, us_per_launch=us, tflops=flops / (us * 1e-6) / 1e12, achieved=flops / (us * 1e-6) / 1e12,
+                algorithmic_flops_per_launch=flops,
+                frac=flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, shape=f"M={N} K={d} N={d}")
 
 
-def cpu_baseline(model, batches, budget_s=12.0):
-    """Reference CPU path on ONE core over a bounded sample (~budget_s of CPU work) of the same
-    workload: the per-graph loop of the reference testbench (model_tb.cpp.jinja:189-205)."""
-    from oracle import oracle as O
+def measure_segmented_gemm(w, N, dev, iters=50):
+    """The large-K update of the workload's full-width layer as the forward runs it: SAGE [mean | x].[Wl|Wr]^T
+    (2 segments, K = 2d) or PNA [x | A | amp.A | att.A].Wpost^T (4 segments, K = 13d, per-row scalers).
+    Launches come from Python here (the kernel is > 300 us, the launch cost is ~10 us and overlaps);
+    HIP events on the launch stream."""
+    import torch
+    from gnnbuilder_amd import runtime
 
-    try:
-        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})  # as build_base_benchmarks.py:188-189
-    except Exception:
-        pass
-    spec, params = model.spec(), [p.numpy() for p in model.canonical_params()]
-    kind = "reference" if O.have_ref() else "port"
-    chunk, done, t_total = 256, 0, 0.0
-    bi, g0 = 0, 0
-    while t_total < budget_s:
-        batch = batches[bi]
-        g1 = min(g0 + chunk, batch.num_graphs)
-        sub = batch.slice(g0, g1)
-        t0 = time.perf_counter()
-        if kind == "reference":
-            try:
-                O.ref_forward_batched(spec, params, sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
-            except ValueError:  # a graph beyond the reference build's MAX_NODES / an uninstantiated size
-                kind = "port"
-                continue
-        else:
-            O.forward_batched(spec, params, sub.x, sub.coo, sub.node_ptr, sub.edge_ptr, std="pyg")
-        t_total += time.perf_counter() - t0
-        done += g1 - g0
-        g0 = g1
-        if g0 >= batch.num_graphs:
-            bi, g0 = (bi + 1) % len(batches), 0  # cycle: the sample is bounded by CPU time, not by graphs
-    what = ("the reference's own C++ kernel library (gnn_builder_lib.h, float mode, g++ -O2) compiled in place "
-            "as oracle/_ref" if kind == "reference" else "C oracle port (oracle/gnnb_oracle.c, gcc -O2)")
-    try:
-        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
-        cpu_model = "unknown"
-    return {"value": done / t_total, "unit": "graphs/s", "cores": 1, "kind": kind,
-            "sample": f"{done} graphs of the timed workload (its batches in order, cycled), one graph per call, {t_total:.1f} s of CPU time; {what}",
-            "host_cpu": cpu_model, "host_cores_available": os.cpu_count()}
+    d = w["hidden"]
+    if w["conv"] == "sage":
+        segs = [(torch.rand(N, d, device=dev) - 0.5, None), (torch.rand(N, d, device=dev) - 0.5, None)]
+        K, what = 2 * d, "SAGE [mean|x].[Wl|Wr]^T, 2 segments"
+    else:
+        agg = torch.rand(N, 4 * d, device=dev) - 0.5
+        amp, att = torch.rand(N, device=dev) + 0.5, torch.rand(N, device=dev) + 0.5
+        segs = [(torch.rand(N, d, device=dev) - 0.5, None), (agg, None), (agg, amp), (agg, att)]
+        K, what = 13 * d, "PNA [x|A|amp.A|att.A].Wpost^T, 4 segments with row scalers"
+    wt = (torch.rand(d, K, device=dev) - 0.5) / K ** 0.5
+    b = torch.rand(d, device=dev)
+    y = torch.empty(N, d, device=dev)
+    act = "relu" if w["conv"] == "sage" else "none"
+    for _ in range(3):
+        runtime.linear(segs, wt, b, None, act, out=y)
+    tm = runtime.HipTimer()
+    torch.cuda.synchronize()
+    tm.start()
+    for _ in range(iters):
+        runtime.linear(segs, wt, b, None, act, out=y)
+    tm.stop()
+    us = tm.elapsed_ms() * 1e3 / iters
+    flops = 2.0 * N * K * d
+    return dict(us_per_launch=us, achieved=flops / (us * 1e-6) / 1e12, algorithmic_flops_per_launch=flops,
+                frac=flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, shape=f"M={N} K={K} N={d}", what=what)
 
 
 def pmc_traffic(kind="aggregate"):
@@ -167,8 +181,6 @@ def pmc_traffic(kind="aggregate"):
 def measure_fused_stack(cm, batch_dev, model_dims, iters=200):
     """The fused 2-layer GCN stack + pooling kernel on one prepared batch: launches issued back to back
     from C, HIP events on the launch stream.  Returns None when the path is not eligible."""
-    from gnnbuilder_amd import runtime
-
     x, coo, nptr, eptr = batch_dev
     N, E, B = int(x.shape[0]), int(coo.shape[0]), int(nptr.numel()) - 1
     f0, h0, h1, npool = model_dims
@@ -207,41 +219,215 @@ def copy_ceiling(N, width, dev, iters=200):
     return out
 
 
+# --------------------------------------------------------------------------------------- CPU baseline legs
+def _cpu_model_name():
+    try:
+        return [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        return "unknown"
+
+
+def cpu_baseline(model, batches, budget_s=12.0):
+    """Reference CPU path on ONE core over a bounded sample (~budget_s of CPU work) of the same
+    workload: the per-graph loop of the reference testbench (model_tb.cpp.jinja:189-205)."""
+    from oracle import oracle as O
+
+    all_cpus = sorted(os.sched_getaffinity(0))
+    try:
+        os.sched_setaffinity(0, {all_cpus[0]})  # as build_base_benchmarks.py:188-189
+    except Exception:
+        pass
+    spec, params = model.spec(), [p.numpy() for p in model.canonical_params()]
+    kind = "reference" if O.have_ref() else "port"
+    chunk, done, t_total = 256, 0, 0.0
+    bi, g0 = 0, 0
+    while t_total < budget_s:
+        batch = batches[bi]
+        g1 = min(g0 + chunk, batch.num_graphs)
+        sub = batch.slice(g0, g1)
+        t0 = time.perf_counter()
+        if kind == "reference":
+            try:
+                O.ref_forward_batched(spec, params, sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
+            except ValueError:  # a graph beyond the reference build's MAX_NODES / an uninstantiated size
+                kind = "port"
+                continue
+        else:
+            O.forward_batched(spec, params, sub.x, sub.coo, sub.node_ptr, sub.edge_ptr, std="pyg")
+        t_total += time.perf_counter() - t0
+        done += g1 - g0
+        g0 = g1
+        if g0 >= batch.num_graphs:
+            bi, g0 = (bi + 1) % len(batches), 0  # cycle: the sample is bounded by CPU time, not by graphs
+    what = ("the reference's own C++ kernel library (gnn_builder_lib.h, float mode, g++ -O2) compiled in place "
+            "as oracle/_ref" if kind == "reference" else "C oracle port (oracle/gnnb_oracle.c, gcc -O2)")
+    res = {"value": done / t_total, "unit": "graphs/s", "cores": 1, "kind": kind,
+           "sample": f"{done} graphs of the timed workload (its batches in order, cycled), one graph per call, {t_total:.1f} s of CPU time; {what}",
+           "host_cpu": _cpu_model_name(), "host_cores_available": len(all_cpus)}
+    try:
+        res.update(torch_cpu_legs(model, batches[0], all_cpus))
+    finally:
+        try:
+            os.sched_setaffinity(0, set(all_cpus))
+        except Exception:
+            pass
+    return res
+
+
+def torch_cpu_legs(model, batch, all_cpus, budget_s=6.0):
+    """The package's own PyTorch forward (GNNModel.forward = the model definition; the PyG-equivalent op
+    sequence without PyG) timed as the reference times PyG-CPU (experiments/build_base_benchmarks.py:158-239):
+    (i) one graph per call, ONE pinned core, torch.utils.benchmark.Timer(...).timeit(5) per graph, mean over graphs;
+    (ii) the whole batch in one call on all host cores."""
+    import torch
+    from torch.utils import benchmark
+
+    out = {}
+    nthreads0 = torch.get_num_threads()
+    # (i) bs=1, one core (the process is already pinned to all_cpus[0])
+    torch.set_num_threads(1)
+    times, t_spent, g = [], 0.0, 0
+    with torch.no_grad():
+        while t_spent < budget_s and g < batch.num_graphs:
+            xg, cg = batch.graph(g)
+            x = torch.from_numpy(np.ascontiguousarray(xg))
+            ei = torch.from_numpy(np.ascontiguousarray(cg.T).astype(np.int64))
+            t0 = time.perf_counter()
+            m = benchmark.Timer(stmt="model(x, ei)", globals={"model": model, "x": x, "ei": ei}, num_threads=1).timeit(5)
+            t_spent += time.perf_counter() - t0
+            times.append(m.mean)
+            g += 1
+    out["torch_1core_per_graph"] = {
+        "value": 1.0 / float(np.mean(times)), "unit": "graphs/s", "cores": 1, "graphs_sampled": len(times),
+        "protocol": "GNNModel.forward per graph (bs=1), torch.set_num_threads(1) + sched_setaffinity to one core, "
+                    "torch.utils.benchmark.Timer.timeit(5).mean per graph, mean over graphs "
+                    "(reference experiments/build_base_benchmarks.py:188-208)"}
+    # (ii) batched, all cores
+    try:
+        os.sched_setaffinity(0, set(all_cpus))
+    except Exception:
+        pass
+    torch.set_num_threads(len(all_cpus))
+    x = torch.from_numpy(batch.x)
+    ei = torch.from_numpy(np.ascontiguousarray(batch.coo.T).astype(np.int64))
+    bv = torch.from_numpy(np.repeat(np.arange(batch.num_graphs), np.diff(batch.node_ptr)).astype(np.int64))
+    with torch.no_grad():
+        model(x, ei, bv)
+        trials = []
+        t_spent = 0.0
+        while len(trials) < 5 or (t_spent < budget_s / 2 and len(trials) < 50):
+            t0 = time.perf_counter()
+            model(x, ei, bv)
+            dt = time.perf_counter() - t0
+            trials.append(dt)
+            t_spent += dt
+    out["torch_allcores_batched"] = {
+        "value": batch.num_graphs / float(np.median(trials)), "unit": "graphs/s", "cores": len(all_cpus),
+        "trials": len(trials), "graphs_per_call": batch.num_graphs,
+        "protocol": "GNNModel.forward on one whole batch (index_add / scatter_reduce / F.linear), "
+                    f"torch.set_num_threads({len(all_cpus)}), median of the trials"}
+    torch.set_num_threads(nthreads0)
+    return out
+
+
+# --------------------------------------------------------------------------------------- launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """Parent of `python bench.py --gpus N` (no launcher around it): start N rank processes of this same
+    script and relay rank 0's JSON line.  The parent makes NO GPU call (no torch.cuda, no HIP library
+    load) and never exec()s; a failing rank makes it exit non-zero."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for l in (out0 or "").splitlines():
+        # rank 0's JSON line goes to stdout; anything else a library printed there (gloo / RCCL banners) to stderr
+        try:
+            json.loads(l)
+            print(l)
+        except ValueError:
+            if l.strip():
+                print(l, file=sys.stderr)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of K steps is run this many times; value = the median repeat")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches rotated per rank")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: each on its own HIP stream and workspace, so the MFMA-bound "
                          "update of one batch overlaps the HBM-bound gather / readout of the next")
+    ap.add_argument("--shard", default="rank-batches", choices=("rank-batches", "one-batch"),
+                    help="rank-batches: every rank draws its own batches of `batch` graphs; one-batch: every global "
+                         "batch of batch x N graphs is cut into contiguous node-balanced ranges "
+                         "(batching.shard_bounds), one per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the HBM-regime gather-aggregate loop (for a rocprofv3 run whose kernel average is that loop)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher / sharding / reduction plumbing on CPU (gloo): the step runs the PyTorch model "
+                         "definition instead of the HIP path; the line is marked dry_launch and is not a measurement")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        self_launch(args.gpus, sys.argv[1:])  # does not return
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(world_env or "1")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU "
+              f"(`python bench.py --gpus N` starts its own ranks)", file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
 
     from gnnbuilder_amd import runtime, synthetic
+    from gnnbuilder_amd.batching import shard_bounds
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`",
-                  file=sys.stderr)
-            sys.exit(2)
-    runtime.load_library(require_gpu=True)  # no fallback: fail loudly without the HIP path
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_launch
+    if dry:
+        dev = torch.device("cpu")
+        torch.set_num_threads(1)
+    else:
+        runtime.load_library(require_gpu=True)  # no fallback: fail loudly without the HIP path
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     w = WORKLOADS[args.workload]
     model = build_model(w)
@@ -254,28 +440,53 @@ def main():
         fused = measure_fused_stack(cm, bd, (int(batch.x.shape[1]), w["hidden"], w["hidden"], len(w["pools"]))) \
             if w["conv"] == "gcn" and w["layers"] == 2 else None
         print(json.dumps({"roofline_only": True, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"],
-                          "fused_stack": fused}))
+                          "copy_same_launch_shape": agg.get("copy_same_launch_shape"), "fused_stack": fused}))
         return
-    # rank-distinct synthetic batches (weak scaling: every GPU gets its own `batch` graphs per step)
-    batches = [synthetic.make_batch(w["shape"], w["batch"], seed=1000 * rank + i) for i in range(args.batches)]
+
+    if args.shard == "one-batch":
+        # every rank draws the SAME global batches (batch x world graphs) and keeps its node-balanced range
+        batches = []
+        for i in range(args.batches):
+            glob = synthetic.make_batch(w["shape"], w["batch"] * world, seed=77000 + i)
+            g0, g1 = shard_bounds(glob.node_ptr, world)[rank]
+            batches.append(glob.slice(g0, g1))
+            del glob
+    else:
+        # rank-distinct synthetic batches (weak scaling: every GPU gets its own `batch` graphs per step)
+        batches = [synthetic.make_batch(w["shape"], w["batch"], seed=1000 * rank + i) for i in range(args.batches)]
     maxn = max(b.num_nodes for b in batches)
     maxe = max(b.num_edges for b in batches)
+    maxb = max(b.num_graphs for b in batches)
     nstreams = max(1, args.streams)
     # promise on the largest graph (validated on the device by every graph prep): lets molecule-sized
     # graphs be staged whole in LDS (fused conv stack)
     max_graph = int(max(np.diff(b.node_ptr).max() for b in batches))
-    cms = [runtime.CompiledModel.from_model(model, w["batch"], maxn, maxe, max_graph_nodes=max_graph)
-           for _ in range(nstreams)]
-    cm = cms[0]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
-    dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr)) for b in batches]
-    outs = [torch.empty(w["batch"], cm.out_dim, device=dev) for _ in batches]
-    torch.cuda.synchronize()
+    if dry:
+        import torch.nn  # noqa: F401
 
-    def step(i):
-        # step i = one batched forward of batch i (mod the rotation) on stream i mod nstreams
-        k = i % len(dev_batches)
-        cms[i % nstreams].forward(*dev_batches[k], out=outs[k], stream=streams[i % nstreams])
+        dev_batches = [(torch.from_numpy(b.x), torch.from_numpy(np.ascontiguousarray(b.coo.T).astype(np.int64)),
+                        torch.from_numpy(np.repeat(np.arange(b.num_graphs), np.diff(b.node_ptr)).astype(np.int64)))
+                       for b in batches]
+        outs = [None] * len(batches)
+
+        def step(i):
+            k = i % len(dev_batches)
+            with torch.no_grad():
+                outs[k] = model(*dev_batches[k])
+        cms, streams, cm = [], [], None
+    else:
+        cms = [runtime.CompiledModel.from_model(model, maxb, maxn, maxe, max_graph_nodes=max_graph)
+               for _ in range(nstreams)]
+        cm = cms[0]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
+        dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr)) for b in batches]
+        outs = [torch.empty(b.num_graphs, cm.out_dim, device=dev) for b in batches]
+        torch.cuda.synchronize()
+
+        def step(i):
+            # step i = one batched forward of batch i (mod the rotation) on stream i mod nstreams
+            k = i % len(dev_batches)
+            cms[i % nstreams].forward(*dev_batches[k], out=outs[k], stream=streams[i % nstreams])
 
     for i in range(args.warmup):
         step(i)
@@ -286,61 +497,68 @@ def main():
         if world > 1:
             dist.barrier()
 
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-
-    graphs_done = float(args.steps * w["batch"])
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    def reduce_max(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # RCCL over xGMI: 8 bytes, latency only
-        elapsed = float(t.item())
-        c = torch.tensor([graphs_done], device=dev, dtype=torch.float64)
+        return float(t.item())
+
+    def timed_region():
+        sync()
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        sync()
+        barrier()
+        sync()
+        return reduce_max(time.perf_counter() - t0)
+
+    repeats = max(1, args.repeats)
+    times = [timed_region() for _ in range(repeats)]
+    elapsed = float(np.median(times))
+
+    graphs_done = float(sum(batches[i % len(batches)].num_graphs for i in range(args.steps)))
+    rccl_ranks = 1
+    if world > 1:
+        c = torch.tensor([graphs_done, 1.0], device=dev, dtype=torch.float64)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        graphs_done = float(c.item())
+        graphs_done, rccl_ranks = float(c[0].item()), int(round(float(c[1].item())))
 
     # opt-in math mode (NOT the headline): the wide update of the fused GCN stack as six bf16 MFMA products of
     # an exact 3-way split of both fp32 operands, fp32 accumulate; same steps, same batches
     split_rate = None
-    if w["conv"] == "gcn" and w["layers"] == 2 and not args.no_roofline:
-        torch.cuda.synchronize()
+    if not dry and w["conv"] == "gcn" and w["layers"] == 2 and not args.no_roofline:
         runtime.set_option("math", 1)
         for i in range(args.warmup):
             step(i)
-        torch.cuda.synchronize()
-        barrier()
-        ts = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - ts
+        el2 = timed_region()
         runtime.set_option("math", 0)
-        if world > 1:
-            t2 = torch.tensor([el2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-            el2 = float(t2.item())
         split_rate = graphs_done / el2
         split_ms = el2 / args.steps * 1e3
 
     # the prep-excluded rate (topology tables re-used; only features change)
-    x0, coo0, np0, ep0 = dev_batches[0]
-    cm.graph_prep(coo0, np0, ep0, int(x0.shape[0]))
-    for _ in range(5):
-        cm.forward_prepared(x0, out=outs[0])
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    nprep = max(args.steps // 2, 10)
-    for _ in range(nprep):
-        cm.forward_prepared(x0, out=outs[0])
-    torch.cuda.synchronize()
-    ms_noprep = (time.perf_counter() - t1) / nprep * 1e3
+    ms_noprep = None
+    if not dry:
+        x0, coo0, np0, ep0 = dev_batches[0]
+        cm.graph_prep(coo0, np0, ep0, int(x0.shape[0]))
+        for _ in range(5):
+            cm.forward_prepared(x0, out=outs[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nprep = max(args.steps // 2, 10)
+        for _ in range(nprep):
+            cm.forward_prepared(x0, out=outs[0])
+        torch.cuda.synchronize()
+        ms_noprep = (time.perf_counter() - t1) / nprep * 1e3
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()  # every collective is done: rank 0 finishes the single-GPU legs alone
+    if rank != 0:
+        return
 
     result = {
         "metric": "graphs/sec whole-node (batched QM9, GCN d=128)" if args.workload == "c2"
@@ -360,10 +578,21 @@ def main():
                    "nodes_per_batch": int(np.mean([b.num_nodes for b in batches])),
                    "edges_per_batch": int(np.mean([b.num_edges for b in batches])),
                    "parallelism": f"graph-sharded x{world}, no data-path collective",
+                   "shard": args.shard, "rccl_ranks": rccl_ranks,
                    "batches_in_flight_per_gpu": nstreams, "max_graph_nodes_promise": max_graph,
                    "csr_build_in_timed_region": True},
+        "repeats": {"n": repeats, "statistic": "median", "steps_per_repeat": args.steps,
+                    "value_min": graphs_done / max(times), "value_max": graphs_done / min(times),
+                    "ms_per_step_all": [t / args.steps * 1e3 for t in times]},
         "ms_per_step_prepared_topology": ms_noprep,
     }
+    if dry:
+        result["dry_launch"] = True
+        result["dtype"] = "f32 (CPU stand-in)"
+        result["config"]["note"] = ("launcher / sharding / reduction plumbing on CPU over gloo; the step is the PyTorch "
+                                    "model definition, NOT the HIP path: not a measurement")
+        print(json.dumps(result))
+        return
     if split_rate is not None:
         result["opt_in_math_bf16x6"] = {
             "value": split_rate, "unit": "graphs/s", "ms_per_step": split_ms,
@@ -373,8 +602,11 @@ def main():
                         "reference 1.4e-7; tests/accuracy_math_modes.py)",
         }
 
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         alg_bytes, agg = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev)
+        ceiling = copy_ceiling(batches[0].num_nodes, w["hidden"], dev)
+        if "copy_same_launch_shape" in agg:
+            ceiling["own_float4_copy_same_launch_shape_hbm"] = agg["copy_same_launch_shape"]
         gather = {
             "kernel": "k_aggregate_shot<GCN> (gather-aggregate, width %d)" % w["hidden"],
             "bound": "hbm", "achieved": agg["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -383,10 +615,12 @@ def main():
             "regime": "inputs/outputs rotate over >256 MiB of distinct buffers (HBM-served); launches issued "
                       "back to back from C, HIP events on the launch stream",
             "in_pipeline_l3_resident": agg["l3_resident"],
-            "copy_ceiling_same_bytes": copy_ceiling(batches[0].num_nodes, w["hidden"], dev),
+            "copy_ceiling_same_bytes": ceiling,
         }
         fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w["hidden"],
                                                         len(w["pools"]))) if w["conv"] == "gcn" and w["layers"] == 2 else None
+        upd = dict(kernel="k_linear_reg (fp32 MFMA), full-width layer update", bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS,
+                   unit="TFLOP/s", traffic=None, **measure_update_mfma(w, batches[0].num_nodes, dev))
         if fused is not None:
             # the step runs the fused stack: that kernel dominates it and is bound by the fp32 matrix rate
             result["roofline"] = {
@@ -398,21 +632,21 @@ def main():
                 "note": "flops = 2 N (F0 h0 + h0 h1), the two dense updates on v_mfma_f32_16x16x4_f32; HIP events on "
                         "the launch stream, launches issued back to back from C on one prepared batch",
             }
-            result["roofline_gather_aggregate"] = gather
+        elif w["conv"] in ("sage", "pna"):
+            # layer-wise workloads with a wide concatenated update: the large-K segmented GEMM dominates the step
+            result["roofline"] = dict(kernel="k_linear_dma (fp32 MFMA 32x32x2, chunks global -> LDS by DMA)", bound="mfma",
+                                      peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", traffic=None,
+                                      **measure_segmented_gemm(w, batches[0].num_nodes, dev))
+        elif w["conv"] == "gin":
+            result["roofline"] = upd
         else:
             result["roofline"] = gather
-        result["roofline_update"] = dict(kernel="k_linear_reg (fp32 MFMA 16x16x4), full-width layer update",
-                                         bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                                         **measure_update_mfma(w, batches[0].num_nodes, dev))
-    if world > 1:
-        dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["roofline_gather_aggregate"] = gather
+        result["roofline_update"] = upd
+    if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(model, batches)
 
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    print(json.dumps(result))
 
 
 if __name__ == "__main__":
