@@ -80,7 +80,7 @@ def build_model(w, seed=0):
 
 
 # --------------------------------------------------------------------------------------- roofline legs
-def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("hbm", "l3_resident")):
+def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("hbm", "l3_resident"), kind="gcn"):
     """GCN gather-aggregate at `width`, timed with HIP events on the launch stream.  Returns both
     the HBM regime (inputs/outputs rotate over > 256 MiB of distinct buffers) and the regime the
     kernel sees inside the pipeline (same buffers every launch: Infinity-Cache resident)."""
@@ -99,7 +99,7 @@ def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("h
     for regime, n in (("hbm", nbuf), ("l3_resident", 1)):
         if regime not in regimes:
             continue
-        us = cm.aggregate_timed("gcn", ins[:n], outs[:n], iters)  # launches issued from C
+        us = cm.aggregate_timed(kind, ins[:n], outs[:n], iters)  # launches issued from C
         res[regime] = dict(us=us, gbps=alg_bytes / (us * 1e-6) / 1e9)
     # calibration with the SAME launch shape and bytes: the library's own float4 row copy (no gather, no CSR)
     try:
@@ -228,11 +228,20 @@ def _cpu_model_name():
 
 
 def cpu_baseline(model, batches, budget_s=12.0):
-    """Reference CPU path on ONE core over a bounded sample (~budget_s of CPU work) of the same
-    workload: the per-graph loop of the reference testbench (model_tb.cpp.jinja:189-205)."""
+    """CPU legs beside the GPU figure, rank 0, bounded samples of the same workload.
+    `value`: the reference CPU path on ONE core -- the per-graph loop of the reference testbench
+    (model_tb.cpp.jinja:189-205) over the reference's own C++ kernel library (oracle/_ref).
+    Beside it the package's own PyTorch forward timed as the reference times PyG-CPU
+    (experiments/build_base_benchmarks.py:158-239): per graph on one pinned core, and batched on all cores.
+    The all-core leg runs FIRST: threads created after the process is pinned inherit the one-core mask."""
     from oracle import oracle as O
 
     all_cpus = sorted(os.sched_getaffinity(0))
+    extra = {}
+    try:
+        extra.update(torch_allcores_leg(model, batches[0], len(all_cpus)))
+    except Exception as e:  # never lose the bench line to a baseline leg
+        extra["torch_allcores_batched"] = {"error": repr(e)}
     try:
         os.sched_setaffinity(0, {all_cpus[0]})  # as build_base_benchmarks.py:188-189
     except Exception:
@@ -265,69 +274,69 @@ def cpu_baseline(model, batches, budget_s=12.0):
            "sample": f"{done} graphs of the timed workload (its batches in order, cycled), one graph per call, {t_total:.1f} s of CPU time; {what}",
            "host_cpu": _cpu_model_name(), "host_cores_available": len(all_cpus)}
     try:
-        res.update(torch_cpu_legs(model, batches[0], all_cpus))
-    finally:
-        try:
-            os.sched_setaffinity(0, set(all_cpus))
-        except Exception:
-            pass
-    return res
-
-
-def torch_cpu_legs(model, batch, all_cpus, budget_s=6.0):
-    """The package's own PyTorch forward (GNNModel.forward = the model definition; the PyG-equivalent op
-    sequence without PyG) timed as the reference times PyG-CPU (experiments/build_base_benchmarks.py:158-239):
-    (i) one graph per call, ONE pinned core, torch.utils.benchmark.Timer(...).timeit(5) per graph, mean over graphs;
-    (ii) the whole batch in one call on all host cores."""
-    import torch
-    from torch.utils import benchmark
-
-    out = {}
-    nthreads0 = torch.get_num_threads()
-    # (i) bs=1, one core (the process is already pinned to all_cpus[0])
-    torch.set_num_threads(1)
-    times, t_spent, g = [], 0.0, 0
-    with torch.no_grad():
-        while t_spent < budget_s and g < batch.num_graphs:
-            xg, cg = batch.graph(g)
-            x = torch.from_numpy(np.ascontiguousarray(xg))
-            ei = torch.from_numpy(np.ascontiguousarray(cg.T).astype(np.int64))
-            t0 = time.perf_counter()
-            m = benchmark.Timer(stmt="model(x, ei)", globals={"model": model, "x": x, "ei": ei}, num_threads=1).timeit(5)
-            t_spent += time.perf_counter() - t0
-            times.append(m.mean)
-            g += 1
-    out["torch_1core_per_graph"] = {
-        "value": 1.0 / float(np.mean(times)), "unit": "graphs/s", "cores": 1, "graphs_sampled": len(times),
-        "protocol": "GNNModel.forward per graph (bs=1), torch.set_num_threads(1) + sched_setaffinity to one core, "
-                    "torch.utils.benchmark.Timer.timeit(5).mean per graph, mean over graphs "
-                    "(reference experiments/build_base_benchmarks.py:188-208)"}
-    # (ii) batched, all cores
+        extra.update(torch_1core_leg(model, batches[0]))
+    except Exception as e:
+        extra["torch_1core_per_graph"] = {"error": repr(e)}
     try:
         os.sched_setaffinity(0, set(all_cpus))
     except Exception:
         pass
-    torch.set_num_threads(len(all_cpus))
+    res.update(extra)
+    return res
+
+
+def torch_allcores_leg(model, batch, ncpus, budget_s=4.0):
+    """GNNModel.forward (the model definition; the PyG-equivalent op sequence without PyG) on one whole batch,
+    torch's default intra-op thread pool on every core the process may use."""
+    import torch
+
+    nthreads = torch.get_num_threads()
     x = torch.from_numpy(batch.x)
     ei = torch.from_numpy(np.ascontiguousarray(batch.coo.T).astype(np.int64))
     bv = torch.from_numpy(np.repeat(np.arange(batch.num_graphs), np.diff(batch.node_ptr)).astype(np.int64))
     with torch.no_grad():
         model(x, ei, bv)
-        trials = []
-        t_spent = 0.0
-        while len(trials) < 5 or (t_spent < budget_s / 2 and len(trials) < 50):
+        trials, t_spent = [], 0.0
+        while len(trials) < 5 or (t_spent < budget_s and len(trials) < 50):
             t0 = time.perf_counter()
             model(x, ei, bv)
             dt = time.perf_counter() - t0
             trials.append(dt)
             t_spent += dt
-    out["torch_allcores_batched"] = {
-        "value": batch.num_graphs / float(np.median(trials)), "unit": "graphs/s", "cores": len(all_cpus),
-        "trials": len(trials), "graphs_per_call": batch.num_graphs,
-        "protocol": "GNNModel.forward on one whole batch (index_add / scatter_reduce / F.linear), "
-                    f"torch.set_num_threads({len(all_cpus)}), median of the trials"}
-    torch.set_num_threads(nthreads0)
-    return out
+    return {"torch_allcores_batched": {
+        "value": batch.num_graphs / float(np.median(trials)), "unit": "graphs/s", "cores": ncpus,
+        "torch_threads": nthreads, "trials": len(trials), "graphs_per_call": batch.num_graphs,
+        "protocol": "GNNModel.forward on one whole batch (index_add / scatter_reduce / F.linear), torch's default "
+                    "thread pool, median of the trials"}}
+
+
+def torch_1core_leg(model, batch, budget_s=6.0):
+    """One graph per call on ONE pinned core: torch.utils.benchmark.Timer(...).timeit(5) per graph, mean over the
+    graphs (reference experiments/build_base_benchmarks.py:188-208, 221)."""
+    import torch
+    from torch.utils import benchmark
+
+    nthreads0 = torch.get_num_threads()
+    torch.set_num_threads(1)
+    times, t_spent, g = [], 0.0, 0
+    try:
+        with torch.no_grad():
+            while t_spent < budget_s and g < batch.num_graphs:
+                xg, cg = batch.graph(g)
+                x = torch.from_numpy(np.ascontiguousarray(xg))
+                ei = torch.from_numpy(np.ascontiguousarray(cg.T).astype(np.int64))
+                t0 = time.perf_counter()
+                m = benchmark.Timer(stmt="model(x, ei)", globals={"model": model, "x": x, "ei": ei}, num_threads=1).timeit(5)
+                t_spent += time.perf_counter() - t0
+                times.append(m.mean)
+                g += 1
+    finally:
+        torch.set_num_threads(nthreads0)
+    return {"torch_1core_per_graph": {
+        "value": 1.0 / float(np.mean(times)), "unit": "graphs/s", "cores": 1, "graphs_sampled": len(times),
+        "protocol": "GNNModel.forward per graph (bs=1), torch.set_num_threads(1) + sched_setaffinity to one core, "
+                    "torch.utils.benchmark.Timer.timeit(5).mean per graph, mean over graphs "
+                    "(reference experiments/build_base_benchmarks.py:188-208)"}}
 
 
 # --------------------------------------------------------------------------------------- launcher

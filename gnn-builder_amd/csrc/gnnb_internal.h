@@ -11,7 +11,8 @@ namespace gnnb {
 
 // Tables produced by graph prep for one batch (all device pointers, owned by a workspace).
 struct BatchTables {
-    int32_t *row_ptr;    // [N+1] CSR by destination, batch-global
+    int32_t *row_ptr;    // [N+1] START of every node's CSR row (batch-global); the row's length is node_rec[2v].y --
+                         //       dropped edges leave a gap at the end of a graph's segment, so differences are not degrees
     int32_t *col;        // [E]   source node (batch-global id) of every in-edge, stable COO order
     int4 *node_rec;      // [2N]  per node {rp0, deg, j0, j1}{j2, j3, -, -}: CSR row start, in-degree and
                          //       its first four sources, so one 32-B read feeds the whole gather
@@ -19,11 +20,13 @@ struct BatchTables {
     float *amp;          // [N]   PNA amplification  log(max(d,1)+1)/delta
     float *att;          // [N]   PNA attenuation    delta/log(max(d,1)+1)
     int32_t *tile_first; // [T+1] first node of node-tile t; tiles are cut at graph boundaries
-    int32_t *tile_edge;  // [T+1] row_ptr[tile_first[t]] (first CSR entry of the tile)
+    int32_t *tile_edge;  // [T+1] first CSR slot of the tile (= edge_ptr of its first graph, clamped)
     int32_t *tile_graph; // [T+1] index of the graph that starts at tile_first[t] (B past the end)
     int32_t max_graph_nodes_hint; // caller's promise (0 = unknown); validated on device by prep
     int32_t *err;        // [1]   != 0 when the batch was malformed
-    const int32_t *node_ptr; // [B+1] caller's graph_node_ptr (device)
+    const int32_t *node_ptr; // [B+1] caller's graph_node_ptr (device): read by graph prep ONLY
+    int32_t *graph_ptr;      // [B+1] the same clamped to [0, N] by graph prep: what every later kernel reads, so
+                             //       that a malformed node_ptr cannot send a pooling loop out of the buffers
     int32_t num_graphs, num_nodes, num_edges;
     int32_t tile_rows;   // target rows per tile
     int32_t num_tiles;
@@ -32,15 +35,15 @@ struct BatchTables {
 constexpr int GNNB_G2_STAGE_ROWS = 48; // rows per stage of the fused 2-layer GCN kernel (3 MFMA units)
 
 struct Options {
-    int tile_rows;    // node-tile granularity of the gather-aggregate kernel
-    int agg_lds_kb;   // LDS budget per aggregate workgroup
-    int agg_tiles_per_wg;
-    int agg_overshoot; // LDS rows reserved for the graph that straddles a tile's end
-    int agg_variant;   // 0 = CSR-streamed gather, 1 = LDS-staged small tiles, 2 = pipelined LDS-DMA (loader wave),
-                       // 3 = record-streamed, 4 = LDS-DMA single burst, 5 = pipelined LDS-DMA (untracked, counted
-                       // waits), 6 = one-shot LDS-DMA per tile group + node records (default)
-    int agg_rows_per_wg; // streaming variant: destination rows per workgroup
-    int agg_xcd_remap; // remap block ids so each XCD owns a contiguous run of row chunks
+    int tile_rows;    // node-tile granularity (rows; tiles are cut at graph boundaries)
+    int agg_lds_kb;   // LDS budget of the gather-aggregate kernel: per CU (ring form) / per workgroup (one-shot form)
+    int agg_tiles_per_wg; // one-shot form: node tiles per workgroup
+    int agg_variant;   // 0 = ring form: persistent, per-wave software pipeline, no workgroup barrier (default);
+                       // 1 = one-shot form: a short-lived workgroup per tile group
+    int agg_ring_waves;   // ring form: waves per workgroup (0 = automatic: the most whose stages hold a graph)
+    int agg_ring_slots;   // ring form: LDS stages per wave
+    int agg_ring_wg_per_cu;
+    int agg_nt_store;     // ring form: non-temporal output stores
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
     int gemm_max_wg_per_cu;
     int gemm_dma;      // 1 = large-K GEMM through LDS-DMA when every segment is plain (default)
@@ -56,8 +59,9 @@ struct Options {
 };
 Options &options();
 
+// drop_self_loops: edges (v, v) are not entered into the tables (GCN: PyG's add_remaining_self_loops)
 hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
-                             BatchTables &t, float pna_delta, hipStream_t s);
+                             BatchTables &t, float pna_delta, int drop_self_loops, hipStream_t s);
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s);

@@ -62,7 +62,7 @@ static constexpr int PREP_REG_CHUNKS = 4;
 __device__ void prep_graph_scan(
     const int2 *__restrict__ coo, int n0, int n1, int e0, int e1, int32_t *__restrict__ row_ptr,
     int32_t *__restrict__ col, int4 *__restrict__ node_rec, float *__restrict__ dinv,
-    float *__restrict__ amp, float *__restrict__ att, float delta, int32_t *__restrict__ err)
+    float *__restrict__ amp, float *__restrict__ att, float delta, int drop_self, int32_t *__restrict__ err)
 {
     const int lane = threadIdx.x & 63;
 
@@ -81,7 +81,7 @@ __device__ void prep_graph_scan(
             const int2 e = coo[e0 + i];
             if (e.x < n0 || e.x >= n1 || e.y < n0 || e.y >= n1)
                 bad = true;
-            else {
+            else if (!(drop_self && e.x == e.y)) { // GCN: an explicit self loop is not an edge (PyG add_remaining_self_loops)
                 es = e.x;
                 ed = e.y;
             }
@@ -137,10 +137,8 @@ __device__ void prep_graph_scan(
             const int dcl = cnt < 1 ? 1 : cnt; // gnn_builder_lib.h:1972-1982
             const float logd = logf((float)(dcl + 1));
             if (delta > 0.0f) { // (delta <= 0: the model has no PNA layer, the scalers are not needed)
-                if (delta > 0.0f) { // (delta <= 0: the model has no PNA layer, the scalers are not needed)
-                    amp[v] = logd / delta;
-                    att[v] = delta / logd;
-                }
+                amp[v] = logd / delta;
+                att[v] = delta / logd;
             }
         }
         // ---- stable fill: edges are visited in COO order; the first four sources also go into
@@ -210,7 +208,8 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     int32_t *__restrict__ col, int4 *__restrict__ node_rec, float *__restrict__ dinv,
     float *__restrict__ amp, float *__restrict__ att, float delta,
     int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int32_t *__restrict__ tile_graph,
-    int tile_rows, int num_tiles, int max_graph_nodes_hint, int32_t *__restrict__ err)
+    int32_t *__restrict__ graph_ptr, int tile_rows, int num_tiles, int max_graph_nodes_hint, int drop_self,
+    int32_t *__restrict__ err)
 {
     __shared__ int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node
     const int lane = threadIdx.x & 63;
@@ -232,29 +231,61 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             tile_edge[t] = pe;
             tile_graph[t] = g;
         }
+        if (lane == 0)
+            graph_ptr[g] = p; // the clamped copy later kernels read
     }
+    // Containment of malformed batches: whatever node_ptr / edge_ptr hold, every row in [0, N) leaves this
+    // kernel with a record that later kernels can follow without leaving the buffers -- start and start + deg
+    // inside [0, E], sources inside [0, N).  A graph's ranges are CLAMPED instead of rejected (any row r < N lies
+    // in some pair node_ptr[g] <= r < node_ptr[g+1] when node_ptr runs from 0 to N; rows before node_ptr[0] or
+    // after node_ptr[B] are given empty records by the last wave), only edges inside the clamped node range are
+    // accepted, and the results of a flagged batch are unspecified but in range.
+    auto empty_rows = [&](int r0, int r1) {
+        for (int v = r0 + lane; v < r1; v += 64) {
+            row_ptr[v] = 0;
+            node_rec[2 * (size_t)v] = make_int4(0, 0, v, v);
+            node_rec[2 * (size_t)v + 1] = make_int4(v, v, 0, 0);
+            dinv[v] = 1.0f;
+            if (delta > 0.0f) {
+                amp[v] = logf(2.0f) / delta;
+                att[v] = delta / logf(2.0f);
+            }
+        }
+    };
     if (g == B) {
+        const int first = node_ptr[0], last = node_ptr[B];
         if (lane == 0) {
             row_ptr[N] = E;
-            if (node_ptr[B] != N || edge_ptr[B] != E || node_ptr[0] != 0 || edge_ptr[0] != 0)
+            if (last != N || edge_ptr[B] != E || first != 0 || edge_ptr[0] != 0)
                 atomicOr(err, 1);
         }
+        if (first > 0)
+            empty_rows(0, min(first, N));
+        if (last < N)
+            empty_rows(max(last, 0), N);
         return;
     }
 
     GNNB_STAMP(0);
-    const int n0 = node_ptr[g], n1 = node_ptr[g + 1];
-    const int e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
+    int n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    int e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
     if (n0 > n1 || e0 > e1 || n1 > N || e1 > E || n0 < 0 || e0 < 0) {
         if (lane == 0)
             atomicOr(err, 2);
-        return;
+        n0 = min(max(n0, 0), N);
+        n1 = min(max(n1, 0), N);
+        e0 = min(max(e0, 0), E);
+        e1 = min(max(e1, 0), E);
+        if (n0 >= n1)
+            return; // covers no row
+        if (e0 > e1)
+            e1 = e0; // no usable edge range: the rows get empty records
     }
     const int n = n1 - n0, ne = e1 - e0;
     if (max_graph_nodes_hint > 0 && n > max_graph_nodes_hint && lane == 0)
         atomicOr(err, 8); // the caller's max_graph_nodes promise does not hold for this batch
     if (n > PREP_FAST_NODES || ne > PREP_FAST_EDGES) { // wave-uniform
-        prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, node_rec, dinv, amp, att, delta, err);
+        prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, node_rec, dinv, amp, att, delta, drop_self, err);
         return;
     }
 
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             const int2 e = coo[e0 + i];
             if (e.x < n0 || e.x >= n1 || e.y < n0 || e.y >= n1)
                 bad = true;
-            else {
+            else if (!(drop_self && e.x == e.y)) { // GCN: an explicit self loop is not an edge (see gnnb_hip.h)
                 es[c] = e.x;
                 ed[c] = e.y - n0; // local destination
             }
@@ -387,7 +418,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
 }
 
 hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
-                             BatchTables &t, float pna_delta, hipStream_t s)
+                             BatchTables &t, float pna_delta, int drop_self_loops, hipStream_t s)
 {
     // t.err is zeroed when the workspace is created and again whenever it is read
     // (gnnb_workspace_check), so no per-batch memset node sits in front of this launch
@@ -396,13 +427,13 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
     if (t.max_graph_nodes_hint > 0 && t.max_graph_nodes_hint <= 64)
         hipLaunchKernelGGL(k_graph_prep<64>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.node_rec,
-                           t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, t.err);
+                           t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
+                           t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err);
     else
         hipLaunchKernelGGL(k_graph_prep<256>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.node_rec,
-                           t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, t.err);
+                           t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
+                           t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err);
     return hipGetLastError();
 }
 
@@ -503,552 +534,8 @@ __device__ inline Vf<1> pyg_std(const Vf<1> &m2, const Vf<1> &m)
     return r;
 }
 
-template <int MODE, int VEC>
-__global__ __launch_bounds__(WG) void k_aggregate(
-    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
-    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const int32_t *__restrict__ tile_first, int num_tiles, int tiles_per_wg, int w, int glog2,
-    int rows_cap, int edge_cap, float eps)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *sx = reinterpret_cast<float *>(smem);
-    // rows_cap*w*4 is kept a multiple of 16 by the launcher
-    int32_t *srp = reinterpret_cast<int32_t *>(sx + (size_t)rows_cap * w);
-    int32_t *scol = srp + ((rows_cap + 1 + 3) & ~3);
-
-    const int tid = threadIdx.x;
-    const int t0 = blockIdx.x * tiles_per_wg;
-    const int t1 = min(t0 + tiles_per_wg, num_tiles);
-    const int nb = tile_first[t0];
-    const int ne = tile_first[t1];
-    const int rows = ne - nb;
-    if (rows <= 0)
-        return;
-    const int eb = row_ptr[nb];
-    const int nedges = row_ptr[ne] - eb;
-    const bool staged = rows <= rows_cap;   // workgroup-uniform
-    const bool ecached = nedges <= edge_cap; // workgroup-uniform
-
-    if (staged) {
-        // one pass over the tile's node rows: the only HBM read of x this launch makes
-        const size_t base = (size_t)nb * w;
-        const int total = rows * w;
-        if (VEC == 4) {
-            const float4 *src = reinterpret_cast<const float4 *>(x + base);
-            float4 *dst = reinterpret_cast<float4 *>(sx);
-            const int nv = total >> 2;
-            int i = tid;
-            // 4 independent 16-B loads in flight per lane
-            for (; i + 3 * WG < nv; i += 4 * WG) {
-                float4 a = src[i], b = src[i + WG], c = src[i + 2 * WG], d = src[i + 3 * WG];
-                dst[i] = a;
-                dst[i + WG] = b;
-                dst[i + 2 * WG] = c;
-                dst[i + 3 * WG] = d;
-            }
-            for (; i < nv; i += WG)
-                dst[i] = src[i];
-        } else {
-            for (int i = tid; i < total; i += WG)
-                sx[i] = x[base + i];
-        }
-        for (int i = tid; i <= rows; i += WG)
-            srp[i] = row_ptr[nb + i];
-    }
-    if (ecached)
-        for (int i = tid; i < nedges; i += WG)
-            scol[i] = col[eb + i];
-    __syncthreads();
-
-    const int nvec = w / VEC;
-    const int G = 1 << glog2;
-    const int groups = WG >> glog2;
-    const int grp = tid >> glog2;
-    const int gl = tid & (G - 1);
-    typedef Vf<VEC> V;
-
-    for (int r = grp; r < rows; r += groups) {
-        const int node = nb + r;
-        const int rp0 = staged ? srp[r] : row_ptr[node];
-        const int rp1 = staged ? srp[r + 1] : row_ptr[node + 1];
-        const int deg = rp1 - rp0;
-        for (int f = gl; f < nvec; f += G) {
-            const int fo = f * VEC;
-            const V xi = staged ? V::load(sx + (size_t)r * w + fo) : V::load(x + (size_t)node * w + fo);
-            V acc = V::splat(0.0f);
-            V vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f), q = V::splat(0.0f);
-            if (MODE == GNNB_AGG_PNA)
-                q = V::load(selfq + (size_t)node * w + fo);
-            const float di = 1.0f + (float)deg;
-            for (int k = rp0; k < rp1; k++) {
-                const int j = ecached ? scol[k - eb] : col[k];
-                const int jr = j - nb;
-                const V xj = staged ? V::load(sx + (size_t)jr * w + fo) : V::load(x + (size_t)j * w + fo);
-                if (MODE == GNNB_AGG_GCN) {
-                    const int dj_i = staged ? (srp[jr + 1] - srp[jr]) : (row_ptr[j + 1] - row_ptr[j]);
-                    const float dj = 1.0f + (float)dj_i;
-                    const float sc = 1.0f / sqrtf(di * dj);
-                    acc = vadd(acc, vmul(xj, V::splat(sc)));
-                } else if (MODE == GNNB_AGG_PNA) {
-                    const V h = vadd(q, xj);
-                    if (k == rp0) {
-                        vmx = h;
-                        vmn = h;
-                    } else {
-                        vmx = vmax(vmx, h);
-                        vmn = vmin(vmn, h);
-                    }
-                    acc = vadd(acc, h);
-                    s2 = vadd(s2, vmul(h, h));
-                } else {
-                    acc = vadd(acc, xj);
-                }
-            }
-            if (MODE == GNNB_AGG_GCN) {
-                const float sself = 1.0f / sqrtf(di * di);
-                acc = vadd(acc, vmul(xi, V::splat(sself)));
-                acc.store(out + (size_t)node * w + fo);
-            } else if (MODE == GNNB_AGG_SUM) {
-                acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
-                acc.store(out + (size_t)node * w + fo);
-            } else if (MODE == GNNB_AGG_MEAN) {
-                if (deg > 0)
-                    acc = vdiv(acc, V::splat((float)deg));
-                acc.store(out + (size_t)node * w + fo);
-            } else {
-                V mean = V::splat(0.0f), sd = V::splat(0.0f);
-                if (deg > 0) {
-                    const V dn = V::splat((float)deg);
-                    mean = vdiv(acc, dn);
-                    sd = pyg_std(vdiv(s2, dn), mean);
-                }
-                float *o = out + (size_t)node * 4 * w + fo;
-                vmx.store(o);
-                vmn.store(o + w);
-                mean.store(o + 2 * (size_t)w);
-                sd.store(o + 3 * (size_t)w);
-            }
-        }
-    }
-}
-
-template <int MODE, int VEC>
-static hipError_t launch_aggregate_t(const BatchTables &t, const float *x, const float *selfq,
-                                     float *out, int w, float eps, hipStream_t s)
-{
-    const Options &o = options();
-    const int nvec = w / VEC;
-    int glog2 = 2;
-    while ((1 << glog2) < nvec && glog2 < 6)
-        glog2++;
-    const int tpw = o.agg_tiles_per_wg < 1 ? 1 : o.agg_tiles_per_wg;
-    // LDS budget -> staged rows; keep the float region a multiple of 16 bytes
-    size_t budget = (size_t)o.agg_lds_kb * 1024;
-    int rows_cap = (int)(budget / ((size_t)w * 4 + 24));
-    // a tile holds tile_rows nodes plus the tail of the graph that straddles its end
-    const int want = t.tile_rows * tpw + o.agg_overshoot;
-    if (rows_cap > want)
-        rows_cap = want;
-    rows_cap &= ~3;
-    if (rows_cap < 4)
-        rows_cap = 4;
-    const int edge_cap = rows_cap * 4;
-    const size_t lds = (size_t)rows_cap * w * 4 + (size_t)((rows_cap + 1 + 3) & ~3) * 4 + (size_t)edge_cap * 4;
-    auto kern = k_aggregate<MODE, VEC>;
-    static size_t lds_allowed = 64 * 1024; // per instantiation
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-        lds_allowed = lds;
-    }
-    const int grid = (t.num_tiles + tpw - 1) / tpw;
-    if (grid <= 0)
-        return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), lds, s, x, selfq, out, t.row_ptr, t.col,
-                       t.tile_first, t.num_tiles, tpw, w, glog2, rows_cap, edge_cap, eps);
-    return hipGetLastError();
-}
-
-
 // -------------------------------------------------------------------------------------
-// CSR-streamed variant (default: fastest measured, see profiles/).  A workgroup owns `rows_per_wg` consecutive destination rows.
-// Only the CSR slice (row_ptr, col) is staged in LDS; feature rows are gathered straight from
-// global memory: a row is fetched from HBM by whoever touches it first (its own lane group or a
-// neighbour's) and the other ~2 uses hit the XCD's L2 microseconds later, because a graph's
-// rows are contiguous and handled by the same or the adjacent workgroup.  Per destination row a
-// lane group issues the self row and two neighbour rows together (three independent 16-B loads
-// per lane in flight), so the kernel behaves like a streaming copy with L2-side gathers: no
-// barrier between load and compute, no LDS capacity limit, any graph size.
-// GCN uses the PyG form of the same normaliser: dinv_i * dinv_j with dinv = (1+d)^-1/2.
-// Per-row state of the streaming kernel: `begin` issues the self row and the first two
-// neighbour rows (three independent 16-B loads per lane), `finish` consumes them.  Two rows per
-// lane group are begun before either is finished, so six loads per lane are in flight.
-// EC: the workgroup's col slice is cached in LDS (compile-time, so the index read is a plain ds_read
-// or a plain global_load -- a runtime select between an LDS and a global pointer becomes a FLAT load
-// whose wait also covers every outstanding row load and store)
-template <int MODE, int VEC, bool EC>
-struct AggRow {
-    typedef Vf<VEC> V;
-    int node, rp0, rp1, j0, j1;
-    float di, s0, s1;
-    V xi, a, b;
-    bool valid;
-
-    __device__ inline int nbr(const int32_t *scol, const int32_t *__restrict__ col, int k, int eb) const
-    {
-        if (EC)
-            return scol[k - eb];
-        return col[k];
-    }
-
-    __device__ inline void begin(bool ok, int nb, int r, const int32_t *srp, const int32_t *scol, int eb,
-                                 const int32_t *__restrict__ col,
-                                 const float *__restrict__ x, const float *__restrict__ xs,
-                                 const float *__restrict__ dinv, int w, int fo)
-    {
-        valid = ok;
-        if (!ok)
-            return;
-        node = nb + r;
-        rp0 = srp[r];
-        rp1 = srp[r + 1];
-        // neighbours 0 and 1; a missing one aliases the self row (cache hit, result discarded)
-        j0 = rp0 < rp1 ? nbr(scol, col, rp0, eb) : node;
-        j1 = rp0 + 1 < rp1 ? nbr(scol, col, rp0 + 1, eb) : j0;
-        xi = V::load(xs + (size_t)node * w + fo);
-        a = V::load(x + (size_t)j0 * w + fo);
-        b = V::load(x + (size_t)j1 * w + fo);
-        if (MODE == GNNB_AGG_GCN) {
-            di = dinv[node];
-            s0 = dinv[j0];
-            s1 = dinv[j1];
-        }
-    }
-
-    __device__ inline void finish(const int32_t *scol, int eb, const int32_t *__restrict__ col, const float *__restrict__ x,
-                                  const float *__restrict__ dinv, float *__restrict__ out, int w,
-                                  int fo, float eps)
-    {
-        if (!valid)
-            return;
-        const int deg = rp1 - rp0;
-        V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
-        auto take = [&](const V &v, float sc, bool first) {
-            if (MODE == GNNB_AGG_GCN) {
-                acc = vadd(acc, vmul(v, V::splat(di * sc)));
-            } else if (MODE == GNNB_AGG_PNA) {
-                const V h = vadd(xi, v);
-                if (first) {
-                    vmx = h;
-                    vmn = h;
-                } else {
-                    vmx = vmax(vmx, h);
-                    vmn = vmin(vmn, h);
-                }
-                acc = vadd(acc, h);
-                s2 = vadd(s2, vmul(h, h));
-            } else {
-                acc = vadd(acc, v);
-            }
-        };
-        if (deg > 0)
-            take(a, s0, true);
-        if (deg > 1)
-            take(b, s1, false);
-        for (int k = rp0 + 2; k < rp1; k++) { // degree > 2: the remaining neighbours, in CSR order
-            const int j = nbr(scol, col, k, eb);
-            const V v = V::load(x + (size_t)j * w + fo);
-            take(v, (MODE == GNNB_AGG_GCN) ? dinv[j] : 0.0f, false);
-        }
-        if (MODE == GNNB_AGG_GCN) {
-            acc = vadd(acc, vmul(xi, V::splat(di * di)));
-            acc.store(out + (size_t)node * w + fo);
-        } else if (MODE == GNNB_AGG_SUM) {
-            acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
-            acc.store(out + (size_t)node * w + fo);
-        } else if (MODE == GNNB_AGG_MEAN) {
-            if (deg > 0)
-                acc = vdiv(acc, V::splat((float)deg));
-            acc.store(out + (size_t)node * w + fo);
-        } else {
-            V mean = V::splat(0.0f), sd = V::splat(0.0f);
-            if (deg > 0) {
-                const V dn = V::splat((float)deg);
-                mean = vdiv(acc, dn);
-                sd = pyg_std(vdiv(s2, dn), mean);
-            }
-            float *o = out + (size_t)node * 4 * w + fo;
-            vmx.store(o);
-            vmn.store(o + w);
-            mean.store(o + 2 * (size_t)w);
-            sd.store(o + 3 * (size_t)w);
-        }
-    }
-};
-
-template <int MODE, int VEC>
-__global__ __launch_bounds__(WG) void k_aggregate_stream(
-    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
-    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const float *__restrict__ dinv, int N, int w, int glog2, int rows_per_wg, int edge_cap, float eps,
-    int xcd_remap)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *srp = reinterpret_cast<int32_t *>(smem);    // [rows_per_wg + 1]
-    int32_t *scol = srp + ((rows_per_wg + 1 + 3) & ~3);  // [edge_cap]
-
-    const int tid = threadIdx.x;
-    const int chunk = xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int nb = chunk * rows_per_wg;
-    const int rows = min(rows_per_wg, N - nb);
-    for (int i = tid; i <= rows; i += WG)
-        srp[i] = row_ptr[nb + i];
-    __syncthreads();
-    const int eb = srp[0];
-    const int nedges = srp[rows] - eb;
-    const bool ecached = nedges <= edge_cap; // workgroup-uniform
-    if (ecached) {
-        for (int i = tid; i < nedges; i += WG)
-            scol[i] = col[eb + i];
-        __syncthreads();
-    }
-
-    const int nvec = w / VEC;
-    const int G = 1 << glog2;
-    const int groups = WG >> glog2;
-    const int grp = tid >> glog2;
-    const int gl = tid & (G - 1);
-    const float *xs = (MODE == GNNB_AGG_PNA) ? selfq : x; // PNA: the self term is q_i, neighbours p_j
-
-    auto run = [&](auto ectag) {
-        constexpr bool EC = decltype(ectag)::value != 0;
-        for (int r = grp; r < rows; r += 2 * groups) {
-            for (int f = gl; f < nvec; f += G) {
-                const int fo = f * VEC;
-                AggRow<MODE, VEC, EC> A, B;
-                A.begin(true, nb, r, srp, scol, eb, col, x, xs, dinv, w, fo);
-                B.begin(r + groups < rows, nb, r + groups, srp, scol, eb, col, x, xs, dinv, w, fo);
-                A.finish(scol, eb, col, x, dinv, out, w, fo, eps);
-                B.finish(scol, eb, col, x, dinv, out, w, fo, eps);
-            }
-        }
-    };
-    if (ecached)
-        run(IntTag<1>{});
-    else
-        run(IntTag<0>{});
-}
-
-template <int MODE, int VEC>
-static hipError_t launch_aggregate_stream_t(const BatchTables &t, const float *x, const float *selfq,
-                                            float *out, int w, float eps, hipStream_t s)
-{
-    const Options &o = options();
-    const int nvec = w / VEC;
-    int glog2 = 2;
-    while ((1 << glog2) < nvec && glog2 < 6)
-        glog2++;
-    const int rpw = o.agg_rows_per_wg;
-    const int edge_cap = rpw * 6;
-    const size_t lds = (size_t)((rpw + 1 + 3) & ~3) * 4 + (size_t)edge_cap * 4;
-    const int grid = (t.num_nodes + rpw - 1) / rpw;
-    if (grid <= 0)
-        return hipSuccess;
-    hipLaunchKernelGGL((k_aggregate_stream<MODE, VEC>), dim3(grid), dim3(WG), lds, s, x, selfq, out,
-                       t.row_ptr, t.col, t.dinv, t.num_nodes, w, glog2, rpw, edge_cap, eps, o.agg_xcd_remap);
-    return hipGetLastError();
-}
-
-
-// -------------------------------------------------------------------------------------
-// Record-streamed variant.  No LDS, no barrier, two dependent memory trips instead
-// of CSR's three: lane k of a lane group reads the 32-byte node record of the group's k-th row
-// ({rp0, deg, j0..j3}, written by graph prep), the records are handed round the group with
-// wave shuffles, and for two destination rows at a time the group issues the self row plus up
-// to four neighbour rows each (ten independent 16-B loads per lane) before consuming any.  A row
-// is fetched from HBM by whoever touches it first; its other ~2 uses hit the XCD's L2, because a
-// graph's rows are contiguous and handled by adjacent lane groups.  Rows of degree > 4 (rare in
-// molecules) finish from the CSR col array.
-template <int MODE, int VEC>
-struct RecRow {
-    typedef Vf<VEC> V;
-    int node, rp0, deg, j[4];
-    float di, sj[4];
-    V xi, nb[4];
-    bool valid;
-
-    __device__ inline void begin(bool ok, int node_, int4 r0, int4 r1, const float *__restrict__ x,
-                                 const float *__restrict__ xs, const float *__restrict__ dinv, int w, int fo)
-    {
-        valid = ok;
-        if (!ok)
-            return;
-        node = node_;
-        rp0 = r0.x;
-        deg = r0.y;
-        j[0] = r0.z;
-        j[1] = r0.w;
-        j[2] = r1.x;
-        j[3] = r1.y;
-        xi = V::load(xs + (size_t)node * w + fo);
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            nb[q] = V::load(x + (size_t)j[q] * w + fo); // unused slots alias the self row (cache hit)
-        if (MODE == GNNB_AGG_GCN) {
-            di = dinv[node];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                sj[q] = dinv[j[q]];
-        }
-    }
-
-    __device__ inline void finish(const int32_t *__restrict__ col, const float *__restrict__ x,
-                                  const float *__restrict__ dinv, float *__restrict__ out, int w, int fo, float eps)
-    {
-        if (!valid)
-            return;
-        V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
-        auto take = [&](const V &v, float sc, bool first) {
-            if (MODE == GNNB_AGG_GCN) {
-                acc = vadd(acc, vmul(v, V::splat(di * sc)));
-            } else if (MODE == GNNB_AGG_PNA) {
-                const V h = vadd(xi, v);
-                if (first) {
-                    vmx = h;
-                    vmn = h;
-                } else {
-                    vmx = vmax(vmx, h);
-                    vmn = vmin(vmn, h);
-                }
-                acc = vadd(acc, h);
-                s2 = vadd(s2, vmul(h, h));
-            } else {
-                acc = vadd(acc, v);
-            }
-        };
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (deg > q)
-                take(nb[q], sj[q], q == 0);
-        for (int k = rp0 + 4; k < rp0 + deg; k++) { // degree > 4: the rest, in CSR order
-            const int jj = col[k];
-            const V v = V::load(x + (size_t)jj * w + fo);
-            take(v, (MODE == GNNB_AGG_GCN) ? dinv[jj] : 0.0f, false);
-        }
-        if (MODE == GNNB_AGG_GCN) {
-            acc = vadd(acc, vmul(xi, V::splat(di * di)));
-            acc.store(out + (size_t)node * w + fo);
-        } else if (MODE == GNNB_AGG_SUM) {
-            acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
-            acc.store(out + (size_t)node * w + fo);
-        } else if (MODE == GNNB_AGG_MEAN) {
-            if (deg > 0)
-                acc = vdiv(acc, V::splat((float)deg));
-            acc.store(out + (size_t)node * w + fo);
-        } else {
-            V mean = V::splat(0.0f), sd = V::splat(0.0f);
-            if (deg > 0) {
-                const V dn = V::splat((float)deg);
-                mean = vdiv(acc, dn);
-                sd = pyg_std(vdiv(s2, dn), mean);
-            }
-            float *o = out + (size_t)node * 4 * w + fo;
-            vmx.store(o);
-            vmn.store(o + w);
-            mean.store(o + 2 * (size_t)w);
-            sd.store(o + 3 * (size_t)w);
-        }
-    }
-};
-
-__device__ inline int4 shfl4(int4 v, int src, int width)
-{
-    return make_int4(__shfl(v.x, src, width), __shfl(v.y, src, width), __shfl(v.z, src, width),
-                     __shfl(v.w, src, width));
-}
-
-template <int MODE, int VEC>
-__global__ __launch_bounds__(WG) void k_aggregate_rec(
-    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
-    const int4 *__restrict__ node_rec, const int32_t *__restrict__ col,
-    const float *__restrict__ dinv, int N, int w, int glog2, int rows_per_group, float eps)
-{
-    const int tid = threadIdx.x;
-    const int G = 1 << glog2;
-    const int groups = WG >> glog2;
-    const int grp = tid >> glog2;
-    const int gl = tid & (G - 1);
-    const int nvec = w / VEC;
-    const int nb = blockIdx.x * groups * rows_per_group;
-    const float *xs = (MODE == GNNB_AGG_PNA) ? selfq : x; // PNA: self term q_i, neighbours p_j
-
-    // lane k of the group fetches the record of the group's k-th row: rows nb + grp + k*groups
-    int4 r0 = make_int4(0, 0, 0, 0), r1 = r0;
-    {
-        const int my = nb + grp + gl * groups;
-        if (gl < rows_per_group && my < N) {
-            r0 = node_rec[2 * (size_t)my];
-            r1 = node_rec[2 * (size_t)my + 1];
-        }
-    }
-    for (int k = 0; k < rows_per_group; k += 2) {
-        const int nodeA = nb + grp + k * groups;
-        const int nodeB = nodeA + groups;
-        if (nodeA >= N)
-            break; // group-uniform, and rows only grow
-        const int4 a0 = shfl4(r0, k, G), a1 = shfl4(r1, k, G);
-        const int4 b0 = shfl4(r0, k + 1, G), b1 = shfl4(r1, k + 1, G);
-        const bool okB = (k + 1 < rows_per_group) && nodeB < N;
-        for (int f = gl; f < nvec; f += G) {
-            const int fo = f * VEC;
-            RecRow<MODE, VEC> A, B;
-            A.begin(true, nodeA, a0, a1, x, xs, dinv, w, fo);
-            B.begin(okB, nodeB, b0, b1, x, xs, dinv, w, fo);
-            A.finish(col, x, dinv, out, w, fo, eps);
-            B.finish(col, x, dinv, out, w, fo, eps);
-        }
-    }
-}
-
-template <int MODE, int VEC>
-static hipError_t launch_aggregate_rec_t(const BatchTables &t, const float *x, const float *selfq,
-                                         float *out, int w, float eps, hipStream_t s)
-{
-    const Options &o = options();
-    const int nvec = w / VEC;
-    int glog2 = 2;
-    while ((1 << glog2) < nvec && glog2 < 6)
-        glog2++;
-    const int G = 1 << glog2, groups = WG >> glog2;
-    int rpg = o.agg_rows_per_wg / groups; // rows per lane group
-    if (rpg < 2)
-        rpg = 2;
-    if (rpg > G)
-        rpg = G; // one record per lane
-    rpg &= ~1;
-    const int rows_per_wg = rpg * groups;
-    const int grid = (t.num_nodes + rows_per_wg - 1) / rows_per_wg;
-    if (grid <= 0)
-        return hipSuccess;
-    hipLaunchKernelGGL((k_aggregate_rec<MODE, VEC>), dim3(grid), dim3(WG), 0, s, x, selfq, out,
-                       t.node_rec, t.col, t.dinv, t.num_nodes, w, glog2, rpg, eps);
-    return hipGetLastError();
-}
-
-
-// -------------------------------------------------------------------------------------
-// LDS-DMA single-burst variant.  Each feature row crosses the vector-memory path exactly
-// once.  The grid is sized so that every workgroup is resident at the same time (two per CU at
-// the default LDS budget) and owns a contiguous run of node tiles = a few dozen whole graphs.
-// Phase 1: all four waves fire `global_load_lds` (LDS-DMA, no VGPR staging) for the whole run:
-//   feature rows in 1-KiB pieces, plus the row_ptr / col / dinv slices -- up to ~80 KB in flight
-//   per workgroup, the deepest read burst the CU can hold.
-// Phase 2 (after one barrier): lane groups reduce each destination row from LDS in CSR order and
-//   stream the result out with 16-B coalesced stores.
-// A run that does not fit the LDS budget (a very large graph) takes the same arithmetic with
-// rows read straight from global memory.
+// LDS-DMA helpers (global_load_lds: global -> LDS without VGPR staging).
 typedef __attribute__((address_space(3))) void *lds_vptr;
 typedef const __attribute__((address_space(1))) void *glb_vptr;
 
@@ -1113,208 +600,141 @@ __device__ __forceinline__ void vmcnt_wait_upto(int n)
 }
 
 
-template <int MODE, int VEC>
-__global__ __launch_bounds__(WG) void k_aggregate_dma(
-    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
-    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const float *__restrict__ dinv, const int32_t *__restrict__ tile_first,
-    const int32_t *__restrict__ tile_edge, int num_tiles, int w, int glog2, int rows_cap,
-    int edge_cap, float eps)
+// vmcnt wait with a run-time, wave-uniform count (the instruction takes an immediate): 0..63
+__device__ __forceinline__ void vmcnt_wait_n(int n)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *sx = reinterpret_cast<float *>(smem);                          // [rows_cap * w]
-    int32_t *srp = reinterpret_cast<int32_t *>(sx + (size_t)rows_cap * w); // [rows_cap + 1]
-    float *sdinv = reinterpret_cast<float *>(srp + ((rows_cap + 1 + 3) & ~3)); // [rows_cap]
-    int32_t *scol = reinterpret_cast<int32_t *>(sdinv + ((rows_cap + 3) & ~3)); // [edge_cap]
-    typedef Vf<VEC> V;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // balanced contiguous tile ranges: workgroup b owns tiles [b*T/G, (b+1)*T/G)
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
-    if (t1 <= t0)
-        return;
-    const int nb = tile_first[t0], ne = tile_first[t1];
-    const int eb = tile_edge[t0], nedges = tile_edge[t1] - eb;
-    const int rows = ne - nb;
-    if (rows <= 0)
-        return;
-    const bool staged = rows <= rows_cap;    // workgroup-uniform
-    const bool ecached = nedges <= edge_cap; // workgroup-uniform
-    GNNB_STAMP(0);
-
-    if (staged) {
-        const char *gsrc = reinterpret_cast<const char *>(x + (size_t)nb * w);
-        char *ldst = reinterpret_cast<char *>(sx);
-        const int bytes = rows * w * 4;
-        if (VEC == 4) {
-            for (int c = wave * 1024; c < bytes; c += (WG / 64) * 1024)
-                if (c + lane * 16 < bytes)
-                    dma16_to_lds(gsrc + c + lane * 16, ldst + c);
-        } else {
-            dma_dwords(gsrc, ldst, rows * w, wave, lane, WG / 64);
-        }
-        dma_dwords(row_ptr + nb, srp, rows + 1, wave, lane, WG / 64);
-        if (MODE == GNNB_AGG_GCN)
-            dma_dwords(dinv + nb, sdinv, rows, wave, lane, WG / 64);
+    switch (__builtin_amdgcn_readfirstlane(n)) { // scalar jump table
+#define GNNB_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define GNNB_VMW8(b) GNNB_VMW(b) GNNB_VMW(b + 1) GNNB_VMW(b + 2) GNNB_VMW(b + 3) GNNB_VMW(b + 4) GNNB_VMW(b + 5) GNNB_VMW(b + 6) GNNB_VMW(b + 7)
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    GNNB_VMW(1) GNNB_VMW(2) GNNB_VMW(3) GNNB_VMW(4) GNNB_VMW(5) GNNB_VMW(6) GNNB_VMW(7)
+    GNNB_VMW(8) GNNB_VMW(9) GNNB_VMW(10) GNNB_VMW(11) GNNB_VMW(12) GNNB_VMW(13) GNNB_VMW(14) GNNB_VMW(15)
+    GNNB_VMW(16) GNNB_VMW(17) GNNB_VMW(18) GNNB_VMW(19) GNNB_VMW(20) GNNB_VMW(21) GNNB_VMW(22) GNNB_VMW(23)
+    GNNB_VMW(24) GNNB_VMW(25) GNNB_VMW(26) GNNB_VMW(27) GNNB_VMW(28) GNNB_VMW(29) GNNB_VMW(30) GNNB_VMW(31)
+    GNNB_VMW(32) GNNB_VMW(33) GNNB_VMW(34) GNNB_VMW(35) GNNB_VMW(36) GNNB_VMW(37) GNNB_VMW(38) GNNB_VMW(39)
+    GNNB_VMW(40) GNNB_VMW(41) GNNB_VMW(42) GNNB_VMW(43) GNNB_VMW(44) GNNB_VMW(45) GNNB_VMW(46) GNNB_VMW(47)
+    GNNB_VMW(48) GNNB_VMW(49) GNNB_VMW(50) GNNB_VMW(51) GNNB_VMW(52) GNNB_VMW(53) GNNB_VMW(54) GNNB_VMW(55)
+    GNNB_VMW(56) GNNB_VMW(57) GNNB_VMW(58) GNNB_VMW(59) GNNB_VMW(60) GNNB_VMW(61) GNNB_VMW(62)
+#undef GNNB_VMW8
+#undef GNNB_VMW
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
     }
-    if (ecached)
-        dma_dwords(col + eb, scol, nedges, wave, lane, WG / 64);
-    GNNB_STAMP(1);
-    __syncthreads(); // the fence drains vmcnt (every DMA has landed) before the barrier releases
-    GNNB_STAMP(2);
-
-    const int nvec = w / VEC;
-    const int G = 1 << glog2;
-    const int groups = WG >> glog2;
-    const int grp = tid >> glog2;
-    const int gl = tid & (G - 1);
-
-    for (int r = grp; r < rows; r += groups) {
-        const int node = nb + r;
-        const int rp0 = staged ? srp[r] : row_ptr[node];
-        const int rp1 = staged ? srp[r + 1] : row_ptr[node + 1];
-        const int deg = rp1 - rp0;
-        float di = 0.0f;
-        if (MODE == GNNB_AGG_GCN)
-            di = staged ? sdinv[r] : dinv[node];
-        for (int f = gl; f < nvec; f += G) {
-            const int fo = f * VEC;
-            V xi;
-            if (MODE == GNNB_AGG_PNA)
-                xi = V::load(selfq + (size_t)node * w + fo);
-            else
-                xi = staged ? V::load(sx + (size_t)r * w + fo) : V::load(x + (size_t)node * w + fo);
-            V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
-            for (int k = rp0; k < rp1; k++) {
-                const int j = ecached ? scol[k - eb] : col[k];
-                const int jr = j - nb;
-                const V xj = staged ? V::load(sx + (size_t)jr * w + fo) : V::load(x + (size_t)j * w + fo);
-                if (MODE == GNNB_AGG_GCN) {
-                    const float dj = staged ? sdinv[jr] : dinv[j];
-                    acc = vadd(acc, vmul(xj, V::splat(di * dj)));
-                } else if (MODE == GNNB_AGG_PNA) {
-                    const V h = vadd(xi, xj);
-                    if (k == rp0) {
-                        vmx = h;
-                        vmn = h;
-                    } else {
-                        vmx = vmax(vmx, h);
-                        vmn = vmin(vmn, h);
-                    }
-                    acc = vadd(acc, h);
-                    s2 = vadd(s2, vmul(h, h));
-                } else {
-                    acc = vadd(acc, xj);
-                }
-            }
-            if (MODE == GNNB_AGG_GCN) {
-                acc = vadd(acc, vmul(xi, V::splat(di * di)));
-                acc.store(out + (size_t)node * w + fo);
-            } else if (MODE == GNNB_AGG_SUM) {
-                acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
-                acc.store(out + (size_t)node * w + fo);
-            } else if (MODE == GNNB_AGG_MEAN) {
-                if (deg > 0)
-                    acc = vdiv(acc, V::splat((float)deg));
-                acc.store(out + (size_t)node * w + fo);
-            } else {
-                V mean = V::splat(0.0f), sd = V::splat(0.0f);
-                if (deg > 0) {
-                    const V dn = V::splat((float)deg);
-                    mean = vdiv(acc, dn);
-                    sd = pyg_std(vdiv(s2, dn), mean);
-                }
-                float *o = out + (size_t)node * 4 * w + fo;
-                vmx.store(o);
-                vmn.store(o + w);
-                mean.store(o + 2 * (size_t)w);
-                sd.store(o + 3 * (size_t)w);
-            }
-        }
-    }
-    GNNB_STAMP_END(3);
 }
 
-template <int MODE, int VEC>
-static hipError_t launch_aggregate_dma_t(const BatchTables &t, const float *x, const float *selfq,
-                                         float *out, int w, float eps, hipStream_t s)
+// 16-B (or 4-B) row-piece store, optionally non-temporal (the output is not re-read by this kernel)
+typedef float agg_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void agg_store(const Vf<4> &v, float *p)
 {
-    const Options &o = options();
-    const int nvec = w / VEC;
-    int glog2 = 2;
-    while ((1 << glog2) < nvec && glog2 < 6)
-        glog2++;
-    if (t.num_tiles <= 0)
-        return hipSuccess;
-    // LDS budget per workgroup -> rows it can stage (row + row_ptr + dinv + ~4 col entries each)
-    const size_t budget = (size_t)o.agg_lds_kb * 1024;
-    int rows_cap = (int)(budget / ((size_t)w * 4 + 24)) & ~3;
-    if (rows_cap < 8)
-        rows_cap = 8;
-    // grid: every workgroup resident at once when the batch allows it, else as many as needed
-    // for a workgroup's run (plus the graph straddling its end) to fit the budget
-    const int margin = t.tile_rows + o.agg_overshoot;
-    const int usable = rows_cap > 2 * margin ? rows_cap - margin : rows_cap / 2;
-    long long grid = ((long long)t.num_nodes + usable - 1) / usable;
-    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (budget + 1024)));
-    const long long resident = 256LL * wg_per_cu;
-    if (grid < resident)
-        grid = resident;
-    if (grid > t.num_tiles)
-        grid = t.num_tiles;
-    // shrink the allocation to what a run of this grid actually needs
-    const int need = (int)(((long long)t.num_nodes + grid - 1) / grid) + margin;
-    if (rows_cap > need)
-        rows_cap = (need + 3) & ~3;
-    const int edge_cap = rows_cap * 4;
-    const size_t lds = (size_t)rows_cap * w * 4 + (size_t)((rows_cap + 1 + 3) & ~3) * 4 +
-                       (size_t)((rows_cap + 3) & ~3) * 4 + (size_t)edge_cap * 4;
-    auto kern = k_aggregate_dma<MODE, VEC>;
-    static size_t lds_allowed = 64 * 1024; // per instantiation
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-        lds_allowed = lds;
+    if (NT) {
+        agg_f32x4 t = {v.v.x, v.v.y, v.v.z, v.v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<agg_f32x4 *>(p));
+    } else {
+        v.store(p);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, x, selfq, out, t.row_ptr, t.col,
-                       t.dinv, t.tile_first, t.tile_edge, t.num_tiles, w, glog2, rows_cap, edge_cap, eps);
-    return hipGetLastError();
+}
+template <bool NT>
+__device__ __forceinline__ void agg_store(const Vf<1> &v, float *p)
+{
+    if (NT)
+        __builtin_nontemporal_store(v.v, p);
+    else
+        v.store(p);
 }
 
+// LGConv normaliser (gnn_builder_lib.h:2383-2386): 1/sqrt(d_i d_j) on IN-degrees, 0 when the product is 0
+__device__ __forceinline__ float lg_coef(int di, int dj)
+{
+    const int pr = di * dj;
+    return pr > 0 ? __frsqrt_rn((float)pr) : 0.0f; // (v_rsq_f32: 1 ulp; the oracle's 1/sqrt differs by < 2e-7 relative)
+}
 
-// -------------------------------------------------------------------------------------
-// Pipelined LDS-DMA variant.  The chip's whole LDS (256 x 160 KiB) is about the size of one
-// feature matrix, so the rows cannot all be resident at once: instead every workgroup is
-// persistent (grid = what fits the chip), owns a contiguous run of node tiles and walks it in
-// stages of whole graphs that fit one LDS buffer.  Two buffers: while the lane groups reduce
-// stage s from one, the LDS-DMA engine (global_load_lds, no VGPRs) fills the other with stage
-// s+1 -- feature rows, their 32-B node records and the dinv slice.  Each feature row crosses the
-// vector-memory path exactly once; every gather is an LDS read; one barrier per stage.
-struct PipeStage {
-    int ta, tb;   // tiles [ta, tb)
-    int nb, rows; // node range
-    bool staged;  // fits the LDS buffer
+// number of rows an output row has (PNA: max | min | mean | std)
+template <int MODE>
+struct AggOut {
+    static constexpr int K = MODE == GNNB_AGG_PNA ? 4 : 1;
 };
 
-template <int MODE, int VEC>
+// The reduction itself, shared by the LDS-staged and the direct forms: `take` one neighbour row at a
+// time in CSR order, `done` adds the self term / finalises and stores.
+template <int MODE, int VEC, bool NT>
+struct AggAcc {
+    typedef Vf<VEC> V;
+    V acc, vmx, vmn, s2;
+    __device__ inline void init() { acc = V::splat(0.0f); vmx = acc; vmn = acc; s2 = acc; }
+    // coef: GCN dinv_i * dinv_j, LG 1/sqrt(d_i d_j); xi: PNA's per-destination term q_i
+    __device__ inline void take(const V &v, float coef, const V &xi, bool first)
+    {
+        if (MODE == GNNB_AGG_GCN || MODE == GNNB_AGG_LG) {
+            acc = vadd(acc, vmul(v, V::splat(coef)));
+        } else if (MODE == GNNB_AGG_PNA) {
+            const V h = vadd(xi, v);
+            if (first) {
+                vmx = h;
+                vmn = h;
+            } else {
+                vmx = vmax(vmx, h);
+                vmn = vmin(vmn, h);
+            }
+            acc = vadd(acc, h);
+            s2 = vadd(s2, vmul(h, h));
+        } else {
+            acc = vadd(acc, v);
+        }
+    }
+    __device__ inline void done(const V &xi, float di, int deg, float eps, float *__restrict__ out, size_t node, int w, int fo)
+    {
+        if (MODE == GNNB_AGG_GCN) {
+            agg_store<NT>(vadd(acc, vmul(xi, V::splat(di * di))), out + node * w + fo);
+        } else if (MODE == GNNB_AGG_SUM) {
+            agg_store<NT>(vadd(acc, vmul(xi, V::splat(1.0f + eps))), out + node * w + fo);
+        } else if (MODE == GNNB_AGG_MEAN) {
+            // one reciprocal per row instead of a division per component (<= 1 ulp from sum / count)
+            agg_store<NT>(deg > 0 ? vmul(acc, V::splat(1.0f / (float)deg)) : acc, out + node * w + fo);
+        } else if (MODE == GNNB_AGG_PNA) {
+            V mean = V::splat(0.0f), sd = V::splat(0.0f);
+            if (deg > 0) {
+                const V dn = V::splat((float)deg);
+                mean = vdiv(acc, dn);
+                sd = pyg_std(vdiv(s2, dn), mean);
+            }
+            float *o = out + node * 4 * w + fo;
+            agg_store<NT>(vmx, o);
+            agg_store<NT>(vmn, o + w);
+            agg_store<NT>(mean, o + 2 * (size_t)w);
+            agg_store<NT>(sd, o + 3 * (size_t)w);
+        } else if (MODE == GNNB_AGG_COPY) {
+            agg_store<NT>(xi, out + node * w + fo);
+        } else { // LG, SIMPLE: no self term
+            agg_store<NT>(acc, out + node * w + fo);
+        }
+    }
+};
+
+// One destination row reduced from an LDS stage that holds its whole graph: rows `sx`, node records
+// `srec`, GCN normalisers `sdinv`, and (PNA, QLDS) the per-destination terms `sq`, all indexed by
+// row - nb.  begin() issues every LDS read of the row (its record gives the first four sources, unused
+// slots alias the row itself), finish() reduces and stores: two rows are begun before either is
+// finished so that ten ds_read_b128 are in flight per lane.
+template <int MODE, int VEC, bool QLDS = false, bool NT = false>
 struct LdsRow {
     typedef Vf<VEC> V;
-    int node, r, rp0, deg, jr[4];
+    int node, rp0, deg, jr[4];
     float di, sj[4];
     V xi, nbv[4];
     bool valid;
 
-    __device__ inline void begin(bool ok, int nb, int r_, const float *sx, const int4 *srec,
+    __device__ inline void begin(bool ok, int nb, int r_, const float *sx, const float *sq, const int4 *srec,
                                  const float *sdinv, const float *__restrict__ selfq, int w, int fo)
     {
         valid = ok;
         if (!ok)
             return;
-        r = r_;
         node = nb + r_;
+        if (MODE == GNNB_AGG_COPY) {
+            xi = V::load(sx + (size_t)r_ * w + fo);
+            return;
+        }
         const int4 r0 = srec[2 * r_], r1 = srec[2 * r_ + 1];
         rp0 = r0.x;
         deg = r0.y;
@@ -1323,8 +743,8 @@ struct LdsRow {
         jr[2] = r1.x - nb;
         jr[3] = r1.y - nb;
         if (MODE == GNNB_AGG_PNA)
-            xi = V::load(selfq + (size_t)node * w + fo);
-        else
+            xi = QLDS ? V::load(sq + (size_t)r_ * w + fo) : V::load(selfq + (size_t)node * w + fo);
+        else if (MODE == GNNB_AGG_GCN || MODE == GNNB_AGG_SUM)
             xi = V::load(sx + (size_t)r_ * w + fo);
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -1333,481 +753,81 @@ struct LdsRow {
             di = sdinv[r_];
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                sj[q] = sdinv[jr[q]];
+                sj[q] = di * sdinv[jr[q]];
+        } else if (MODE == GNNB_AGG_LG) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                sj[q] = lg_coef(deg, srec[2 * jr[q]].y);
         }
     }
 
-    __device__ inline void finish(int nb, const float *sx, const float *sdinv,
+    __device__ inline void finish(int nb, const float *sx, const int4 *srec, const float *sdinv,
                                   const int32_t *__restrict__ col, float *__restrict__ out, int w, int fo,
                                   float eps)
     {
         if (!valid)
             return;
-        V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
-        auto take = [&](const V &v, float sc, bool first) {
-            if (MODE == GNNB_AGG_GCN) {
-                acc = vadd(acc, vmul(v, V::splat(di * sc)));
-            } else if (MODE == GNNB_AGG_PNA) {
-                const V h = vadd(xi, v);
-                if (first) {
-                    vmx = h;
-                    vmn = h;
-                } else {
-                    vmx = vmax(vmx, h);
-                    vmn = vmin(vmn, h);
-                }
-                acc = vadd(acc, h);
-                s2 = vadd(s2, vmul(h, h));
-            } else {
-                acc = vadd(acc, v);
-            }
-        };
+        AggAcc<MODE, VEC, NT> a;
+        a.init();
+        if (MODE != GNNB_AGG_COPY) {
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (deg > q)
-                take(nbv[q], sj[q], q == 0);
-        for (int k = rp0 + 4; k < rp0 + deg; k++) { // degree > 4: the rest of the CSR row
-            const int j = col[k] - nb;
-            const V v = V::load(sx + (size_t)j * w + fo);
-            take(v, (MODE == GNNB_AGG_GCN) ? sdinv[j] : 0.0f, false);
-        }
-        if (MODE == GNNB_AGG_GCN) {
-            acc = vadd(acc, vmul(xi, V::splat(di * di)));
-            acc.store(out + (size_t)node * w + fo);
-        } else if (MODE == GNNB_AGG_SUM) {
-            acc = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
-            acc.store(out + (size_t)node * w + fo);
-        } else if (MODE == GNNB_AGG_MEAN) {
-            if (deg > 0)
-                acc = vdiv(acc, V::splat((float)deg));
-            acc.store(out + (size_t)node * w + fo);
-        } else {
-            V mean = V::splat(0.0f), sd = V::splat(0.0f);
-            if (deg > 0) {
-                const V dn = V::splat((float)deg);
-                mean = vdiv(acc, dn);
-                sd = pyg_std(vdiv(s2, dn), mean);
+            for (int q = 0; q < 4; q++)
+                if (deg > q)
+                    a.take(nbv[q], sj[q], xi, q == 0);
+            for (int k = rp0 + 4; k < rp0 + deg; k++) { // degree > 4: the rest of the CSR row
+                const int j = col[k] - nb;
+                const V v = V::load(sx + (size_t)j * w + fo);
+                float c = 0.0f;
+                if (MODE == GNNB_AGG_GCN)
+                    c = di * sdinv[j];
+                else if (MODE == GNNB_AGG_LG)
+                    c = lg_coef(deg, srec[2 * j].y);
+                a.take(v, c, xi, false);
             }
-            float *o = out + (size_t)node * 4 * w + fo;
-            vmx.store(o);
-            vmn.store(o + w);
-            mean.store(o + 2 * (size_t)w);
-            sd.store(o + 3 * (size_t)w);
         }
+        a.done(xi, di, deg, eps, out, (size_t)node, w, fo);
     }
 };
 
-static constexpr int PIPE_TCAP = 512; // tile-table entries a workgroup keeps in LDS
-
-static constexpr int PIPE_THREADS = WG + 64; // 4 reducer waves + 1 loader wave
-
-template <int MODE, int VEC>
-__global__ __launch_bounds__(PIPE_THREADS) void k_aggregate_pipe(
-    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
-    const int4 *__restrict__ node_rec, const int32_t *__restrict__ row_ptr,
-    const int32_t *__restrict__ col, const float *__restrict__ dinv,
-    const int32_t *__restrict__ tile_first, int num_tiles, int w, int glog2, int rows_cap, float eps)
+// The same row straight from global memory (a graph larger than an LDS stage): neighbour rows are
+// L2-side gathers, the degree comes from the node record (row_ptr holds row STARTS only: dropped edges
+// leave gaps at the end of a graph's CSR segment, so row_ptr[v+1] - row_ptr[v] is not a degree).
+template <int MODE, int VEC, bool NT>
+__device__ inline void agg_row_direct(int node, const float *__restrict__ x, const float *__restrict__ selfq,
+                                      float *__restrict__ out, const int4 *__restrict__ node_rec,
+                                      const int32_t *__restrict__ col, const float *__restrict__ dinv, int w, int fo,
+                                      float eps)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // one buffer = [rows_cap*w floats | rows_cap*2 int4 | rows_cap floats]
-    const size_t buf_bytes = ((size_t)rows_cap * w * 4 + (size_t)rows_cap * 32 + (size_t)rows_cap * 4 + 15) & ~(size_t)15;
-    int32_t *stile = reinterpret_cast<int32_t *>(smem + 2 * buf_bytes); // [PIPE_TCAP + 1]
     typedef Vf<VEC> V;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
-    if (t1 <= t0)
-        return;
-    for (int i = tid; i <= t1 - t0; i += PIPE_THREADS)
-        stile[i] = tile_first[t0 + i];
-    __syncthreads();
-    // Wave 4 is the loader: it alone issues the LDS-DMA of the next stage and waits for it, so its
-    // vmcnt holds nothing else.  The four reducer waves meet it at a raw s_barrier and never wait on
-    // vmcnt: on CDNA4 that counter includes stores, and a __syncthreads() per stage would make every
-    // stage wait for the previous stage's output rows to reach memory.
-    const bool loader = wave == 4; // wave-uniform
-
-    auto plan = [&](int ta) {
-        PipeStage st;
-        st.ta = ta;
-        st.tb = ta;
-        st.nb = 0;
-        st.rows = 0;
-        st.staged = true;
-        if (ta >= t1)
-            return st;
-        st.nb = stile[ta - t0];
-        int tb = ta + 1;
-        // whole tiles while they fit one buffer
-        while (tb < t1 && stile[tb + 1 - t0] - st.nb <= rows_cap)
-            tb++;
-        st.tb = tb;
-        st.rows = stile[tb - t0] - st.nb;
-        st.staged = st.rows <= rows_cap; // a single tile larger than the buffer: direct path
-        return st;
-    };
-    auto issue = [&](const PipeStage &st, int b) {
-        if (!st.staged || st.rows <= 0)
-            return;
-        char *base = smem + (size_t)b * buf_bytes;
-        char *lx = base;
-        char *lrec = base + (size_t)rows_cap * w * 4;
-        char *ldinv = lrec + (size_t)rows_cap * 32;
-        const char *gx = reinterpret_cast<const char *>(x + (size_t)st.nb * w);
-        const int bytes = st.rows * w * 4;
-        if (VEC == 4) {
-            for (int c = 0; c < bytes; c += 1024)
-                if (c + lane * 16 < bytes)
-                    dma16_to_lds(gx + c + lane * 16, lx + c);
-        } else {
-            dma_dwords(gx, lx, st.rows * w, 0, lane, 1);
-        }
-        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
-        const int rbytes = st.rows * 32;
-        for (int c = 0; c < rbytes; c += 1024)
-            if (c + lane * 16 < rbytes)
-                dma16_to_lds(grec + c + lane * 16, lrec + c);
+    AggAcc<MODE, VEC, NT> a;
+    a.init();
+    int rp0 = 0, deg = 0;
+    if (MODE != GNNB_AGG_COPY) {
+        const int4 r0 = node_rec[2 * (size_t)node];
+        rp0 = r0.x;
+        deg = r0.y;
+    }
+    const float di = (MODE == GNNB_AGG_GCN) ? dinv[node] : 0.0f;
+    V xi = V::splat(0.0f);
+    if (MODE == GNNB_AGG_PNA)
+        xi = V::load(selfq + (size_t)node * w + fo);
+    else if (MODE == GNNB_AGG_GCN || MODE == GNNB_AGG_SUM || MODE == GNNB_AGG_COPY)
+        xi = V::load(x + (size_t)node * w + fo);
+    for (int k = rp0; k < rp0 + deg; k++) {
+        const int j = col[k];
+        const V xj = V::load(x + (size_t)j * w + fo);
+        float c = 0.0f;
         if (MODE == GNNB_AGG_GCN)
-            dma_dwords(dinv + st.nb, ldinv, st.rows, 0, lane, 1);
-    };
-
-    const int nvec = w / VEC;
-    const int G = 1 << glog2;
-    const int groups = WG >> glog2;
-    const int grp = tid >> glog2;
-    const int gl = tid & (G - 1);
-
-    PipeStage cur = plan(t0);
-    int b = 0;
-    if (loader) {
-        issue(cur, 0);
-        while (cur.ta < t1) {
-            const PipeStage nxt = plan(cur.tb);
-            // stage `cur` has landed -> release it; passing the barrier also means the reducers are
-            // done with the other buffer, which the next DMA overwrites
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            issue(nxt, b ^ 1);
-            cur = nxt;
-            b ^= 1;
-        }
-        return;
+            c = di * dinv[j];
+        else if (MODE == GNNB_AGG_LG)
+            c = lg_coef(deg, node_rec[2 * (size_t)j].y);
+        a.take(xj, c, xi, k == rp0);
     }
-    while (cur.ta < t1) {
-        const PipeStage nxt = plan(cur.tb);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // stage `cur` is in LDS
-        if (cur.staged) {
-            const char *base = smem + (size_t)b * buf_bytes;
-            const float *sx = reinterpret_cast<const float *>(base);
-            const int4 *srec = reinterpret_cast<const int4 *>(base + (size_t)rows_cap * w * 4);
-            const float *sdinv = reinterpret_cast<const float *>(base + (size_t)rows_cap * w * 4 + (size_t)rows_cap * 32);
-            for (int r = grp; r < cur.rows; r += 2 * groups) {
-                for (int f = gl; f < nvec; f += G) {
-                    const int fo = f * VEC;
-                    LdsRow<MODE, VEC> A, B;
-                    A.begin(true, cur.nb, r, sx, srec, sdinv, selfq, w, fo);
-                    B.begin(r + groups < cur.rows, cur.nb, r + groups, sx, srec, sdinv, selfq, w, fo);
-                    A.finish(cur.nb, sx, sdinv, col, out, w, fo, eps);
-                    B.finish(cur.nb, sx, sdinv, col, out, w, fo, eps);
-                }
-            }
-        } else {
-            // a graph larger than the LDS buffer: same arithmetic straight from global memory
-            for (int r = grp; r < cur.rows; r += groups) {
-                const int node = cur.nb + r;
-                const int rp0 = row_ptr[node], rp1 = row_ptr[node + 1];
-                const int deg = rp1 - rp0;
-                const float di = (MODE == GNNB_AGG_GCN) ? dinv[node] : 0.0f;
-                for (int f = gl; f < nvec; f += G) {
-                    const int fo = f * VEC;
-                    const V xi = V::load((MODE == GNNB_AGG_PNA ? selfq : x) + (size_t)node * w + fo);
-                    V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
-                    for (int k = rp0; k < rp1; k++) {
-                        const int j = col[k];
-                        const V xj = V::load(x + (size_t)j * w + fo);
-                        if (MODE == GNNB_AGG_GCN) {
-                            acc = vadd(acc, vmul(xj, V::splat(di * dinv[j])));
-                        } else if (MODE == GNNB_AGG_PNA) {
-                            const V h = vadd(xi, xj);
-                            vmx = (k == rp0) ? h : vmax(vmx, h);
-                            vmn = (k == rp0) ? h : vmin(vmn, h);
-                            acc = vadd(acc, h);
-                            s2 = vadd(s2, vmul(h, h));
-                        } else {
-                            acc = vadd(acc, xj);
-                        }
-                    }
-                    if (MODE == GNNB_AGG_GCN) {
-                        vadd(acc, vmul(xi, V::splat(di * di))).store(out + (size_t)node * w + fo);
-                    } else if (MODE == GNNB_AGG_SUM) {
-                        vadd(acc, vmul(xi, V::splat(1.0f + eps))).store(out + (size_t)node * w + fo);
-                    } else if (MODE == GNNB_AGG_MEAN) {
-                        (deg > 0 ? vdiv(acc, V::splat((float)deg)) : acc).store(out + (size_t)node * w + fo);
-                    } else {
-                        V mean = V::splat(0.0f), sd = V::splat(0.0f);
-                        if (deg > 0) {
-                            mean = vdiv(acc, V::splat((float)deg));
-                            sd = pyg_std(vdiv(s2, V::splat((float)deg)), mean);
-                        }
-                        float *o = out + (size_t)node * 4 * w + fo;
-                        vmx.store(o);
-                        vmn.store(o + w);
-                        mean.store(o + 2 * (size_t)w);
-                        sd.store(o + 3 * (size_t)w);
-                    }
-                }
-            }
-        }
-        cur = nxt;
-        b ^= 1;
-    }
-}
-
-template <int MODE, int VEC>
-static hipError_t launch_aggregate_pipe_t(const BatchTables &t, const float *x, const float *selfq,
-                                          float *out, int w, float eps, hipStream_t s)
-{
-    const Options &o = options();
-    const int nvec = w / VEC;
-    int glog2 = 2;
-    while ((1 << glog2) < nvec && glog2 < 6)
-        glog2++;
-    if (t.num_tiles <= 0)
-        return hipSuccess;
-    // two LDS buffers per workgroup inside the per-workgroup budget
-    const size_t budget = (size_t)o.agg_lds_kb * 1024;
-    const size_t per_row = (size_t)w * 4 + 32 + 4;
-    int rows_cap = (int)((budget - (PIPE_TCAP + 1) * 4 - 64) / 2 / per_row) & ~3;
-    if (rows_cap < 8)
-        rows_cap = 8;
-    const size_t buf_bytes = ((size_t)rows_cap * per_row + 15) & ~(size_t)15;
-    const size_t lds = 2 * buf_bytes + (PIPE_TCAP + 1) * 4;
-    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
-    long long grid = 256LL * wg_per_cu; // persistent: everything resident
-    if (grid > t.num_tiles)
-        grid = t.num_tiles;
-    const long long min_grid = ((long long)t.num_tiles + PIPE_TCAP - 2) / (PIPE_TCAP - 1);
-    if (grid < min_grid)
-        grid = min_grid; // a workgroup's tile table must fit its LDS copy
-    auto kern = k_aggregate_pipe<MODE, VEC>;
-    static size_t lds_allowed = 64 * 1024; // per instantiation
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-        lds_allowed = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PIPE_THREADS), lds, s, x, selfq, out, t.node_rec,
-                       t.row_ptr, t.col, t.dinv, t.tile_first, t.num_tiles, w, glog2, rows_cap, eps);
-    return hipGetLastError();
+    a.done(xi, di, deg, eps, out, (size_t)node, w, fo);
 }
 
 // -------------------------------------------------------------------------------------
-// LDS-staged pipelined variant, second take (variant 5).  Same idea as variant 2 -- persistent
-// workgroups, every feature row crosses the CU's memory port ONCE (LDS-DMA), neighbours are gathered
-// from LDS -- rebuilt on what the fused GCN kernel taught: the DMA is issued from inline
-// asm by ALL waves (the builtin makes the compiler put s_waitcnt vmcnt(0) in front of every later
-// ds_read, which is why variant 2 needed a dedicated loader wave), one raw barrier per stage, and a
-// COUNTED vmcnt wait at the stage top so that the previous stage's output stores stay in flight.
-template <int MODE, int VEC>
-__global__ __launch_bounds__(WG) void k_aggregate_lds(
-    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
-    const int4 *__restrict__ node_rec, const int32_t *__restrict__ row_ptr,
-    const int32_t *__restrict__ col, const float *__restrict__ dinv,
-    const int32_t *__restrict__ tile_first, int num_tiles, int w, int glog2, int rows_cap, float eps)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // one buffer = [rows_cap*w floats | rows_cap*2 int4 | rows_cap floats]
-    const size_t buf_bytes = ((size_t)rows_cap * w * 4 + (size_t)rows_cap * 32 + (size_t)rows_cap * 4 + 15) & ~(size_t)15;
-    int32_t *stile = reinterpret_cast<int32_t *>(smem + 2 * buf_bytes); // [PIPE_TCAP + 1]
-    typedef Vf<VEC> V;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
-    if (t1 <= t0)
-        return;
-    for (int i = tid; i <= t1 - t0; i += WG)
-        stile[i] = tile_first[t0 + i];
-    __syncthreads();
-
-    auto plan = [&](int ta) {
-        PipeStage st;
-        st.ta = ta;
-        st.tb = ta;
-        st.nb = 0;
-        st.rows = 0;
-        st.staged = true;
-        if (ta >= t1)
-            return st;
-        st.nb = stile[ta - t0];
-        int tb = ta + 1;
-        while (tb < t1 && stile[tb + 1 - t0] - st.nb <= rows_cap) // whole tiles while they fit one buffer
-            tb++;
-        st.tb = tb;
-        st.rows = stile[tb - t0] - st.nb;
-        st.staged = st.rows <= rows_cap; // a single tile larger than the buffer: direct path
-        return st;
-    };
-    auto issue = [&](const PipeStage &st, int b) {
-        if (!st.staged || st.rows <= 0)
-            return;
-        char *base = smem + (size_t)b * buf_bytes;
-        char *lrec = base + (size_t)rows_cap * w * 4;
-        char *ldinv = lrec + (size_t)rows_cap * 32;
-        const char *gx = reinterpret_cast<const char *>(x + (size_t)st.nb * w);
-        const int bytes = st.rows * w * 4;
-        if (VEC == 4) {
-            for (int c = wave * 1024; c < bytes; c += (WG / 64) * 1024)
-                if (c + lane * 16 < bytes)
-                    dma16_to_lds_u(gx + c + lane * 16, base + c);
-        } else {
-            dma_dwords_u(gx, base, st.rows * w, wave, lane, WG / 64);
-        }
-        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
-        const int rbytes = st.rows * 32;
-        for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
-            if (c + lane * 16 < rbytes)
-                dma16_to_lds_u(grec + c + lane * 16, lrec + c);
-        if (MODE == GNNB_AGG_GCN)
-            dma_dwords_u(dinv + st.nb, ldinv, st.rows, wave, lane, WG / 64);
-    };
-
-    const int nvec = w / VEC;
-    const int G = 1 << glog2;
-    const int groups = WG >> glog2;
-    const int grp = tid >> glog2;
-    const int gl = tid & (G - 1);
-    const int gpw = 64 >> glog2 > 0 ? 64 >> glog2 : 1; // lane groups per wave
-    const int stores_per_row = (MODE == GNNB_AGG_PNA ? 4 : 1) * ((nvec + G - 1) / G);
-
-    PipeStage cur = plan(t0);
-    issue(cur, 0);
-    int b = 0, stores_behind_dma = 0;
-    while (cur.ta < t1) {
-        const PipeStage nxt = plan(cur.tb);
-        // stage `cur` has landed; the output stores issued after its DMA may stay in flight
-        vmcnt_wait_upto(stores_behind_dma);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // ... for everyone; the other buffer is free
-        issue(nxt, b ^ 1);
-        stores_behind_dma = 0;
-        if (cur.staged) {
-            const char *base = smem + (size_t)b * buf_bytes;
-            const float *sx = reinterpret_cast<const float *>(base);
-            const int4 *srec = reinterpret_cast<const int4 *>(base + (size_t)rows_cap * w * 4);
-            const float *sdinv = reinterpret_cast<const float *>(base + (size_t)rows_cap * w * 4 + (size_t)rows_cap * 32);
-            for (int r = grp; r < cur.rows; r += 2 * groups) {
-                for (int f = gl; f < nvec; f += G) {
-                    const int fo = f * VEC;
-                    LdsRow<MODE, VEC> A, B;
-                    A.begin(true, cur.nb, r, sx, srec, sdinv, selfq, w, fo);
-                    B.begin(r + groups < cur.rows, cur.nb, r + groups, sx, srec, sdinv, selfq, w, fo);
-                    A.finish(cur.nb, sx, sdinv, col, out, w, fo, eps);
-                    B.finish(cur.nb, sx, sdinv, col, out, w, fo, eps);
-                }
-            }
-            // store instructions this WAVE issued (exact, or the counted wait above would be unsafe): its
-            // first lane group makes the most loop trips; row A stores in every trip, row B when it exists
-            const int g0 = wave * gpw;
-            int cnt = 0;
-            for (int r = g0; r < cur.rows; r += 2 * groups)
-                cnt += stores_per_row * (1 + (r + groups < cur.rows ? 1 : 0));
-            stores_behind_dma = (MODE == GNNB_AGG_PNA || VEC != 4) ? (1 << 20) : cnt; // (PNA reads q_i from global memory in between)
-        } else {
-            stores_behind_dma = 1 << 20;
-            // a graph larger than the LDS buffer: same arithmetic straight from global memory
-            for (int r = grp; r < cur.rows; r += groups) {
-                const int node = cur.nb + r;
-                const int rp0 = row_ptr[node], rp1 = row_ptr[node + 1];
-                const int deg = rp1 - rp0;
-                const float di = (MODE == GNNB_AGG_GCN) ? dinv[node] : 0.0f;
-                for (int f = gl; f < nvec; f += G) {
-                    const int fo = f * VEC;
-                    const V xi = V::load((MODE == GNNB_AGG_PNA ? selfq : x) + (size_t)node * w + fo);
-                    V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
-                    for (int k = rp0; k < rp1; k++) {
-                        const int j = col[k];
-                        const V xj = V::load(x + (size_t)j * w + fo);
-                        if (MODE == GNNB_AGG_GCN) {
-                            acc = vadd(acc, vmul(xj, V::splat(di * dinv[j])));
-                        } else if (MODE == GNNB_AGG_PNA) {
-                            const V h = vadd(xi, xj);
-                            vmx = (k == rp0) ? h : vmax(vmx, h);
-                            vmn = (k == rp0) ? h : vmin(vmn, h);
-                            acc = vadd(acc, h);
-                            s2 = vadd(s2, vmul(h, h));
-                        } else {
-                            acc = vadd(acc, xj);
-                        }
-                    }
-                    if (MODE == GNNB_AGG_GCN) {
-                        vadd(acc, vmul(xi, V::splat(di * di))).store(out + (size_t)node * w + fo);
-                    } else if (MODE == GNNB_AGG_SUM) {
-                        vadd(acc, vmul(xi, V::splat(1.0f + eps))).store(out + (size_t)node * w + fo);
-                    } else if (MODE == GNNB_AGG_MEAN) {
-                        (deg > 0 ? vdiv(acc, V::splat((float)deg)) : acc).store(out + (size_t)node * w + fo);
-                    } else {
-                        V mean = V::splat(0.0f), sd = V::splat(0.0f);
-                        if (deg > 0) {
-                            mean = vdiv(acc, V::splat((float)deg));
-                            sd = pyg_std(vdiv(s2, V::splat((float)deg)), mean);
-                        }
-                        float *o = out + (size_t)node * 4 * w + fo;
-                        vmx.store(o);
-                        vmn.store(o + w);
-                        mean.store(o + 2 * (size_t)w);
-                        sd.store(o + 3 * (size_t)w);
-                    }
-                }
-            }
-        }
-        cur = nxt;
-        b ^= 1;
-    }
-}
-
-template <int MODE, int VEC>
-static hipError_t launch_aggregate_lds_t(const BatchTables &t, const float *x, const float *selfq,
-                                         float *out, int w, float eps, hipStream_t s)
-{
-    const Options &o = options();
-    const int nvec = w / VEC;
-    int glog2 = 2;
-    while ((1 << glog2) < nvec && glog2 < 6)
-        glog2++;
-    if (t.num_tiles <= 0)
-        return hipSuccess;
-    const size_t budget = (size_t)o.agg_lds_kb * 1024;
-    const size_t per_row = (size_t)w * 4 + 32 + 4;
-    int rows_cap = (int)((budget - (PIPE_TCAP + 1) * 4 - 64) / 2 / per_row) & ~3;
-    if (rows_cap < 8)
-        rows_cap = 8;
-    const size_t buf_bytes = ((size_t)rows_cap * per_row + 15) & ~(size_t)15;
-    const size_t lds = 2 * buf_bytes + (PIPE_TCAP + 1) * 4;
-    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
-    long long grid = 256LL * wg_per_cu; // persistent: everything resident
-    if (grid > t.num_tiles)
-        grid = t.num_tiles;
-    const long long min_grid = ((long long)t.num_tiles + PIPE_TCAP - 2) / (PIPE_TCAP - 1);
-    if (grid < min_grid)
-        grid = min_grid; // a workgroup's tile table must fit its LDS copy
-    auto kern = k_aggregate_lds<MODE, VEC>;
-    static size_t lds_allowed = 64 * 1024; // per instantiation
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-        lds_allowed = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, x, selfq, out, t.node_rec, t.row_ptr, t.col,
-                       t.dinv, t.tile_first, t.num_tiles, w, glog2, rows_cap, eps);
-    return hipGetLastError();
-}
-
-// -------------------------------------------------------------------------------------
-// One-shot LDS-staged variant (variant 6).  A workgroup owns `tpw` consecutive node tiles (whole graphs):
+// One-shot LDS-staged form (agg_variant 1).  A workgroup owns `tpw` consecutive node tiles (whole graphs):
 // LDS-DMA of their feature rows + node records + dinv, one barrier, reduce from LDS with two rows in
 // flight per lane group, stream the result out, exit.  No pipeline inside the workgroup: the overlap
 // comes from several short-lived workgroups per CU (LDS ~ 0.55 KB per row).  Rows that do not fit the
@@ -1815,17 +835,14 @@ static hipError_t launch_aggregate_lds_t(const BatchTables &t, const float *x, c
 template <int MODE, int VEC>
 __global__ __launch_bounds__(WG) void k_aggregate_shot(
     const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
-    const int4 *__restrict__ node_rec, const int32_t *__restrict__ row_ptr,
-    const int32_t *__restrict__ col, const float *__restrict__ dinv,
-    const int32_t *__restrict__ tile_first, int num_tiles, int tpw, int w, int glog2, int rows_cap, float eps,
-    int xcd_remap)
+    const int4 *__restrict__ node_rec, const int32_t *__restrict__ col, const float *__restrict__ dinv,
+    const int32_t *__restrict__ tile_first, int num_tiles, int N, int tpw, int w, int glog2, int rows_cap, float eps)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef Vf<VEC> V;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int ta = chunk * tpw, tb = min(ta + tpw, num_tiles);
-    const int nb = tile_first[ta], rows = tile_first[tb] - nb;
+    const int ta = blockIdx.x * tpw, tb = min(ta + tpw, num_tiles);
+    // (clamped: the tile table of a malformed batch may hold stale entries; a flagged batch must still stay in range)
+    const int nb = min(tile_first[ta], N), rows = min(tile_first[tb], N) - nb;
     if (rows <= 0)
         return;
     const int nvec = w / VEC;
@@ -1845,11 +862,13 @@ __global__ __launch_bounds__(WG) void k_aggregate_shot(
         } else {
             dma_dwords_u(gx, smem, rows * w, wave, lane, WG / 64);
         }
-        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)nb);
-        const int rbytes = rows * 32;
-        for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
-            if (c + lane * 16 < rbytes)
-                dma16_to_lds_u(grec + c + lane * 16, lrec + c);
+        if (MODE != GNNB_AGG_COPY) {
+            const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)nb);
+            const int rbytes = rows * 32;
+            for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
+                if (c + lane * 16 < rbytes)
+                    dma16_to_lds_u(grec + c + lane * 16, lrec + c);
+        }
         if (MODE == GNNB_AGG_GCN)
             dma_dwords_u(dinv + nb, ldinv, rows, wave, lane, WG / 64);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1860,59 +879,18 @@ __global__ __launch_bounds__(WG) void k_aggregate_shot(
             for (int f = gl; f < nvec; f += G) {
                 const int fo = f * VEC;
                 LdsRow<MODE, VEC> A, B;
-                A.begin(true, nb, r, sx, srec, sdinv, selfq, w, fo);
-                B.begin(r + groups < rows, nb, r + groups, sx, srec, sdinv, selfq, w, fo);
-                A.finish(nb, sx, sdinv, col, out, w, fo, eps);
-                B.finish(nb, sx, sdinv, col, out, w, fo, eps);
+                A.begin(true, nb, r, sx, nullptr, srec, sdinv, selfq, w, fo);
+                B.begin(r + groups < rows, nb, r + groups, sx, nullptr, srec, sdinv, selfq, w, fo);
+                A.finish(nb, sx, srec, sdinv, col, out, w, fo, eps);
+                B.finish(nb, sx, srec, sdinv, col, out, w, fo, eps);
             }
         }
         return;
     }
     // a graph larger than the LDS buffer: straight from global memory
-    for (int r = grp; r < rows; r += groups) {
-        const int node = nb + r;
-        const int rp0 = row_ptr[node], rp1 = row_ptr[node + 1];
-        const int deg = rp1 - rp0;
-        const float di = (MODE == GNNB_AGG_GCN) ? dinv[node] : 0.0f;
-        for (int f = gl; f < nvec; f += G) {
-            const int fo = f * VEC;
-            const V xi = V::load((MODE == GNNB_AGG_PNA ? selfq : x) + (size_t)node * w + fo);
-            V acc = V::splat(0.0f), vmx = V::splat(0.0f), vmn = V::splat(0.0f), s2 = V::splat(0.0f);
-            for (int k = rp0; k < rp1; k++) {
-                const int j = col[k];
-                const V xj = V::load(x + (size_t)j * w + fo);
-                if (MODE == GNNB_AGG_GCN) {
-                    acc = vadd(acc, vmul(xj, V::splat(di * dinv[j])));
-                } else if (MODE == GNNB_AGG_PNA) {
-                    const V h = vadd(xi, xj);
-                    vmx = (k == rp0) ? h : vmax(vmx, h);
-                    vmn = (k == rp0) ? h : vmin(vmn, h);
-                    acc = vadd(acc, h);
-                    s2 = vadd(s2, vmul(h, h));
-                } else {
-                    acc = vadd(acc, xj);
-                }
-            }
-            if (MODE == GNNB_AGG_GCN) {
-                vadd(acc, vmul(xi, V::splat(di * di))).store(out + (size_t)node * w + fo);
-            } else if (MODE == GNNB_AGG_SUM) {
-                vadd(acc, vmul(xi, V::splat(1.0f + eps))).store(out + (size_t)node * w + fo);
-            } else if (MODE == GNNB_AGG_MEAN) {
-                (deg > 0 ? vdiv(acc, V::splat((float)deg)) : acc).store(out + (size_t)node * w + fo);
-            } else {
-                V mean = V::splat(0.0f), sd = V::splat(0.0f);
-                if (deg > 0) {
-                    mean = vdiv(acc, V::splat((float)deg));
-                    sd = pyg_std(vdiv(s2, V::splat((float)deg)), mean);
-                }
-                float *o = out + (size_t)node * 4 * w + fo;
-                vmx.store(o);
-                vmn.store(o + w);
-                mean.store(o + 2 * (size_t)w);
-                sd.store(o + 3 * (size_t)w);
-            }
-        }
-    }
+    for (int r = grp; r < rows; r += groups)
+        for (int f = gl; f < nvec; f += G)
+            agg_row_direct<MODE, VEC, false>(nb + r, x, selfq, out, node_rec, col, dinv, w, f * VEC, eps);
 }
 
 template <int MODE, int VEC>
@@ -1930,7 +908,7 @@ static hipError_t launch_aggregate_shot_t(const BatchTables &t, const float *x, 
     const size_t per_row = (size_t)w * 4 + 32 + 4;
     // rows of tpw tiles: <= tpw * tile_rows + (largest graph - 1); sized for molecule-scale graphs inside the
     // LDS budget, anything larger takes the direct path
-    int rows_cap = (int)(((size_t)o.agg_lds_kb * 1024) / per_row) & ~3;
+    int rows_cap = (int)(((size_t)(o.agg_lds_kb > 0 ? o.agg_lds_kb : 39) * 1024) / per_row) & ~3;
     // with the caller's promise on the largest graph the buffer is sized exactly (more workgroups per CU)
     if (t.max_graph_nodes_hint > 0)
         rows_cap = std::min(rows_cap, (tpw * t.tile_rows + t.max_graph_nodes_hint - 1 + 3) & ~3);
@@ -1939,17 +917,317 @@ static hipError_t launch_aggregate_shot_t(const BatchTables &t, const float *x, 
     const size_t lds = (((size_t)rows_cap * per_row) + 15) & ~(size_t)15;
     const int grid = (t.num_tiles + tpw - 1) / tpw;
     auto kern = k_aggregate_shot<MODE, VEC>;
-    static size_t lds_allowed = 64 * 1024; // per instantiation
-    if (lds > lds_allowed) {
+    if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        lds_allowed = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), lds, s, x, selfq, out, t.node_rec, t.row_ptr, t.col, t.dinv,
-                       t.tile_first, t.num_tiles, tpw, w, glog2, rows_cap, eps, 0 /* every row is fetched once: nothing to gain from an XCD remap */);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), lds, s, x, selfq, out, t.node_rec, t.col, t.dinv,
+                       t.tile_first, t.num_tiles, t.num_nodes, tpw, w, glog2, rows_cap, eps);
     return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------
+// Ring form (agg_variant 0, default): persistent, one workgroup per CU, and NO workgroup barrier -- every
+// WAVE runs its own software pipeline over a contiguous run of node tiles (whole graphs).  A wave owns a
+// ring of `nslots` LDS stages of `cap` rows; per stage it fires the LDS-DMA of the rows, node records and
+// normalisers (global_load_lds, no VGPRs), and it retires stages in order behind a COUNTED vmcnt wait
+// (VM operations retire in issue order, so "at most n younger operations outstanding" proves the stage has
+// landed while the younger stages' DMA and the previous stages' output stores stay in flight).  At the
+// BASELINE sizes a CU's whole share of the input fits its ring, so all of a wave's reads are in flight from
+// the first microsecond and the stores start as soon as the first stage lands; bigger batches cycle the ring.
+// A tile that does not fit a stage (one very large graph) is reduced straight from global memory.
+static constexpr int RING_MAX_SLOTS = 4;
+
+// Diagnostic build: wave 0 of every workgroup logs wall-clock stamps of its stage events (100 MHz ticks)
+#ifdef GNNB_PROBE
+#define RING_EV(code)                                                                                        \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < 2048 && pev < 31) {                                             \
+            g_probe[blockIdx.x * 64 + 2 + 2 * pev] = wall_clock64();                                         \
+            g_probe[blockIdx.x * 64 + 3 + 2 * pev] = (unsigned long long)(code);                             \
+            pev++;                                                                                           \
+            g_probe[blockIdx.x * 64 + 1] = pev;                                                              \
+        }                                                                                                    \
+    } while (0)
+#else
+#define RING_EV(code) do { } while (0)
+#endif
+
+template <int MODE, int VEC, bool NT, bool COOP>
+__global__ __launch_bounds__(COOP ? 1024 : 512) void k_aggregate_ring(
+    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
+    const int4 *__restrict__ node_rec, const int32_t *__restrict__ col, const float *__restrict__ dinv,
+    const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_edge, int num_tiles, int N, int E, int w,
+    int glog2, int cap, int ecap, int nslots, int slot_bytes, int slack, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool HASQ = MODE == GNNB_AGG_PNA, HASREC = MODE != GNNB_AGG_COPY, HASDINV = MODE == GNNB_AGG_GCN;
+    constexpr int KOUT = AggOut<MODE>::K;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    // COOP: the workgroup's waves share ONE ring of big stages (each wave issues 1/nw of a stage's DMA and reduces
+    // 1/nw of its rows; two barriers per stage); otherwise every wave owns a ring and a tile range of its own
+    const int pw = COOP ? 0 : wave, pn = COOP ? 1 : nw;   // this wave's share of a stage's work: index, count ...
+    const int sw = COOP ? wave : 0, sn = COOP ? nw : 1;   // ... and of the tile ranges
+    const int gw = blockIdx.x * pn + pw, tw = gridDim.x * pn;
+    const int t0 = (int)(((long long)gw * num_tiles) / tw), t1 = (int)(((long long)(gw + 1) * num_tiles) / tw);
+    if (t0 >= t1)
+        return; // (COOP: workgroup-uniform)
+#ifdef GNNB_PROBE
+    int pev = 0;
+    if (threadIdx.x == 0 && blockIdx.x < 2048)
+        g_probe[blockIdx.x * 64] = wall_clock64();
+#endif
+    char *wbase = smem + (size_t)pw * nslots * slot_bytes;
+    const int off_q = cap * w * 4;
+    const int off_rec = off_q + (HASQ ? cap * w * 4 : 0);
+    const int off_dinv = off_rec + cap * 32;
+    const int off_col = off_dinv + cap * 4; // the stage's CSR slice (rows of degree > 4 read it): ecap entries
+    const int nvec = w / VEC;
+    const int G = 1 << glog2;       // lanes per destination row
+    const int groups = 64 >> glog2; // rows a wave reduces at once
+    const int grp = lane >> glog2;
+    const int gl = lane & (G - 1);
+    const int fiter = (nvec + G - 1) / G;
+
+    // window of the tile table in a register: lane l holds tile_first[wb + l]
+    // (clamped to N: the table of a malformed batch may hold stale entries; a flagged batch must still stay in range)
+    int wb = t0;
+    int tfv = min(tile_first[min(wb + lane, num_tiles)], N);
+    int tev = HASREC ? min(tile_edge[min(wb + lane, num_tiles)], E) : 0;
+    const int tf_end = min(tile_first[t1], N); // end of this ring's node range
+    int ts = t0; // next tile to plan
+
+    int f_nb[RING_MAX_SLOTS], f_rows[RING_MAX_SLOTS], f_mark[RING_MAX_SLOTS], f_e0[RING_MAX_SLOTS];
+    int nfifo = 0, vm = 0, issue_slot = 0, head_slot = 0;
+
+    auto issue = [&](int slot, int nb_, int rows_, int e0_, int ne_) -> int {
+        char *sb = wbase + (size_t)slot * slot_bytes;
+        int ops = 0;
+        const int bytes = rows_ * w * 4;
+        {
+            const char *gx = reinterpret_cast<const char *>(x + (size_t)nb_ * w);
+            if (VEC == 4) {
+                for (int c = sw * 1024; c < bytes; c += sn * 1024, ops++)
+                    if (c + lane * 16 < bytes)
+                        dma16_to_lds_u(gx + c + lane * 16, sb + c);
+            } else {
+                for (int c = sw * 64; c < rows_ * w; c += sn * 64, ops++)
+                    if (c + lane < rows_ * w)
+                        dma4_to_lds_u(gx + (size_t)(c + lane) * 4, sb + (size_t)c * 4);
+            }
+        }
+        if (HASQ) {
+            const char *gq = reinterpret_cast<const char *>(selfq + (size_t)nb_ * w);
+            if (VEC == 4) {
+                for (int c = sw * 1024; c < bytes; c += sn * 1024, ops++)
+                    if (c + lane * 16 < bytes)
+                        dma16_to_lds_u(gq + c + lane * 16, sb + off_q + c);
+            } else {
+                for (int c = sw * 64; c < rows_ * w; c += sn * 64, ops++)
+                    if (c + lane < rows_ * w)
+                        dma4_to_lds_u(gq + (size_t)(c + lane) * 4, sb + off_q + (size_t)c * 4);
+            }
+        }
+        if (HASREC) {
+            const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)nb_);
+            const int rbytes = rows_ * 32;
+            for (int c = sw * 1024; c < rbytes; c += sn * 1024, ops++)
+                if (c + lane * 16 < rbytes)
+                    dma16_to_lds_u(grec + c + lane * 16, sb + off_rec + c);
+        }
+        if (HASDINV) {
+            for (int c = sw * 64; c < rows_; c += sn * 64, ops++)
+                if (c + lane < rows_)
+                    dma4_to_lds_u(dinv + nb_ + c + lane, sb + off_dinv + (size_t)c * 4);
+        }
+        if (HASREC) { // (a tracked global read of col inside the reduction would drain this wave's whole pipeline)
+            for (int c = sw * 64; c < ne_; c += sn * 64, ops++)
+                if (c + lane < ne_)
+                    dma4_to_lds_u(col + e0_ + c + lane, sb + off_col + (size_t)c * 4);
+        }
+        return ops;
+    };
+
+    // reduce one landed stage; returns the number of store instructions the wave issued
+    auto compute = [&](int slot, int nb_, int rows_, int e0_) -> int {
+        const char *sb = wbase + (size_t)slot * slot_bytes;
+        const float *sx = reinterpret_cast<const float *>(sb);
+        const float *sq = reinterpret_cast<const float *>(sb + off_q);
+        const int4 *srec = reinterpret_cast<const int4 *>(sb + off_rec);
+        const float *sdinv = reinterpret_cast<const float *>(sb + off_dinv);
+        const int32_t *scol = reinterpret_cast<const int32_t *>(sb + off_col) - e0_; // indexed by the CSR slot itself
+        int nst = 0;
+        for (int rb = sw * 2 * groups; rb < rows_; rb += sn * 2 * groups) {
+            const bool has_b = rb + groups < rows_; // wave-uniform: the second row's store exists or not for the whole wave
+            for (int f = gl; f < nvec; f += G) {
+                const int fo = f * VEC;
+                LdsRow<MODE, VEC, true, NT> A, B;
+                A.begin(rb + grp < rows_, nb_, rb + grp, sx, sq, srec, sdinv, selfq, w, fo);
+                if (has_b)
+                    B.begin(rb + groups + grp < rows_, nb_, rb + groups + grp, sx, sq, srec, sdinv, selfq, w, fo);
+                A.finish(nb_, sx, srec, sdinv, scol, out, w, fo, eps);
+                if (has_b)
+                    B.finish(nb_, sx, srec, sdinv, scol, out, w, fo, eps);
+            }
+            nst += KOUT * fiter * (has_b ? 2 : 1);
+        }
+        return nst;
+    };
+
+    for (;;) {
+        // ---- fill the ring: plan greedy stages of whole tiles and fire their DMA
+        while (nfifo < nslots && ts < t1) {
+            int rel = __builtin_amdgcn_readfirstlane(ts - wb);
+            if (rel >= 32 && wb + 63 < t1) { // slide the window (a tracked load: drain first so the counts stay exact)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wb = ts;
+                tfv = min(tile_first[min(wb + lane, num_tiles)], N);
+                tev = HASREC ? min(tile_edge[min(wb + lane, num_tiles)], E) : 0;
+                rel = 0;
+            }
+            const int nb_ = __builtin_amdgcn_readlane(tfv, rel);
+            const int e0_ = __builtin_amdgcn_readlane(tev, rel);
+            // a stage = a run of whole tiles whose rows AND CSR slice fit a slot.  The remaining rows are cut into
+            // EQUAL stages (a greedy cut leaves a tiny last stage, and every stage costs a memory latency when the
+            // ring is shallower than the range): aim at remaining / ceil(remaining / cap) rows, + half a tile
+            const int rem = max(tf_end - nb_, 1);
+            const int nrem = (rem + cap - 1) / cap;
+            const int cap_eff = min(cap, (rem + nrem - 1) / nrem + slack);
+            unsigned long long m = __ballot(lane > rel && wb + lane <= t1 && tfv - nb_ <= cap_eff && tev - e0_ <= ecap &&
+                                            tev >= e0_);
+            if (m == 0 && cap_eff < cap)
+                m = __ballot(lane > rel && wb + lane <= t1 && tfv - nb_ <= cap && tev - e0_ <= ecap && tev >= e0_);
+            int te;
+            bool big = false;
+            if (m == 0) { // the next tile alone exceeds a stage
+                te = ts + 1;
+                big = true;
+            } else {
+                te = wb + 63 - __builtin_clzll(m);
+            }
+            const int rows_ = __builtin_amdgcn_readlane(tfv, __builtin_amdgcn_readfirstlane(te - wb)) - nb_;
+            const int ne_ = big ? 0 : __builtin_amdgcn_readlane(tev, __builtin_amdgcn_readfirstlane(te - wb)) - e0_;
+            ts = te;
+            if (rows_ <= 0)
+                continue;
+            if (big) {
+                for (int r = sw * groups + grp; r < rows_; r += sn * groups)
+                    for (int f = gl; f < nvec; f += G)
+                        agg_row_direct<MODE, VEC, NT>(nb_ + r, x, selfq, out, node_rec, col, dinv, w, f * VEC, eps);
+                continue;
+            }
+            vm += issue(issue_slot, nb_, rows_, e0_, ne_);
+            RING_EV(1000000 + rows_); // stage issued
+#pragma unroll
+            for (int i = 0; i < RING_MAX_SLOTS; i++)
+                if (i == nfifo) {
+                    f_nb[i] = nb_;
+                    f_rows[i] = rows_;
+                    f_mark[i] = vm;
+                    f_e0[i] = e0_;
+                }
+            nfifo++;
+            issue_slot = issue_slot + 1 == nslots ? 0 : issue_slot + 1;
+        }
+        if (nfifo == 0)
+            break;
+        // ---- retire the oldest stage: everything issued after its DMA may stay in flight
+        RING_EV(2000000 + f_rows[0]); // waiting for the oldest stage
+        vmcnt_wait_n(min(vm - f_mark[0], 63));
+        if (COOP)
+            asm volatile("s_barrier" ::: "memory"); // every wave's share of the stage has landed
+        RING_EV(3000000 + f_rows[0]); // landed
+        vm += compute(head_slot, f_nb[0], f_rows[0], f_e0[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // its LDS reads are done before the slot is refilled
+        if (COOP)
+            asm volatile("s_barrier" ::: "memory"); // ... by every wave
+        RING_EV(4000000 + f_rows[0]); // reduced, stores issued
+#pragma unroll
+        for (int i = 0; i + 1 < RING_MAX_SLOTS; i++) {
+            f_nb[i] = f_nb[i + 1];
+            f_rows[i] = f_rows[i + 1];
+            f_mark[i] = f_mark[i + 1];
+            f_e0[i] = f_e0[i + 1];
+        }
+        nfifo--;
+        head_slot = head_slot + 1 == nslots ? 0 : head_slot + 1;
+    }
+}
+
+template <int MODE, int VEC, bool COOP>
+static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, const float *selfq,
+                                          float *out, int w, float eps, hipStream_t s)
+{
+    const Options &o = options();
+    if (t.num_tiles <= 0)
+        return hipSuccess;
+    const int nvec = w / VEC;
+    int glog2 = 0;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int devid = 0;
+        hipDeviceProp_t prop;
+        num_cus = (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+                      ? prop.multiProcessorCount : 256;
+    }
+    // per staged row: the row itself (PNA: p and q), its 32-B record, its normaliser, and 4 CSR entries (a stage
+    // whose CSR slice is longer than 4 per row -- multigraphs, hubs -- is cut shorter by the planner)
+    constexpr int ECAP_PER_ROW = 4;
+    const size_t per_row = (size_t)w * 4 * (MODE == GNNB_AGG_PNA ? 2 : 1) + (MODE != GNNB_AGG_COPY ? 32 + 4 + 4 * ECAP_PER_ROW : 0);
+    const int wgs = std::max(o.agg_ring_wg_per_cu, 1);
+    const size_t budget = (size_t)(o.agg_lds_kb > 0 ? std::min(std::max(o.agg_lds_kb, 8), 158) : 158 / wgs) * 1024;
+    int ns = std::min(std::max(o.agg_ring_slots, 1), RING_MAX_SLOTS);
+    int nw = o.agg_ring_waves;
+    int cap;
+    if (COOP) {
+        // one ring per workgroup: stages as large as the budget allows (whole graphs of a few hundred nodes fit)
+        if (nw <= 0)
+            nw = 16; // (measured: 16 waves issue a stage's DMA and drain its stores faster than 8)
+        nw = std::min(std::max(nw, 1), 16);
+        cap = (int)((budget / ns) / per_row);
+    } else {
+        // one ring per wave.  A stage must hold a whole tile = up to tile_rows - 1 rows of slack + one graph; with
+        // the caller's promise the bound is known, otherwise aim at molecule-sized graphs
+        const int want = t.max_graph_nodes_hint > 0 ? t.tile_rows - 1 + t.max_graph_nodes_hint : 36;
+        auto cap_of = [&](int nw_, int ns_) { return (int)((budget / nw_ / ns_) / per_row); };
+        if (nw <= 0) { // automatic: the most waves (8, 4, 2, 1) whose stages still hold `want` rows
+            nw = 8;
+            ns = 1;
+            while (nw > 1 && cap_of(nw, ns) < want)
+                nw >>= 1;
+        }
+        nw = std::min(std::max(nw, 1), 8);
+        cap = cap_of(nw, ns);
+    }
+    cap = std::min(std::max(cap, 1), 4096);
+    const int slot_bytes = (int)((((size_t)cap * per_row) + 15) & ~(size_t)15);
+    const size_t lds = (size_t)(COOP ? 1 : nw) * ns * slot_bytes;
+    // persistent: `wgs` workgroups per CU; fewer when the batch has fewer tiles than rings
+    int grid = num_cus * wgs;
+    grid = std::min(grid, COOP ? t.num_tiles : (t.num_tiles + nw - 1) / nw);
+    if (grid < 1)
+        grid = 1;
+    auto launch = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess)
+                return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, x, selfq, out, t.node_rec, t.col, t.dinv,
+                           t.tile_first, t.tile_edge, t.num_tiles, t.num_nodes, t.num_edges, w, glog2, cap,
+                           cap * ECAP_PER_ROW, ns, slot_bytes, std::max(t.tile_rows / 2, 1) + 2, eps);
+        return hipGetLastError();
+    };
+    if (o.agg_nt_store)
+        return launch(k_aggregate_ring<MODE, VEC, true, COOP>);
+    return launch(k_aggregate_ring<MODE, VEC, false, COOP>);
 }
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
@@ -1957,39 +1235,25 @@ hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, cons
 {
     const bool v4 = (width % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0) &&
                     (selfq == nullptr || ((uintptr_t)selfq & 15) == 0);
-    const bool stream = options().agg_variant == 0;
-    const bool rec = options().agg_variant == 3;
-    const bool dma = options().agg_variant == 4;
-    const bool pipe = options().agg_variant == 2;
-    const bool lds5 = options().agg_variant == 5;
-    const bool shot = options().agg_variant == 6;
+    const bool shot = options().agg_variant == 1, perwave = options().agg_variant == 2;
 #define GNNB_AGG_CASE(K)                                                                         \
     case K:                                                                                      \
         if (shot)                                                                                \
             return v4 ? launch_aggregate_shot_t<K, 4>(t, x, selfq, out, width, eps, s)           \
                       : launch_aggregate_shot_t<K, 1>(t, x, selfq, out, width, eps, s);          \
-        if (lds5)                                                                                \
-            return v4 ? launch_aggregate_lds_t<K, 4>(t, x, selfq, out, width, eps, s)            \
-                      : launch_aggregate_lds_t<K, 1>(t, x, selfq, out, width, eps, s);           \
-        if (pipe)                                                                                \
-            return v4 ? launch_aggregate_pipe_t<K, 4>(t, x, selfq, out, width, eps, s)           \
-                      : launch_aggregate_pipe_t<K, 1>(t, x, selfq, out, width, eps, s);          \
-        if (dma)                                                                                 \
-            return v4 ? launch_aggregate_dma_t<K, 4>(t, x, selfq, out, width, eps, s)            \
-                      : launch_aggregate_dma_t<K, 1>(t, x, selfq, out, width, eps, s);           \
-        if (rec)                                                                                 \
-            return v4 ? launch_aggregate_rec_t<K, 4>(t, x, selfq, out, width, eps, s)            \
-                      : launch_aggregate_rec_t<K, 1>(t, x, selfq, out, width, eps, s);           \
-        if (stream)                                                                              \
-            return v4 ? launch_aggregate_stream_t<K, 4>(t, x, selfq, out, width, eps, s)         \
-                      : launch_aggregate_stream_t<K, 1>(t, x, selfq, out, width, eps, s);        \
-        return v4 ? launch_aggregate_t<K, 4>(t, x, selfq, out, width, eps, s)                    \
-                  : launch_aggregate_t<K, 1>(t, x, selfq, out, width, eps, s);
+        if (perwave)                                                                             \
+            return v4 ? launch_aggregate_ring_t<K, 4, false>(t, x, selfq, out, width, eps, s)    \
+                      : launch_aggregate_ring_t<K, 1, false>(t, x, selfq, out, width, eps, s);   \
+        return v4 ? launch_aggregate_ring_t<K, 4, true>(t, x, selfq, out, width, eps, s)         \
+                  : launch_aggregate_ring_t<K, 1, true>(t, x, selfq, out, width, eps, s);
     switch (kind) {
         GNNB_AGG_CASE(GNNB_AGG_GCN)
         GNNB_AGG_CASE(GNNB_AGG_SUM)
         GNNB_AGG_CASE(GNNB_AGG_MEAN)
         GNNB_AGG_CASE(GNNB_AGG_PNA)
+        GNNB_AGG_CASE(GNNB_AGG_LG)
+        GNNB_AGG_CASE(GNNB_AGG_SIMPLE)
+        GNNB_AGG_CASE(GNNB_AGG_COPY)
     default:
         return hipErrorInvalidValue;
     }
@@ -4192,7 +3456,7 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
             return;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_WG), lds, s, x, f0, t.node_rec, t.col, t.dinv,
-                           t.tile_first, t.tile_graph, t.node_ptr, t.num_tiles, t.num_graphs, w0, b0, h0, w1, b1, h1, p0, p1, p2,
+                           t.tile_first, t.tile_graph, t.graph_ptr, t.num_tiles, t.num_graphs, w0, b0, h0, w1, b1, h1, p0, p1, p2,
                            num_pools, pooled);
         rc = hipGetLastError();
     };

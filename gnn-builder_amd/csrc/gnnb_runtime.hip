@@ -51,10 +51,11 @@ static int env_int(const char *name, int dflt)
 
 Options &options()
 {
-    static Options o = {env_int("GNNB_TILE_ROWS", 16), env_int("GNNB_AGG_LDS_KB", 39),
-                        env_int("GNNB_AGG_TILES_PER_WG", 1), env_int("GNNB_AGG_OVERSHOOT", 32),
-                        env_int("GNNB_AGG_VARIANT", 6),      env_int("GNNB_AGG_ROWS_PER_WG", 48),
-                        env_int("GNNB_AGG_XCD_REMAP", 1),    env_int("GNNB_GEMM_VARIANT", 0),
+    static Options o = {env_int("GNNB_TILE_ROWS", 8), env_int("GNNB_AGG_LDS_KB", 0),
+                        env_int("GNNB_AGG_TILES_PER_WG", 1),  env_int("GNNB_AGG_VARIANT", 0),
+                        env_int("GNNB_AGG_RING_WAVES", 0),    env_int("GNNB_AGG_RING_SLOTS", 2),
+                        env_int("GNNB_AGG_RING_WG_PER_CU", 1), env_int("GNNB_AGG_NT_STORE", 1),
+                        env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_GEMM_DMA", 1),
                         env_int("GNNB_FUSE_NARROW", 1),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
@@ -187,18 +188,20 @@ int gnnb_set_option(const char *name, int value)
         return fail(GNNB_ERR_INVALID, "null option name");
     if (!strcmp(name, "tile_rows") && value >= 4)
         o.tile_rows = value;
-    else if (!strcmp(name, "agg_lds_kb") && value >= 4 && value <= 160)
-        o.agg_lds_kb = value;
+    else if (!strcmp(name, "agg_lds_kb") && value >= 0 && value <= 160)
+        o.agg_lds_kb = value; // 0 = default of the selected form
     else if (!strcmp(name, "agg_tiles_per_wg") && value >= 1)
         o.agg_tiles_per_wg = value;
-    else if (!strcmp(name, "agg_overshoot") && value >= 0)
-        o.agg_overshoot = value;
-    else if (!strcmp(name, "agg_variant") && value >= 0 && value <= 6)
+    else if (!strcmp(name, "agg_variant") && value >= 0 && value <= 2)
         o.agg_variant = value;
-    else if (!strcmp(name, "agg_rows_per_wg") && value >= 8 && value <= 4096)
-        o.agg_rows_per_wg = value;
-    else if (!strcmp(name, "agg_xcd_remap") && value >= 0 && value <= 1)
-        o.agg_xcd_remap = value;
+    else if (!strcmp(name, "agg_ring_waves") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16))
+        o.agg_ring_waves = value;
+    else if (!strcmp(name, "agg_ring_slots") && value >= 1 && value <= 4)
+        o.agg_ring_slots = value;
+    else if (!strcmp(name, "agg_ring_wg_per_cu") && value >= 1 && value <= 4)
+        o.agg_ring_wg_per_cu = value;
+    else if (!strcmp(name, "agg_nt_store") && value >= 0 && value <= 1)
+        o.agg_nt_store = value;
     else if (!strcmp(name, "fuse_narrow") && value >= 0 && value <= 1)
         o.fuse_narrow = value;
     else if (!strcmp(name, "fuse_gcn2") && value >= 0 && value <= 1)
@@ -379,7 +382,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     };
     const size_t N = max_nodes, E = std::max(max_edges, 1), B = max_graphs;
     const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
-                 o_att = carve(N * 4), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4),
+                 o_att = carve(N * 4), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_gptr = carve((B + 1) * 4),
                  o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4),
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
                  o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
@@ -400,6 +403,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->t.amp = (float *)(b + o_amp);
     ws->t.att = (float *)(b + o_att);
     ws->t.tile_first = (int32_t *)(b + o_tile);
+    ws->t.graph_ptr = (int32_t *)(b + o_gptr);
     ws->t.tile_edge = (int32_t *)(b + o_tedge);
     ws->t.tile_graph = (int32_t *)(b + o_tgraph);
     ws->t.err = (int32_t *)(b + o_err);
@@ -466,7 +470,10 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     // the degree scalers (amp / att) are only read by PNA layers: a model-bound workspace of another conv type
     // skips their computation and their 8 B/node of writes (delta <= 0 tells the kernel)
     const float prep_delta = ws->desc.conv_type == GNNB_CONV_PNA ? pna_delta : -1.0f;
-    GNNB_HIP_TRY(launch_graph_prep(coo_dev, node_ptr_dev, edge_ptr_dev, t, prep_delta,
+    // GCN: an explicit self-loop edge is not entered into the tables (PyG's gcn_norm replaces the self loops of the
+    // input by exactly one per node; the reference C++ would count it on top of its own self term, see gnnb_hip.h)
+    const int drop_self = ws->desc.conv_type == GNNB_CONV_GCN ? 1 : 0;
+    GNNB_HIP_TRY(launch_graph_prep(coo_dev, node_ptr_dev, edge_ptr_dev, t, prep_delta, drop_self,
                                    (hipStream_t)stream));
     ws->prepared = true;
     return GNNB_OK;
@@ -496,16 +503,17 @@ int gnnb_graph_tables_to_host(gnnb_workspace *ws, int32_t *row_ptr, int32_t *col
         return fail(GNNB_ERR_INVALID, "workspace has no prepared batch");
     hipStream_t s = (hipStream_t)stream;
     const int N = ws->t.num_nodes, E = ws->t.num_edges;
-    std::vector<int32_t> rp((size_t)N + 1);
-    GNNB_HIP_TRY(hipMemcpyAsync(rp.data(), ws->t.row_ptr, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> rec(in_deg ? (size_t)N * 8 : 0); // node records {start, degree, j0, j1}{j2, j3, -, -}
+    if (row_ptr)
+        GNNB_HIP_TRY(hipMemcpyAsync(row_ptr, ws->t.row_ptr, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (in_deg && N > 0)
+        GNNB_HIP_TRY(hipMemcpyAsync(rec.data(), ws->t.node_rec, (size_t)N * 32, hipMemcpyDeviceToHost, s));
     if (col && E > 0)
         GNNB_HIP_TRY(hipMemcpyAsync(col, ws->t.col, (size_t)E * 4, hipMemcpyDeviceToHost, s));
     GNNB_HIP_TRY(hipStreamSynchronize(s));
-    if (row_ptr)
-        memcpy(row_ptr, rp.data(), ((size_t)N + 1) * 4);
     if (in_deg)
         for (int i = 0; i < N; i++)
-            in_deg[i] = rp[i + 1] - rp[i];
+            in_deg[i] = rec[(size_t)i * 8 + 1];
     return GNNB_OK;
 }
 
@@ -516,7 +524,7 @@ int gnnb_aggregate(gnnb_workspace *ws, int agg_kind, const float *x_dev, const f
         return fail(GNNB_ERR_INVALID, "gnnb_aggregate needs a prepared batch (gnnb_graph_prep)");
     if (!x_dev || !out_dev || width < 1)
         return fail(GNNB_ERR_INVALID, "bad argument to gnnb_aggregate");
-    if (agg_kind < GNNB_AGG_GCN || agg_kind > GNNB_AGG_PNA)
+    if (agg_kind < GNNB_AGG_GCN || agg_kind > GNNB_AGG_COPY)
         return fail(GNNB_ERR_INVALID, "unknown aggregate kind %d", agg_kind);
     if (agg_kind == GNNB_AGG_PNA && !self_dev)
         return fail(GNNB_ERR_INVALID, "PNA aggregate needs the per-destination term");
@@ -583,7 +591,7 @@ int gnnb_global_pool(gnnb_workspace *ws, const float *x_dev, int d, const int32_
     for (int i = 0; i < num_pools; i++)
         if (pools[i] < 0 || pools[i] > GNNB_POOL_MAX)
             return fail(GNNB_ERR_INVALID, "unsupported pooling %d", pools[i]);
-    GNNB_HIP_TRY(launch_global_pool(x_dev, ws->t.node_ptr, ws->t.num_graphs, d, pools, num_pools,
+    GNNB_HIP_TRY(launch_global_pool(x_dev, ws->t.graph_ptr, ws->t.num_graphs, d, pools, num_pools,
                                     out_dev, (hipStream_t)stream));
     return GNNB_OK;
 }
@@ -626,7 +634,7 @@ int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const flo
                 head.dims[i] = din;
                 head.dims[i + 1] = dout;
             }
-            he = launch_pool_mlp(nullptr, ws->t.node_ptr, B, d.out_dim, d.pools, d.num_pools, head, d.mlp_activation,
+            he = launch_pool_mlp(nullptr, ws->t.graph_ptr, B, d.out_dim, d.pools, d.num_pools, head, d.mlp_activation,
                                  out_dev, (hipStream_t)stream, ws->pooled);
             if (he == hipSuccess)
                 return GNNB_OK;
@@ -763,10 +771,10 @@ int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const flo
                 // 119 KB of LDS of the one-launch form, so both share CUs with other batches' kernels
                 if ((rc = gnnb_global_pool(ws, cur, gw, d.pools, d.num_pools, ws->pooled, stream)))
                     return rc;
-                he = launch_pool_mlp(nullptr, ws->t.node_ptr, B, gw, d.pools, d.num_pools, head, d.mlp_activation, out_dev,
+                he = launch_pool_mlp(nullptr, ws->t.graph_ptr, B, gw, d.pools, d.num_pools, head, d.mlp_activation, out_dev,
                                      (hipStream_t)stream, ws->pooled);
             } else {
-                he = launch_pool_mlp(cur, ws->t.node_ptr, B, gw, d.pools, d.num_pools, head, d.mlp_activation, out_dev,
+                he = launch_pool_mlp(cur, ws->t.graph_ptr, B, gw, d.pools, d.num_pools, head, d.mlp_activation, out_dev,
                                      (hipStream_t)stream);
             }
             if (he == hipSuccess)

@@ -56,6 +56,10 @@ class _GCNConv(nn.Module):
 
     def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
         n = x.size(0)
+        # PyG gcn_norm -> add_remaining_self_loops: the input's explicit self loops are REPLACED by exactly one
+        # self loop per node, so an edge (v, v) neither adds a message nor raises the degree
+        if edge_index.numel():
+            edge_index = edge_index[:, edge_index[0] != edge_index[1]]
         src, dst = edge_index[0], edge_index[1]
         dinv = (_in_degree(edge_index, n).to(x.dtype) + 1.0).pow(-0.5)
         h = self.lin(x)

@@ -24,7 +24,7 @@ CSRC_DIR = PKG_DIR / "csrc"
 CONV = {"gcn": 0, "gin": 1, "sage": 2, "pna": 3}
 ACT = {"relu": 0, "gelu": 1, "sigmoid": 2, "tanh": 3, "none": 4}
 POOL = {"add": 0, "mean": 1, "max": 2}
-AGG = {"gcn": 0, "sum": 1, "mean": 2, "pna": 3}
+AGG = {"gcn": 0, "sum": 1, "mean": 2, "pna": 3, "lg": 4, "simple": 5, "copy": 6}
 
 GNNB_OK = 0
 

@@ -159,7 +159,10 @@ typedef enum gnnb_agg {
     GNNB_AGG_GCN = 0,  /* sum_j x_j/sqrt((1+d_i)(1+d_j)) + x_i/(1+d_i)   gnn_builder_lib.h:1213-1289 */
     GNNB_AGG_SUM = 1,  /* sum_j x_j + (1+eps) x_i                         gnn_builder_lib.h:1389-1437,1525-1535 */
     GNNB_AGG_MEAN = 2, /* mean_j x_j (0 if no neighbour)                  gnn_builder_lib.h:2161-2209 */
-    GNNB_AGG_PNA = 3   /* [max|min|mean|std]_j (q_i + p_j), out width 4w  gnn_builder_lib.h:1750-1834, PyG std */
+    GNNB_AGG_PNA = 3,  /* [max|min|mean|std]_j (q_i + p_j), out width 4w  gnn_builder_lib.h:1750-1834, PyG std */
+    GNNB_AGG_LG = 4,   /* sum_j x_j/sqrt(d_i d_j), no self term, 0 where d_i d_j = 0   gnn_builder_lib.h:2350-2499 (lg_conv) */
+    GNNB_AGG_SIMPLE = 5, /* sum_j x_j, no self term                           gnn_builder_lib.h:2501-2634 (simple_conv) */
+    GNNB_AGG_COPY = 6  /* out = x: the kernel's launch shape and bytes with no gather (calibration of the roofline) */
 } gnnb_agg;
 /* Gather-aggregate over the prepared batch.  x_dev [N,width]; out_dev [N,width]
  * ([N,4*width] for PNA).  self_dev: PNA only, the per-destination term q [N,width]

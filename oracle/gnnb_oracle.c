@@ -409,6 +409,21 @@ int gnnb_oracle_forward(const gnnb_oracle_desc *d, const float *const *params, c
         return -2; /* models.py:512-518 */
 
     size_t nn = (size_t)(n > 0 ? n : 1), ee = (size_t)(e > 0 ? e : 1);
+    /* GCN, PyG semantics: explicit self loops are not edges (gcn_norm -> add_remaining_self_loops keeps exactly
+     * one self loop per node); the reference C++ would count them on top of its self term (HLS mode). */
+    int32_t *noloop = NULL;
+    if (d->conv_type == GNNB_O_CONV_GCN && d->gcn_self_loop_mode == GNNB_O_SELF_LOOPS_PYG) {
+        noloop = (int32_t *)malloc(sizeof(int32_t) * 2 * ee);
+        int m = 0;
+        for (int i = 0; i < e; i++)
+            if (coo[2 * i] != coo[2 * i + 1]) {
+                noloop[2 * m] = coo[2 * i];
+                noloop[2 * m + 1] = coo[2 * i + 1];
+                m++;
+            }
+        coo = noloop;
+        e = m;
+    }
     int32_t *in_deg = (int32_t *)malloc(sizeof(int32_t) * nn);
     int32_t *out_deg = (int32_t *)malloc(sizeof(int32_t) * nn);
     int32_t *offsets = (int32_t *)malloc(sizeof(int32_t) * nn);
@@ -495,6 +510,7 @@ int gnnb_oracle_forward(const gnnb_oracle_desc *d, const float *const *params, c
     free(out_deg);
     free(offsets);
     free(nbrs);
+    free(noloop);
     return 0;
 }
 

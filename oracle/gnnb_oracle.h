@@ -34,7 +34,14 @@ enum { GNNB_O_POOL_ADD = 0, GNNB_O_POOL_MEAN = 1, GNNB_O_POOL_MAX = 2 };
 /* PNA std flavour: PyG (production parity target) or the HLS library formula. */
 enum { GNNB_O_STD_PYG = 0, GNNB_O_STD_HLS = 1 };
 
-/* Same field order as include/gnnb_hip.h's gnnb_model_desc plus pna_std_mode. */
+/* GCN and explicit self-loop edges (v, v) in the input.  PYG (production parity target): PyG's gcn_norm calls
+ * add_remaining_self_loops, which REPLACES the input's self loops by exactly one per node (weight 1), so an
+ * explicit self loop neither adds a message nor raises the degree.  HLS: the reference C++ counts the edge in
+ * the in-degree and sums its message IN ADDITION to its own self term (gnn_builder_lib.h:1234-1278).  The two
+ * agree on inputs without self loops (every molecule set). */
+enum { GNNB_O_SELF_LOOPS_PYG = 0, GNNB_O_SELF_LOOPS_HLS = 1 };
+
+/* Same field order as include/gnnb_hip.h's gnnb_model_desc plus pna_std_mode, gcn_self_loop_mode. */
 typedef struct gnnb_oracle_desc {
     int32_t conv_type;
     int32_t num_layers;      /* gnn_num_layers (models.py:486) */
@@ -52,6 +59,7 @@ typedef struct gnnb_oracle_desc {
     float gin_eps;
     float pna_delta;
     int32_t pna_std_mode;
+    int32_t gcn_self_loop_mode;
 } gnnb_oracle_desc;
 
 /* graph prep: gnn_builder_lib.h:1051-1083, :1086-1124 */

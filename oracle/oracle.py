@@ -22,6 +22,7 @@ CONV = {"gcn": 0, "gin": 1, "sage": 2, "pna": 3}
 ACT = {"relu": 0, "gelu": 1, "sigmoid": 2, "tanh": 3, "none": 4}
 POOL = {"add": 0, "mean": 1, "max": 2}
 STD = {"pyg": 0, "hls": 1}
+SELF_LOOPS = {"pyg": 0, "hls": 1}
 
 
 class Desc(C.Structure):
@@ -42,6 +43,7 @@ class Desc(C.Structure):
         ("gin_eps", C.c_float),
         ("pna_delta", C.c_float),
         ("pna_std_mode", C.c_int32),
+        ("gcn_self_loop_mode", C.c_int32),
     ]
 
 
@@ -226,7 +228,7 @@ def global_pool(x, kind: str, use_ref: bool = False):
 
 
 # ----------------------------------------------------------------------------- whole model
-def make_desc(spec: dict, std: str = "pyg") -> Desc:
+def make_desc(spec: dict, std: str = "pyg", self_loops: str = None) -> Desc:
     """``spec`` is the plain-dict model description produced by
     ``gnnbuilder_amd.models.GNNModel.spec()`` (conv, num_layers, dims, activation, ...)."""
     d = Desc()
@@ -247,6 +249,9 @@ def make_desc(spec: dict, std: str = "pyg") -> Desc:
     d.gin_eps = spec.get("gin_eps", 0.0)
     d.pna_delta = spec.get("pna_delta", 1.0)
     d.pna_std_mode = STD[std]
+    # explicit self-loop edges under GCN: PyG drops them (parity target); the reference library counts them.
+    # std="hls" selects the reference library's flavour as a whole unless told otherwise.
+    d.gcn_self_loop_mode = SELF_LOOPS[self_loops if self_loops is not None else std]
     return d
 
 
@@ -256,9 +261,9 @@ def _param_array(params):
     return keep, arr
 
 
-def forward(spec: dict, params, x, coo, std: str = "pyg") -> np.ndarray:
+def forward(spec: dict, params, x, coo, std: str = "pyg", self_loops: str = None) -> np.ndarray:
     """Whole model on ONE graph; ``params`` in canonical order (see gnnb_oracle.h)."""
-    d = make_desc(spec, std)
+    d = make_desc(spec, std, self_loops)
     keep, arr = _param_array(params)
     assert len(keep) == lib().gnnb_oracle_num_params(C.byref(d)), "wrong number of parameters"
     x = _f32(x).reshape(-1, spec["in_dim"])
@@ -270,8 +275,9 @@ def forward(spec: dict, params, x, coo, std: str = "pyg") -> np.ndarray:
     return out
 
 
-def forward_batched(spec: dict, params, x, coo, node_ptr, edge_ptr, std: str = "pyg") -> np.ndarray:
-    d = make_desc(spec, std)
+def forward_batched(spec: dict, params, x, coo, node_ptr, edge_ptr, std: str = "pyg",
+                    self_loops: str = None) -> np.ndarray:
+    d = make_desc(spec, std, self_loops)
     keep, arr = _param_array(params)
     assert len(keep) == lib().gnnb_oracle_num_params(C.byref(d)), "wrong number of parameters"
     x = _f32(x).reshape(-1, spec["in_dim"])
