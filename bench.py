@@ -617,7 +617,7 @@ def main():
         if "copy_same_launch_shape" in agg:
             ceiling["own_float4_copy_same_launch_shape_hbm"] = agg["copy_same_launch_shape"]
         gather = {
-            "kernel": "k_aggregate_shot<GCN> (gather-aggregate, width %d)" % w["hidden"],
+            "kernel": "k_aggregate_ring<GCN> (gather-aggregate, width %d)" % w["hidden"],
             "bound": "hbm", "achieved": agg["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic("aggregate"),
             "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": agg["hbm"]["us"],

@@ -47,6 +47,8 @@ struct Options {
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
     int gemm_max_wg_per_cu;
     int gemm_dma;      // 1 = large-K GEMM through LDS-DMA when every segment is plain (default)
+    int gemm_wlds;     // 1 = K, N in {64,128}, no skip operand: weights-in-LDS, barrier-free kernel (default); 0 = register-resident weights
+    int gemm_wlds_slots; // ... its ring depth per wave (capped by what fits beside W in LDS)
     int fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
     int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)

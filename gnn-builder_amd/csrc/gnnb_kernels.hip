@@ -8,10 +8,35 @@
 // Wavefront = 64 lanes everywhere.  Reference semantics are cited per kernel
 // (paths relative to the reference repository root).
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "gnnb_internal.h"
 
 namespace gnnb {
+
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised first.
+// The attribute is per device and per kernel: remembered here per (device, kernel) under a lock, so that launches
+// from several host threads or on several devices of one process each get it, and the runtime call (a few
+// microseconds of host time) is not paid on every launch.
+static hipError_t ensure_dynamic_lds(const void *kern, size_t lds)
+{
+    if (lds <= 64 * 1024)
+        return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> granted;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[std::make_pair(dev, kern)];
+    if (have >= lds)
+        return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+        have = lds;
+    return e;
+}
 
 static constexpr int WG = 256; // 4 wavefronts
 
@@ -917,9 +942,8 @@ static hipError_t launch_aggregate_shot_t(const BatchTables &t, const float *x, 
     const size_t lds = (((size_t)rows_cap * per_row) + 15) & ~(size_t)15;
     const int grid = (t.num_tiles + tpw - 1) / tpw;
     auto kern = k_aggregate_shot<MODE, VEC>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess)
             return e;
     }
@@ -1214,9 +1238,8 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
     if (grid < 1)
         grid = 1;
     auto launch = [&](auto kern) -> hipError_t {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        {
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
             if (e != hipSuccess)
                 return e;
         }
@@ -2115,13 +2138,10 @@ static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const floa
     }
     const int num_stages = (M + stage_rows - 1) / stage_rows;
     auto kern = k_linear_reg<KQ, VEC_A, MATH>;
-    static size_t lds_allowed = 64 * 1024;
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess)
             return e;
-        lds_allowed = lds;
     }
     // persistent grid = what is resident at once (registers + LDS), asked of the runtime once per
     // LDS size and capped (MI355X_MICROARCH: keep <= 4 blocks of 256 threads per CU)
@@ -2175,6 +2195,276 @@ static hipError_t launch_linear_reg(const GemmArgs &g, const float *w, int ldw, 
     return hipErrorInvalidValue;
 }
 
+// -------------------------------------------------------------------------------------
+// k_linear_wlds: the K, N <= 128 dense update with the WEIGHTS IN LDS and no workgroup barrier in the loop.
+// Reference: `linear` per node vector (gnn_builder_lib.h:808-905); here Y[M,N] = act(A[M,K] . W[N,K]^T + b (+ skip)).
+//
+// What the probe of k_linear_reg showed (profiles/r02_linear_reg_probe.txt): of a wave's cycles 60 % are the MFMA
+// loop (two waves of a SIMD compete for one pipe), 23 % the per-stage barrier (four waves on four SIMDs, each
+// sharing its SIMD with a wave of another workgroup, arrive skewed) and 16 % the epilogue (transpose through LDS).
+// Here every WAVE is independent:
+//   * W (<= 64 KB) is loaded ONCE per workgroup into LDS (LDS-DMA, XOR-swizzled through the source address) and
+//     only read afterwards -- no synchronisation after the prologue;
+//   * each wave streams its own 16-row units of A through a private LDS ring (untracked LDS-DMA, counted vmcnt
+//     waits as in the gather-aggregate ring), so a slow wave delays nobody;
+//   * the MFMA operands are SWAPPED (W fragment as the A operand): the 16x16 accumulator then holds
+//     Y[m0 + li][n0 + 4 lg .. + 3] per lane, i.e. four CONSECUTIVE output columns -- bias / skip / activation are
+//     float4 operations and the result is stored with one 16-B store per tile, no transpose;
+//   * one wave per SIMD (four per CU): the fp32 matrix pipe has a single client that issues back to back, with the
+//     next k block's fragments requested from LDS before the current block's 4 NT MFMAs are issued.
+// Eligibility: K, N in {64, 128}, 16-B aligned rows; anything else takes k_linear_reg / k_linear.
+template <int KQ, int NT, int ACT>
+__global__ __launch_bounds__(WG, 1) void k_linear_wlds(const float *__restrict__ A, int lda, const float *__restrict__ W,
+                                                      int ldw, const float *__restrict__ bias, float *__restrict__ Y,
+                                                      int M, int nslots)
+{
+    constexpr int K = 16 * KQ, N = 16 * NT;
+    constexpr int C = K / 4;                           // 16-B chunks per A / W row
+    constexpr int P = C >= 16 ? 16 : C;                // XOR-swizzle period (power of two)
+    constexpr int SLOT = 16 * K * 4;                   // one 16-row unit of A; its DMA is exactly KQ wave-instructions
+    constexpr int TPB = (NT + KQ - 1) / KQ;            // deferred stores issued per k block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    char *wl = smem;                                   // W: N rows x K floats, swizzled
+    char *ring = smem + N * K * 4 + (size_t)wave * nslots * SLOT;
+
+    // ---- this wave's run of 16-row units
+    const int num_units = (M + 15) >> 4;
+    const int gw = blockIdx.x * (WG / 64) + wave, tw = gridDim.x * (WG / 64);
+    const int u0 = (int)(((long long)gw * num_units) / tw), u1 = (int)(((long long)(gw + 1) * num_units) / tw);
+
+    // ---- prologue: the whole W -> LDS, all four waves; chunk sl of row n lands in slot sl, holding source chunk sl ^ (n & (P-1))
+    for (int c0 = wave * 64; c0 < N * C; c0 += WG) {
+        const int L = c0 + lane;
+        if (L < N * C) {
+            const int n = L / C, sl = L - n * C;
+            dma16_to_lds_u(W + (size_t)n * ldw + ((sl ^ (n & (P - 1))) << 2), wl + (size_t)c0 * 16);
+        }
+    }
+    float4 bq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+        bq[t] = bias ? *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+        asm volatile("" : "+v"(bq[t].x), "+v"(bq[t].y), "+v"(bq[t].z), "+v"(bq[t].w)); // loaded HERE, not inside the loop
+
+    // one 1-KiB piece (64 chunks) of unit u's A rows -> its slot; returns 1 if the instruction was issued
+    const int lrow = lane / C, lsl = lane - lrow * C;  // (C >= 16: a piece covers 64 / C whole rows)
+    auto issue_piece = [&](int u, int slot, int q) -> int {
+        const int m0 = u << 4;
+        const int rows = min(16, M - m0);
+        if (q * 64 >= rows * C)
+            return 0; // wave-uniform
+        const int i = q * (64 / C) + lrow;
+        if (i < rows)
+            dma16_to_lds_u(A + (size_t)(m0 + i) * lda + ((lsl ^ (i & (P - 1))) << 2), ring + (size_t)slot * SLOT + (size_t)q * 1024);
+        return 1;
+    };
+
+    // ring bookkeeping: unit u lives in slot (u - u0) % nslots; f_mark[j] = VM operations issued when the DMA of the
+    // j-th oldest outstanding unit was complete
+    int vm = 0;
+    int f_mark[4] = {0, 0, 0, 0};
+    const int ahead = nslots - 1; // units requested before they are needed
+    for (int j = 0; j < (ahead > 0 ? ahead : 1) && u0 + j < u1; j++) {
+#pragma unroll
+        for (int q = 0; q < KQ; q++)
+            vm += issue_piece(u0 + j, j, q);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i == j)
+                f_mark[i] = vm;
+    }
+    // W (and the first units) landed for every wave: the only barrier of the kernel
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const float *wls = reinterpret_cast<const float *>(wl);
+    const int swz = li & (P - 1); // (16 t + li) & (P - 1) == li & (P - 1): one swizzle term for W rows and A rows
+#ifdef GNNB_PROBE
+    unsigned long long pt_wait = 0, pt_mma = 0, pt_epi = 0, pt0 = clock64(), pw0 = wall_clock64(), pt_last = pt0;
+#endif
+    float4 pv[NT];           // the previous unit's finished tiles: stored during THIS unit's MFMA stream
+    int pm = M;              // ... their row (>= M: nothing to store)
+    bool have_prev = false;  // wave-uniform
+    int head_slot = 0, fill_slot = ahead == 0 ? 0 : (ahead % nslots);
+    auto store_prev = [&](int t) { // tile t of the previous unit
+        if (pm < M)
+            *reinterpret_cast<float4 *>(Y + (size_t)pm * N + 16 * t + 4 * lg) = pv[t];
+    };
+    for (int u = u0; u < u1; u++) {
+        vmcnt_wait_n(min(vm - f_mark[0], 63));
+        GNNB_PT(pt_wait, pt_last);
+        const float *sa = reinterpret_cast<const float *>(ring + (size_t)head_slot * SLOT);
+        const int un = u + ahead;                 // the unit requested during this one (into the slot freed last time)
+        const bool more = ahead > 0 && un < u1;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto afrag = [&](int q) { return *reinterpret_cast<const float4 *>(sa + li * K + (((4 * q + lg) ^ swz) << 2)); };
+        auto wfrag = [&](int q, int t) {
+            return *reinterpret_cast<const float4 *>(wls + (16 * t + li) * K + (((4 * q + lg) ^ swz) << 2));
+        };
+        // Two fragment sets, statically alternated (the q loop is fully unrolled).  The scheduler barriers pin the
+        // order "request block q+1's nine fragments, THEN issue block q's 4 NT MFMAs": left alone the compiler sinks
+        // every ds_read to just above its first use and the single wave of the SIMD eats the LDS latency nine
+        // times per k block (measured: 2x).  The previous unit's stores and the next unit's DMA pieces ride in the
+        // same stream, one piece per k block: a vector-memory issue costs the wave 60-180 cycles, which the matrix
+        // pipe spends on the MFMAs already queued.
+        float4 af[2], wf[2][NT];
+        af[0] = afrag(0);
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            wf[0][t] = wfrag(0, t);
+#pragma unroll
+        for (int q = 0; q < KQ; q++) {
+            const int cb = q & 1, nb2 = cb ^ 1;
+            if (q + 1 < KQ) {
+                af[nb2] = afrag(q + 1);
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    wf[nb2][t] = wfrag(q + 1, t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (have_prev) {
+#pragma unroll
+                for (int i = 0; i < TPB; i++)
+                    if (q * TPB + i < NT) {
+                        store_prev(q * TPB + i);
+                        vm++;
+                    }
+            }
+            if (more)
+                vm += issue_piece(un, fill_slot, q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sk = 0; sk < 4; sk++) {
+                const float av = sk == 0 ? af[cb].x : (sk == 1 ? af[cb].y : (sk == 2 ? af[cb].z : af[cb].w));
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const float wv = sk == 0 ? wf[cb][t].x : (sk == 1 ? wf[cb][t].y : (sk == 2 ? wf[cb][t].z : wf[cb][t].w));
+                    // operands swapped: D[n][m] -- the lane ends up with Y[m0 + li][16 t + 4 lg + r], r = 0..3
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, av, acc[t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef GNNB_PROBE
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[NT - 1][3]));
+#endif
+        GNNB_PT(pt_mma, pt_last);
+        // ---- epilogue (VALU only): bias + activation on float4; the stores follow inside the next unit's stream
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            pv[t].x = act_t<ACT>(acc[t][0] + bq[t].x);
+            pv[t].y = act_t<ACT>(acc[t][1] + bq[t].y);
+            pv[t].z = act_t<ACT>(acc[t][2] + bq[t].z);
+            pv[t].w = act_t<ACT>(acc[t][3] + bq[t].w);
+        }
+        pm = (u << 4) + li;
+        have_prev = true;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this slot's LDS reads are done before it is refilled
+        // retire unit u; the unit requested during it joins the tail of the queue
+#pragma unroll
+        for (int i = 0; i + 1 < 4; i++)
+            f_mark[i] = f_mark[i + 1];
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (i == ahead - 1)
+                    f_mark[i] = vm;
+        }
+        if (ahead == 0 && u + 1 < u1) { // single slot: no overlap, request the next unit now
+#pragma unroll
+            for (int q = 0; q < KQ; q++)
+                vm += issue_piece(u + 1, 0, q);
+            f_mark[0] = vm;
+        }
+        fill_slot = head_slot; // the slot just consumed is the next to be refilled
+        head_slot = head_slot + 1 == nslots ? 0 : head_slot + 1;
+        GNNB_PT(pt_epi, pt_last);
+    }
+    if (have_prev) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            store_prev(t);
+    }
+#ifdef GNNB_PROBE
+    if (lane == 0 && wave == 0 && blockIdx.x < 8192) {
+        unsigned long long *o = g_probe + blockIdx.x * 8;
+        o[0] = pw0;
+        o[1] = wall_clock64();
+        o[2] = pt_wait;
+        o[3] = pt_mma;
+        o[4] = pt_epi;
+        o[5] = clock64() - pt0;
+        o[6] = (unsigned long long)(u1 - u0);
+    }
+#endif
+}
+
+static bool linear_wlds_eligible(const GemmArgs &g, const float *w, int ldw, const float *bias, const float *skip,
+                                 const float *y, int N)
+{
+    if (options().gemm_variant != 0 || options().math != 0 || !options().gemm_wlds)
+        return false;
+    if (skip != nullptr) // (a skip tile per unit would not leave room for the ring beside a 64 KB W: k_linear_reg)
+        return false;
+    if (g.nseg != 1 || g.rs[0] != nullptr || !g.avec[0])
+        return false;
+    const int K = g.k[0];
+    if (!(K == 64 || K == 128) || !(N == 64 || N == 128))
+        return false;
+    return (ldw % 4 == 0) && (((uintptr_t)w & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
+           (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (skip == nullptr || ((uintptr_t)skip & 15) == 0);
+}
+
+static hipError_t launch_linear_wlds(const GemmArgs &g, const float *w, int ldw, const float *bias, const float *skip,
+                                     float *y, int M, int N, int act, hipStream_t s)
+{
+    const int K = g.k[0];
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int devid = 0;
+        hipDeviceProp_t prop;
+        num_cus = (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+                      ? prop.multiProcessorCount : 256;
+    }
+    const int slot = 16 * K * 4;
+    // ring depth: what fits beside W in the CU's 160 KiB of LDS, at most 4.  A unit is requested ns - 1 units before
+    // it is needed, piece by piece inside the MFMA stream.  Measured (tools/bench_gemm.py): ns = 2 beats ns = 3 at the
+    // BASELINE sizes (31.9 vs 35.8 us at M = 73 763): a wave has only 4-7 units, and the deeper ring's longer blocking
+    // prologue costs more than its steadier stream gains.
+    int ns = (int)((160 * 1024 - (size_t)N * K * 4) / ((size_t)4 * slot));
+    ns = std::min(std::max(ns, 1), std::min(options().gemm_wlds_slots, 4));
+    const size_t lds = (size_t)N * K * 4 + (size_t)4 * ns * slot;
+    const int num_units = (M + 15) / 16;
+    int grid = std::min(num_cus, (num_units + 3) / 4);
+    if (grid < 1)
+        grid = 1;
+    hipError_t rc = hipSuccess;
+    auto go = [&](auto atag, auto qtag, auto ntag) {
+        constexpr int ACT = decltype(atag)::value, KQ = decltype(qtag)::value, NTL = decltype(ntag)::value;
+        auto kern = k_linear_wlds<KQ, NTL, ACT>;
+        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+        if (rc != hipSuccess)
+            return;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), lds, s, g.a[0], g.lda[0], w, ldw, bias, y, M, ns);
+        rc = hipGetLastError();
+    };
+    auto go_k = [&](auto atag) {
+        if (K == 128 && N == 128) go(atag, IntTag<8>{}, IntTag<8>{});
+        else if (K == 128) go(atag, IntTag<8>{}, IntTag<4>{});
+        else if (N == 128) go(atag, IntTag<4>{}, IntTag<8>{});
+        else go(atag, IntTag<4>{}, IntTag<4>{});
+    };
+    GNNB_DISPATCH_ACT(act, go_k)
+    return rc;
+}
+
 // Fused narrow-input conv: Y = act(aggregate(x) . W^T + b (+ skip)) in one launch (K <= 32).
 hipError_t launch_conv_gather(const BatchTables &t, int agg_kind, float eps, const float *x, int lda,
                               int K, const float *w, int ldw, const float *bias, const float *skip,
@@ -2200,6 +2490,8 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
 {
     if (M <= 0 || N <= 0)
         return hipSuccess;
+    if (linear_wlds_eligible(g, w, ldw, bias, skip, y, N))
+        return launch_linear_wlds(g, w, ldw, bias, skip, y, M, N, act, s);
     if (linear_reg_eligible(g))
         return launch_linear_reg(g, w, ldw, bias, skip, y, M, N, act, s);
     const int gm = (M + BM - 1) / BM;
@@ -2209,13 +2501,10 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             plain = g.avec[sg] && g.wvec[sg] && (g.k[sg] % BK == 0) && (g.koff[sg] % 4 == 0);
         if (plain) {
             const size_t lds = 2 * 2 * (size_t)BM * BK * 4;
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            {
+                hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_linear_dma), lds);
                 if (e != hipSuccess)
                     return e;
-                attr_set = true;
             }
             hipLaunchKernelGGL(k_linear_dma, dim3(gm, (N + 127) / 128), dim3(WG), lds, s, g, w, ldw, bias, skip, y, M, N,
                                act);
@@ -2225,13 +2514,10 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
     if (N > 64) {
         constexpr int NT = 2;
         const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * 64 * NT * LDS_LD) * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear<NT>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        {
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_linear<NT>), lds);
             if (e != hipSuccess)
                 return e;
-            attr_set = true;
         }
         hipLaunchKernelGGL(k_linear<NT>, dim3(gm, (N + 127) / 128), dim3(WG), lds, s, g, w, ldw,
                            bias, skip, y, M, N, act);
@@ -2766,12 +3052,7 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
     auto go = [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
         auto kern = k_pool_mlp<ACT>;
-        static size_t lds_allowed = 64 * 1024;
-        if (lds > lds_allowed) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) == hipSuccess)
-                lds_allowed = lds;
-        }
+        (void)ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(HEAD_THREADS), lds, s, x, node_ptr, num_graphs, d, glog2, p0, p1, p2,
                            num_pools, head, out, prepooled, act0_floats, act1_floats, woff[0], woff[1], woff[2], woff[3], woff[4], woff[5],
                            woff[6], woff[7]);
@@ -3429,15 +3710,13 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
         constexpr int MATH = decltype(mtag)::value;
         auto kern = k_gcn2_fused<ACT, KQ0, KQ1, MATH>;
-        static size_t lds_set = 0;
+        if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess) {
+            rc = hipErrorNotSupported;
+            return;
+        }
+        static size_t lds_set = 0; // (occupancy of this instantiation at this LDS size: the same on every MI355X of a node)
         static int blocks = 0, cus = 256;
         if (lds_set != lds) {
-            if (lds > 64 * 1024 &&
-                hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess) {
-                rc = hipErrorNotSupported;
-                return;
-            }
             int nb = 0, devid = 0;
             hipDeviceProp_t prop;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G2_WG, lds) != hipSuccess || nb < 1)

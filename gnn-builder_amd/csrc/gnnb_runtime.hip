@@ -57,6 +57,7 @@ Options &options()
                         env_int("GNNB_AGG_RING_WG_PER_CU", 1), env_int("GNNB_AGG_NT_STORE", 1),
                         env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_GEMM_DMA", 1),
+                        env_int("GNNB_GEMM_WLDS", 1),             env_int("GNNB_GEMM_WLDS_SLOTS", 2),
                         env_int("GNNB_FUSE_NARROW", 1),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
@@ -218,6 +219,10 @@ int gnnb_set_option(const char *name, int value)
         o.gemm_variant = value;
     else if (!strcmp(name, "gemm_dma") && value >= 0 && value <= 1)
         o.gemm_dma = value;
+    else if (!strcmp(name, "gemm_wlds") && value >= 0 && value <= 1)
+        o.gemm_wlds = value;
+    else if (!strcmp(name, "gemm_wlds_slots") && value >= 1 && value <= 4)
+        o.gemm_wlds_slots = value;
     else if (!strcmp(name, "gemm_max_wg_per_cu") && value >= 1 && value <= 8)
         o.gemm_max_wg_per_cu = value;
     else

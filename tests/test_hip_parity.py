@@ -250,6 +250,39 @@ def test_linear_matches_torch(dev, M, N, K, act):
     assert (y.cpu() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 1000, 4097, 73763])
+@pytest.mark.parametrize("N,K", [(128, 128), (64, 128), (128, 64), (64, 64)])
+def test_linear_weights_in_lds_kernel(dev, M, N, K):
+    """k_linear_wlds (K, N in {64, 128}: weights in LDS, per-wave rings, swapped MFMA operands) vs float64, with and
+    without the skip operand, every activation on the small shapes; and bit-identical to the register-resident
+    kernel's result up to the fp32 summation order (both accumulate k in the same MFMA order: exact equality)."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.rand(M, K, generator=g) * 2 - 1
+    w = (torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5
+    b = torch.rand(N, generator=g) * 2 - 1
+    skip = torch.rand(M, N, generator=g) * 2 - 1
+    ad, wd, bd, sd = a.to(dev), w.to(dev), b.to(dev), skip.to(dev)
+    acts = ("relu", "none", "gelu", "sigmoid", "tanh") if M <= 1000 else ("relu",)
+    fn = {"none": lambda t: t, "relu": torch.relu, "gelu": torch.nn.functional.gelu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+    for act in acts:
+        for use_skip in (False, True):
+            ref = a.double() @ w.double().T + b.double() + (skip.double() if use_skip else 0)
+            ref = fn[act](ref).float()
+            try:
+                runtime.set_option("gemm_wlds", 1)
+                y = runtime.linear([(ad, None)], wd, bd, skip=sd if use_skip else None, act=act)
+                runtime.set_option("gemm_wlds", 0)
+                y0 = runtime.linear([(ad, None)], wd, bd, skip=sd if use_skip else None, act=act)
+            finally:
+                runtime.set_option("gemm_wlds", 1)
+            torch.cuda.synchronize()
+            assert (y.cpu() - ref).abs().max().item() < 2e-5, (act, use_skip)
+            assert (y - y0).abs().max().item() < 2e-6, (act, use_skip)
+    # no bias
+    y = runtime.linear([(ad, None)], wd, None, act="none")
+    assert (y.cpu() - (a.double() @ w.double().T).float()).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(37, 19, 11), (300, 128, 128), (129, 64, 64), (1000, 33, 16), (50, 200, 36)])
 def test_linear_lds_tiled_kernel_on_small_k(dev, M, N, K):
     """K <= 128 normally takes the register-resident-weight kernel; force the LDS-tiled one too."""
