@@ -68,10 +68,13 @@ class GraphBatch:
                 raise ValueError("an edge leaves its graph")
 
 
-def pack_graphs(graphs: Sequence[Tuple[np.ndarray, np.ndarray]]) -> GraphBatch:
-    """``graphs``: sequence of (x [n, F], edges) where edges is either ``[e, 2]`` (src, dst) rows
-    -- the tb_data ``*_coo.bin`` layout, reference code_gen.py:262 -- or a PyG-style
-    ``edge_index`` ``[2, e]``; ids are graph-local."""
+def pack_graphs(graphs: Sequence[Tuple[np.ndarray, np.ndarray]], layout: str = "coo") -> GraphBatch:
+    """``graphs``: sequence of (x [n, F], edges); ids are graph-local.  ``layout``: ``"coo"`` (default) = edges are
+    ``[e, 2]`` (src, dst) rows -- the tb_data ``*_coo.bin`` layout, reference code_gen.py:262, and what
+    ``GraphBatch.graph`` returns; ``"edge_index"`` = PyG-style ``[2, e]``; ``"auto"`` accepts either and refuses the
+    one ambiguous shape, ``[2, 2]``."""
+    if layout not in ("auto", "coo", "edge_index"):
+        raise ValueError("layout must be 'auto', 'coo' or 'edge_index'")
     xs, coos, nptr, eptr = [], [], [0], [0]
     feat = None
     for x, ei in graphs:
@@ -84,6 +87,16 @@ def pack_graphs(graphs: Sequence[Tuple[np.ndarray, np.ndarray]]) -> GraphBatch:
         ei = np.asarray(ei)
         if ei.size == 0:
             ei = np.zeros((0, 2), dtype=np.int32)
+        elif layout == "edge_index":
+            if ei.ndim != 2 or ei.shape[0] != 2:
+                raise ValueError("edge_index must be [2, e]")
+            ei = ei.T
+        elif layout == "coo":
+            if ei.ndim != 2 or ei.shape[1] != 2:
+                raise ValueError("coo edges must be [e, 2]")
+        elif ei.ndim == 2 and ei.shape == (2, 2):
+            raise ValueError("a [2, 2] edge array is ambiguous: pass layout='coo' (two (src, dst) rows) or "
+                             "layout='edge_index' (PyG [2, e])")
         elif ei.ndim == 2 and ei.shape[0] == 2 and ei.shape[1] != 2:
             ei = ei.T
         elif ei.ndim != 2 or ei.shape[1] != 2:

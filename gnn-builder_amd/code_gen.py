@@ -138,7 +138,7 @@ class Project:
     # ------------------------------------------------------------------ template context
     @cached_property
     def template_dict(self) -> dict:
-        from .runtime import ACT, CONV, POOL
+        from .runtime import ACT, CONV, OUT_ACT, POOL
 
         spec = self.model.spec()
         names = self.model.layer_parameter_names_flat
@@ -155,6 +155,7 @@ class Project:
             "mlp_num_linear": spec["mlp_hidden_layers"] + 1, "mlp_hidden": spec["mlp_hidden"],
             "mlp_out": spec["mlp_out"], "mlp_activation": ACT[spec["mlp_activation"]],
             "gin_eps": repr(float(spec["gin_eps"])), "pna_delta": repr(float(spec["pna_delta"])),
+            "output_activation": OUT_ACT[spec.get("output_activation")],
         }
         return {
             "name": self.name,

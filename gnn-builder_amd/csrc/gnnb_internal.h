@@ -14,6 +14,7 @@ struct BatchTables {
     int32_t *row_ptr;    // [N+1] START of every node's CSR row (batch-global); the row's length is node_rec[2v].y --
                          //       dropped edges leave a gap at the end of a graph's segment, so differences are not degrees
     int32_t *col;        // [E]   source node (batch-global id) of every in-edge, stable COO order
+    int32_t *eid;        // [E]   COO row of every CSR slot (the reference's edge_index_table, gnn_builder_lib.h:1126-1166)
     int4 *node_rec;      // [2N]  per node {rp0, deg, j0, j1}{j2, j3, -, -}: CSR row start, in-degree and
                          //       its first four sources, so one 32-B read feeds the whole gather
     float *dinv;         // [N]   GCN normaliser     1/sqrt(1 + in_degree)
@@ -67,6 +68,9 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s);
+// GINE: out_i = (1 + eps) x_i + sum_j relu(x_j + eterm[edge]); eterm [E, width] in COO order
+hipError_t launch_aggregate_edges(const BatchTables &t, const float *x, const float *eterm, float *out, int width,
+                                  float eps, hipStream_t s);
 
 struct GemmArgs {
     const float *a[4];
@@ -106,6 +110,8 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
 hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                              int h0, const float *w1, const float *b1, int h1, int act,
                              const int32_t *pools, int num_pools, float *pooled, hipStream_t s);
+
+hipError_t launch_output_activation(float *out, int num_graphs, int n, int kind, hipStream_t s);
 
 hipError_t launch_global_pool(const float *x, const int32_t *node_ptr, int num_graphs, int d,
                               const int32_t *pools, int num_pools, float *out, hipStream_t s);

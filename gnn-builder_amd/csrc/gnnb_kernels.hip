@@ -86,7 +86,7 @@ static constexpr int PREP_REG_CHUNKS = 4;
 // General path (any graph size): lane = destination node, edges scanned one at a time.
 __device__ void prep_graph_scan(
     const int2 *__restrict__ coo, int n0, int n1, int e0, int e1, int32_t *__restrict__ row_ptr,
-    int32_t *__restrict__ col, int4 *__restrict__ node_rec, float *__restrict__ dinv,
+    int32_t *__restrict__ col, int32_t *__restrict__ eid, int4 *__restrict__ node_rec, float *__restrict__ dinv,
     float *__restrict__ amp, float *__restrict__ att, float delta, int drop_self, int32_t *__restrict__ err)
 {
     const int lane = threadIdx.x & 63;
@@ -170,12 +170,13 @@ __device__ void prep_graph_scan(
         // the node record
         int pos = start;
         int jf[4] = {v, v, v, v};
-        auto put = [&](int src) {
+        auto put = [&](int src, int edge) {
             const int q = pos - start;
             if (q == 0) jf[0] = src;
             else if (q == 1) jf[1] = src;
             else if (q == 2) jf[2] = src;
             else if (q == 3) jf[3] = src;
+            eid[pos] = edge; // COO row of the CSR slot (compute_neighbor_and_edge_index_tables, gnn_builder_lib.h:1126-1166)
             col[pos++] = src;
         };
         if (inreg) {
@@ -187,7 +188,7 @@ __device__ void prep_graph_scan(
                         const int d = __builtin_amdgcn_readlane(rd[c], i);
                         const int sc = __builtin_amdgcn_readlane(rs[c], i);
                         if (d == v)
-                            put(sc);
+                            put(sc, e0 + c * 64 + i);
                     }
                 }
             }
@@ -200,7 +201,7 @@ __device__ void prep_graph_scan(
                     const int d = __builtin_amdgcn_readlane(ed, i);
                     const int sc = __builtin_amdgcn_readlane(es, i);
                     if (d == v)
-                        put(sc);
+                        put(sc, e0 + c * 64 + i);
                 }
             }
         }
@@ -230,7 +231,7 @@ template <int PREP_FAST_NODES>
 __global__ __launch_bounds__(WG) void k_graph_prep(
     const int2 *__restrict__ coo, const int32_t *__restrict__ node_ptr,
     const int32_t *__restrict__ edge_ptr, int B, int N, int E, int32_t *__restrict__ row_ptr,
-    int32_t *__restrict__ col, int4 *__restrict__ node_rec, float *__restrict__ dinv,
+    int32_t *__restrict__ col, int32_t *__restrict__ eid, int4 *__restrict__ node_rec, float *__restrict__ dinv,
     float *__restrict__ amp, float *__restrict__ att, float delta,
     int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int32_t *__restrict__ tile_graph,
     int32_t *__restrict__ graph_ptr, int tile_rows, int num_tiles, int max_graph_nodes_hint, int drop_self,
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     if (max_graph_nodes_hint > 0 && n > max_graph_nodes_hint && lane == 0)
         atomicOr(err, 8); // the caller's max_graph_nodes promise does not hold for this batch
     if (n > PREP_FAST_NODES || ne > PREP_FAST_EDGES) { // wave-uniform
-        prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, node_rec, dinv, amp, att, delta, drop_self, err);
+        prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, eid, node_rec, dinv, amp, att, delta, drop_self, err);
         return;
     }
 
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             }
             if (ed[c] >= 0) {
                 col[st + erank[c]] = es[c];
+                eid[st + erank[c]] = e0 + c * 64 + lane; // COO row of this CSR slot (gnn_builder_lib.h:1126-1166)
                 if (erank[c] < 4)
                     s_first[wave][d * 4 + erank[c]] = es[c];
             }
@@ -451,12 +453,12 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
     const int grid = (waves + (WG / 64) - 1) / (WG / 64);
     if (t.max_graph_nodes_hint > 0 && t.max_graph_nodes_hint <= 64)
         hipLaunchKernelGGL(k_graph_prep<64>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
-                           edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.node_rec,
+                           edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
                            t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err);
     else
         hipLaunchKernelGGL(k_graph_prep<256>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
-                           edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.node_rec,
+                           edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
                            t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err);
     return hipGetLastError();
@@ -1251,6 +1253,62 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
     if (o.agg_nt_store)
         return launch(k_aggregate_ring<MODE, VEC, true, COOP>);
     return launch(k_aggregate_ring<MODE, VEC, false, COOP>);
+}
+
+// -------------------------------------------------------------------------------------
+// GINE aggregate (reference gine_conv_agg + the self term of gine_conv, gnn_builder_lib.h:1555-1742):
+//   out_i = (1 + eps) x_i + sum_{j -> i} relu(x_j + p_e),   p_e = W_e e_ij + b_e  (projected by the GEMM kernel,
+// [E, w] rows in COO order; the CSR slot's COO row comes from the edge-index table graph prep writes,
+// compute_neighbor_and_edge_index_tables :1126-1166).  One lane group per destination row, rows and edge terms
+// gathered straight from L2: GINE is not on a BASELINE workload, this is the plain form.
+template <int VEC>
+__global__ __launch_bounds__(WG) void k_aggregate_edges(const float *__restrict__ x, const float *__restrict__ eterm,
+                                                        float *__restrict__ out, const int4 *__restrict__ node_rec,
+                                                        const int32_t *__restrict__ col, const int32_t *__restrict__ eid,
+                                                        int N, int w, int glog2, float eps)
+{
+    typedef Vf<VEC> V;
+    const int G = 1 << glog2, groups = WG >> glog2;
+    const int grp = threadIdx.x >> glog2, gl = threadIdx.x & (G - 1);
+    const int node = blockIdx.x * groups + grp;
+    if (node >= N)
+        return;
+    const int4 r0 = node_rec[2 * (size_t)node];
+    const int rp0 = r0.x, deg = r0.y;
+    const int nvec = w / VEC;
+    for (int f = gl; f < nvec; f += G) {
+        const int fo = f * VEC;
+        V acc = V::splat(0.0f);
+        for (int k = rp0; k < rp0 + deg; k++) {
+            const V xj = V::load(x + (size_t)col[k] * w + fo);
+            const V pe = V::load(eterm + (size_t)eid[k] * w + fo);
+            acc = vadd(acc, vmax(vadd(xj, pe), V::splat(0.0f))); // merge_sum_1d, activation_relu, sum_incremental
+        }
+        const V xi = V::load(x + (size_t)node * w + fo);
+        vadd(acc, vmul(xi, V::splat(1.0f + eps))).store(out + (size_t)node * w + fo);
+    }
+}
+
+hipError_t launch_aggregate_edges(const BatchTables &t, const float *x, const float *eterm, float *out, int width,
+                                  float eps, hipStream_t s)
+{
+    if (t.num_nodes <= 0)
+        return hipSuccess;
+    const bool v4 = (width % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0) &&
+                    (((uintptr_t)eterm & 15) == 0);
+    const int nvec = v4 ? width / 4 : width;
+    int glog2 = 0;
+    while ((1 << glog2) < nvec && glog2 < 6)
+        glog2++;
+    const int groups = WG >> glog2;
+    const int grid = (t.num_nodes + groups - 1) / groups;
+    if (v4)
+        hipLaunchKernelGGL(k_aggregate_edges<4>, dim3(grid), dim3(WG), 0, s, x, eterm, out, t.node_rec, t.col, t.eid,
+                           t.num_nodes, width, glog2, eps);
+    else
+        hipLaunchKernelGGL(k_aggregate_edges<1>, dim3(grid), dim3(WG), 0, s, x, eterm, out, t.node_rec, t.col, t.eid,
+                           t.num_nodes, width, glog2, eps);
+    return hipGetLastError();
 }
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
@@ -3220,7 +3278,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_graph,
-    const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, const float *__restrict__ W0,
+    const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, int N, const float *__restrict__ W0,
     const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ b1,
     int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled)
 {
@@ -3256,9 +3314,10 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
     if (t1 <= t0)
         return;
+    // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
     for (int i = tid; i <= t1 - t0; i += G2_WG) {
-        stile[i] = tile_first[t0 + i];
-        sgraph[i] = tile_graph[t0 + i];
+        stile[i] = min(max(tile_first[t0 + i], 0), N);
+        sgraph[i] = min(max(tile_graph[t0 + i], 0), num_graphs);
     }
     __syncthreads();
 
@@ -3277,11 +3336,11 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         while (tb < t1 && stile[tb + 1 - t0] - st.nb <= G2_CAP)
             tb++;
         st.tb = tb;
-        st.rows = min(stile[tb - t0] - st.nb, G2_CAP); // (> CAP only if the max_graph_nodes promise is broken)
+        st.rows = max(min(stile[tb - t0] - st.nb, G2_CAP), 0); // (> CAP only if the max_graph_nodes promise is broken)
         st.ga = sgraph[ta - t0];
         // (empty graphs after the last node belong to the last stage: when N is a multiple of the tile
         // size the first of them already owns tile_graph[num_tiles])
-        st.gb = tb == num_tiles ? num_graphs : sgraph[tb - t0];
+        st.gb = max(tb == num_tiles ? num_graphs : sgraph[tb - t0], st.ga);
         return st;
     };
     auto issue = [&](const G2Stage &st, int bb, int lane, int wave) { // (lane, wave: see `tv` below)
@@ -3735,7 +3794,7 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
             return;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_WG), lds, s, x, f0, t.node_rec, t.col, t.dinv,
-                           t.tile_first, t.tile_graph, t.graph_ptr, t.num_tiles, t.num_graphs, w0, b0, h0, w1, b1, h1, p0, p1, p2,
+                           t.tile_first, t.tile_graph, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, w0, b0, h0, w1, b1, h1, p0, p1, p2,
                            num_pools, pooled);
         rc = hipGetLastError();
     };
@@ -3755,6 +3814,32 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     };
     GNNB_DISPATCH_ACT(act, go_q)
     return rc;
+}
+
+// GNNModel.output_activation (models.py:500-502, 572-573): softmax / log_softmax over each graph's output row.
+// OUT is a handful of values (1..19 at the BASELINE configs): one lane per graph, three passes over the row.
+__global__ __launch_bounds__(WG) void k_output_activation(float *__restrict__ out, int B, int n, int kind)
+{
+    const int g = blockIdx.x * WG + threadIdx.x;
+    if (g >= B)
+        return;
+    float *o = out + (size_t)g * n;
+    float mx = o[0];
+    for (int i = 1; i < n; i++)
+        mx = fmaxf(mx, o[i]);
+    float sum = 0.0f;
+    for (int i = 0; i < n; i++)
+        sum += expf(o[i] - mx);
+    for (int i = 0; i < n; i++)
+        o[i] = kind == GNNB_OUT_SOFTMAX ? expf(o[i] - mx) / sum : (o[i] - mx) - logf(sum);
+}
+
+hipError_t launch_output_activation(float *out, int num_graphs, int n, int kind, hipStream_t s)
+{
+    if (num_graphs <= 0 || kind == GNNB_OUT_NONE)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_output_activation, dim3((num_graphs + WG - 1) / WG), dim3(WG), 0, s, out, num_graphs, n, kind);
+    return hipGetLastError();
 }
 
 #ifdef GNNB_PROBE

@@ -128,6 +128,8 @@ static int validate_desc(const gnnb_model_desc *d)
         return fail(GNNB_ERR_INVALID, "bad MLP head shape");
     if (d->conv_type == GNNB_CONV_PNA && !(d->pna_delta > 0.0f))
         return fail(GNNB_ERR_INVALID, "pna_delta must be > 0");
+    if (d->output_activation < GNNB_OUT_NONE || d->output_activation > GNNB_OUT_LOG_SOFTMAX)
+        return fail(GNNB_ERR_INVALID, "unsupported output_activation %d", d->output_activation);
     return GNNB_OK;
 }
 
@@ -159,6 +161,8 @@ struct gnnb_workspace {
     bool prepared = false;
     int max_graph_nodes = 0; // caller's promise (0 = none)
     int device = 0;
+    char *stage = nullptr;   // device staging of the host-buffer entry (x | coo | node_ptr | edge_ptr | out), sized for
+    size_t stage_bytes = 0;  // the workspace's capacities; allocated by the first gnnb_forward_batched_host call
 };
 
 // ---------------------------------------------------------------------------------------
@@ -386,7 +390,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
         return o;
     };
     const size_t N = max_nodes, E = std::max(max_edges, 1), B = max_graphs;
-    const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
+    const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_eid = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
                  o_att = carve(N * 4), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_gptr = carve((B + 1) * 4),
                  o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4),
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
@@ -403,6 +407,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     char *b = ws->blob;
     ws->t.row_ptr = (int32_t *)(b + o_rp);
     ws->t.col = (int32_t *)(b + o_col);
+    ws->t.eid = (int32_t *)(b + o_eid);
     ws->t.node_rec = (int4 *)(b + o_rec);
     ws->t.dinv = (float *)(b + o_dinv);
     ws->t.amp = (float *)(b + o_amp);
@@ -431,6 +436,8 @@ void gnnb_workspace_destroy(gnnb_workspace *ws)
         return;
     if (ws->blob)
         (void)hipFree(ws->blob);
+    if (ws->stage)
+        (void)hipFree(ws->stage);
     delete ws;
 }
 
@@ -522,6 +529,28 @@ int gnnb_graph_tables_to_host(gnnb_workspace *ws, int32_t *row_ptr, int32_t *col
     return GNNB_OK;
 }
 
+int gnnb_edge_index_table_to_host(gnnb_workspace *ws, int32_t *edge_index_table, void *stream)
+{
+    if (!ws || !ws->prepared || !edge_index_table)
+        return fail(GNNB_ERR_INVALID, "gnnb_edge_index_table_to_host needs a prepared batch and an output array");
+    if (ws->t.num_edges > 0)
+        GNNB_HIP_TRY(hipMemcpyAsync(edge_index_table, ws->t.eid, (size_t)ws->t.num_edges * 4, hipMemcpyDeviceToHost,
+                                    (hipStream_t)stream));
+    GNNB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GNNB_OK;
+}
+
+int gnnb_aggregate_edges(gnnb_workspace *ws, const float *x_dev, const float *edge_term_dev, float *out_dev,
+                         int width, float eps, void *stream)
+{
+    if (!ws || !ws->prepared)
+        return fail(GNNB_ERR_INVALID, "gnnb_aggregate_edges needs a prepared batch (gnnb_graph_prep)");
+    if (!x_dev || !out_dev || width < 1 || (ws->t.num_edges > 0 && !edge_term_dev))
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_aggregate_edges");
+    GNNB_HIP_TRY(launch_aggregate_edges(ws->t, x_dev, edge_term_dev, out_dev, width, eps, (hipStream_t)stream));
+    return GNNB_OK;
+}
+
 int gnnb_aggregate(gnnb_workspace *ws, int agg_kind, const float *x_dev, const float *self_dev,
                    float *out_dev, int width, float eps, void *stream)
 {
@@ -609,8 +638,24 @@ static int linear1(const float *a, int lda, int k, const float *w, int ldw, cons
     return gnnb_linear(&seg, 1, w, ldw, bias, skip, y, M, N, act, stream);
 }
 
+static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, float *out_dev,
+                                 void *stream);
+
 int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev,
                           float *out_dev, void *stream)
+{
+    int rc = forward_prepared_body(model, ws, x_dev, out_dev, stream);
+    if (rc != GNNB_OK)
+        return rc;
+    // output_activation(dim=-1) over every graph's output row (models.py:572-573)
+    if (model->desc.output_activation != GNNB_OUT_NONE)
+        GNNB_HIP_TRY(launch_output_activation(out_dev, ws->t.num_graphs, model->desc.mlp_out, model->desc.output_activation,
+                                              (hipStream_t)stream));
+    return GNNB_OK;
+}
+
+static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, float *out_dev,
+                                 void *stream)
 {
     if (!model || !ws || !x_dev || !out_dev)
         return fail(GNNB_ERR_INVALID, "null argument to gnnb_forward");
@@ -830,41 +875,36 @@ int gnnb_forward_batched_host(const gnnb_model *model, gnnb_workspace *ws, const
                     "batch (%d graphs, %d nodes, %d edges) exceeds workspace (%d, %d, %d)",
                     num_graphs, num_nodes, num_edges, ws->max_graphs, ws->max_nodes, ws->max_edges);
     const gnnb_model_desc &d = model->desc;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // staging buffers live in the workspace, sized once for its capacities: the reference's <name>_top is called once
+    // per graph (model_tb.cpp.jinja:189-205), and a hipMalloc / hipFree pair per call would dominate it
+    const size_t cx = up((size_t)ws->max_nodes * d.in_dim * 4), cc = up((size_t)std::max(ws->max_edges, 1) * 8),
+                 cp = up(((size_t)ws->max_graphs + 1) * 4), co = up((size_t)ws->max_graphs * d.mlp_out * 4);
+    if (!ws->stage) {
+        GNNB_HIP_TRY(hipMalloc((void **)&ws->stage, cx + cc + 2 * cp + co));
+        ws->stage_bytes = cx + cc + 2 * cp + co;
+    }
+    float *dx = (float *)ws->stage;
+    int32_t *dc = (int32_t *)(ws->stage + cx);
+    int32_t *dn = (int32_t *)(ws->stage + cx + cc);
+    int32_t *de = (int32_t *)(ws->stage + cx + cc + cp);
+    float *dout = (float *)(ws->stage + cx + cc + 2 * cp);
     const size_t bx = (size_t)num_nodes * d.in_dim * 4, bc = (size_t)num_edges * 8,
                  bp = ((size_t)num_graphs + 1) * 4, bo = (size_t)num_graphs * d.mlp_out * 4;
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    char *dev = nullptr;
-    GNNB_HIP_TRY(hipMalloc((void **)&dev, up(bx) + up(bc) + 2 * up(bp) + up(bo) + 256));
-    float *dx = (float *)dev;
-    int32_t *dc = (int32_t *)(dev + up(bx));
-    int32_t *dn = (int32_t *)((char *)dc + up(bc));
-    int32_t *de = (int32_t *)((char *)dn + up(bp));
-    float *dout = (float *)((char *)de + up(bp));
-    int rc = GNNB_OK;
-    hipError_t e = hipSuccess;
+    hipStream_t s0 = nullptr;
     if (bx)
-        e = hipMemcpy(dx, x, bx, hipMemcpyHostToDevice);
-    if (e == hipSuccess && bc)
-        e = hipMemcpy(dc, coo, bc, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(dn, node_ptr, bp, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(de, edge_ptr, bp, hipMemcpyHostToDevice);
-    if (e != hipSuccess)
-        rc = fail(GNNB_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e));
+        GNNB_HIP_TRY(hipMemcpyAsync(dx, x, bx, hipMemcpyHostToDevice, s0));
+    if (bc)
+        GNNB_HIP_TRY(hipMemcpyAsync(dc, coo, bc, hipMemcpyHostToDevice, s0));
+    GNNB_HIP_TRY(hipMemcpyAsync(dn, node_ptr, bp, hipMemcpyHostToDevice, s0));
+    GNNB_HIP_TRY(hipMemcpyAsync(de, edge_ptr, bp, hipMemcpyHostToDevice, s0));
+    int rc = gnnb_forward_batched(model, ws, dx, dc, dn, de, num_graphs, num_nodes, num_edges, dout, nullptr);
+    if (rc == GNNB_OK && bo)
+        GNNB_HIP_TRY(hipMemcpyAsync(out, dout, bo, hipMemcpyDeviceToHost, s0));
     if (rc == GNNB_OK)
-        rc = gnnb_forward_batched(model, ws, dx, dc, dn, de, num_graphs, num_nodes, num_edges, dout, nullptr);
-    if (rc == GNNB_OK)
-        rc = gnnb_workspace_check(ws, nullptr);
-    if (rc == GNNB_OK && bo) {
-        e = hipMemcpy(out, dout, bo, hipMemcpyDeviceToHost);
-        if (e != hipSuccess)
-            rc = fail(GNNB_ERR_HIP, "D2H copy failed: %s", hipGetErrorString(e));
-    }
-    (void)hipDeviceSynchronize();
-    ws->t.node_ptr = nullptr; // the temporary ptr array dies with this call
-    ws->prepared = false;
-    (void)hipFree(dev);
+        rc = gnnb_workspace_check(ws, nullptr); // one synchronisation: the validation word and `out` are both back
+    else
+        (void)hipStreamSynchronize(s0);
     return rc;
 }
 

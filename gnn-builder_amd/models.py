@@ -234,6 +234,47 @@ class PNAConv_GNNB(nn.Module):
         return self.conv(x, edge_index)
 
 
+# --------------------------------------------------------------------------------------- GINE
+class _GINEConv(nn.Module):
+    """``nn((1+eps) x_i + sum_j relu(x_j + lin(e_ij)))`` (PyG GINEConv with edge_dim; reference models.py:97-123,
+    native gine_conv gnn_builder_lib.h:1555-1742).  Parameters: ``nn.*``, ``lin.weight`` [in, edge_dim], ``lin.bias``."""
+
+    def __init__(self, mlp: nn.Module, in_channels: int, edge_dim: int, eps: float = 0.0):
+        super().__init__()
+        self.nn = mlp
+        self.lin = nn.Linear(edge_dim, in_channels)
+        self.register_buffer("eps", torch.tensor([float(eps)]))
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
+        src, dst = edge_index[0], edge_index[1]
+        agg = torch.zeros_like(x)
+        if src.numel():
+            agg = agg.index_add(0, dst, torch.relu(x[src] + self.lin(edge_attr)))
+        return self.nn(agg + (1.0 + self.eps) * x)
+
+
+class GINEConv_GNNB(nn.Module):
+    """Reference models.py:97-123.  Not in SUPPORTED_GNN_CONVS there (the emitter has a TODO for it,
+    templates/model.cpp.jinja:143-144), so ``GNNModel`` does not stack it; the native layer is reachable through
+    ``runtime.CompiledModel.gine_conv`` (C ABI ``gnnb_aggregate_edges`` + ``gnnb_linear``)."""
+
+    def __init__(self, in_channels: int, out_channels: int, edge_dim: int, hidden_dim: Optional[int] = None,
+                 eps: float = 0.0, p_in: int = 1, p_out: int = 1):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.edge_dim = edge_dim
+        self.hidden_dim = hidden_dim
+        self.eps = eps
+        self.p_in = p_in
+        self.p_out = p_out
+        self.mlp = GIN_MLP(in_channels, out_channels, hidden_dim)
+        self.conv = _GINEConv(self.mlp, in_channels, edge_dim, eps=eps)
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
+        return self.conv(x, edge_index, edge_attr)
+
+
 class GATConv_GNNB(nn.Module):
     """Listed by the reference's SUPPORTED_GNN_CONVS but it has no native kernel for it
     (gnn_builder_lib.h:2343 ``// TODO: GAT layer``; template TODO model.cpp.jinja:141-142);
@@ -487,9 +528,13 @@ class GNNModel(nn.Module):
         (include/gnnb_hip.h)."""
         if self.gnn_conv not in _CONV_NAME:
             raise NotImplementedError(f"{self.gnn_conv.__name__} has no native path")
+        out_act = None
         if self.output_activation is not None:
-            raise NotImplementedError("output_activation is not supported by the native path "
-                                      "(every in-repo use of the reference passes None)")
+            # the reference builds output_activation(dim=-1) (models.py:500-502): a softmax-like module
+            out_act = {nn.Softmax: "softmax", nn.LogSoftmax: "log_softmax"}.get(self.output_activation)
+            if out_act is None:
+                raise NotImplementedError(f"output_activation {self.output_activation} has no native path "
+                                          "(nn.Softmax and nn.LogSoftmax do)")
         conv0 = self.gnn_convs[0] if len(self.gnn_convs) else None
         return {
             "conv": _CONV_NAME[self.gnn_conv],
@@ -506,6 +551,7 @@ class GNNModel(nn.Module):
             "mlp_activation": _ACT_NAME[self.mlp_head.activation],
             "gin_eps": float(conv0.eps) if isinstance(conv0, GINConv_GNNB) else 0.0,
             "pna_delta": float(conv0.delta_scaler) if isinstance(conv0, PNAConv_GNNB) else 1.0,
+            "output_activation": out_act,
         }
 
     def canonical_param_names(self) -> List[str]:

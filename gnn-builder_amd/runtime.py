@@ -24,6 +24,7 @@ CSRC_DIR = PKG_DIR / "csrc"
 CONV = {"gcn": 0, "gin": 1, "sage": 2, "pna": 3}
 ACT = {"relu": 0, "gelu": 1, "sigmoid": 2, "tanh": 3, "none": 4}
 POOL = {"add": 0, "mean": 1, "max": 2}
+OUT_ACT = {None: 0, "none": 0, "softmax": 1, "log_softmax": 2}
 AGG = {"gcn": 0, "sum": 1, "mean": 2, "pna": 3, "lg": 4, "simple": 5, "copy": 6}
 
 GNNB_OK = 0
@@ -55,6 +56,7 @@ class ModelDesc(C.Structure):
         ("mlp_activation", C.c_int32),
         ("gin_eps", C.c_float),
         ("pna_delta", C.c_float),
+        ("output_activation", C.c_int32),
     ]
 
 
@@ -72,6 +74,7 @@ EXPORTED_SYMBOLS = [
     "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
     "gnnb_malloc", "gnnb_free", "gnnb_memcpy_h2d", "gnnb_memcpy_d2h", "gnnb_set_option",
     "gnnb_aggregate_timed", "gnnb_linear_timed", "gnnb_gcn_stack_timed",
+    "gnnb_aggregate_edges", "gnnb_edge_index_table_to_host",
 ]
 
 
@@ -134,6 +137,8 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
         lib.gnnb_linear_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.POINTER(C.c_float)]
+        lib.gnnb_aggregate_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        lib.gnnb_edge_index_table_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.gnnb_gcn_stack_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                              C.POINTER(C.c_float)]
         _lib = lib
@@ -171,6 +176,7 @@ def make_desc(spec: dict) -> ModelDesc:
     d.mlp_activation = ACT[spec["mlp_activation"]]
     d.gin_eps = spec.get("gin_eps", 0.0)
     d.pna_delta = spec.get("pna_delta", 1.0)
+    d.output_activation = OUT_ACT[spec.get("output_activation")]
     return d
 
 
@@ -182,6 +188,21 @@ def _stream_ptr(stream=None) -> int:
 
 def _dptr(t) -> int:
     return int(t.data_ptr())
+
+
+def _require(t, name: str, dtype, ndim: int, last: Optional[int] = None):
+    """A raw pointer crosses the C ABI: a tensor of another dtype / layout / device would be silently reinterpreted
+    (a PyG edge_index, int64 [2, E], read as int32 [E, 2] is garbage edges) -- refuse it here."""
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GnnbError(f"{name} must be a CUDA (HIP) tensor")
+    if t.dtype != dtype:
+        raise GnnbError(f"{name} must be {dtype}, got {t.dtype}")
+    if t.dim() != ndim or (last is not None and t.shape[-1] != last):
+        raise GnnbError(f"{name} has shape {tuple(t.shape)}; expected {ndim} dimensions" +
+                        (f" with last dimension {last}" if last is not None else ""))
+    if not t.is_contiguous():
+        raise GnnbError(f"{name} must be contiguous")
 
 
 class CompiledModel:
@@ -249,18 +270,34 @@ class CompiledModel:
 
     # ------------------------------------------------------------------ whole forward
     def forward(self, x, coo, node_ptr, edge_ptr, out=None, stream=None):
-        """All arguments are torch CUDA tensors (fp32 / int32, contiguous); returns ``out``
-        [B, mlp_out].  Asynchronous on the current torch stream."""
+        """All arguments are torch CUDA tensors (fp32 / int32, contiguous; ``coo`` is [E, 2] (src, dst) rows, NOT a PyG
+        ``edge_index`` [2, E] -- transpose it); returns ``out`` [B, mlp_out].  Asynchronous on the current torch stream.
+        With a ``max_graph_nodes`` promise set, call ``check()`` on the batch: a broken promise is flagged there, and
+        the results of a flagged batch are unspecified."""
         import torch
+        self._check_batch(x, coo, node_ptr, edge_ptr)
         B = int(node_ptr.numel()) - 1
         N, E = int(x.shape[0]), int(coo.shape[0])
         if out is None:
             out = torch.empty((B, self.out_dim), dtype=torch.float32, device=x.device)
+        else:
+            _require(out, "out", torch.float32, 2, self.out_dim)
         _check(self.lib.gnnb_forward_batched(self._model, self._ws, _dptr(x), _dptr(coo), _dptr(node_ptr),
                                              _dptr(edge_ptr), B, N, E, _dptr(out), _stream_ptr(stream)))
         return out
 
+    def _check_batch(self, x, coo, node_ptr, edge_ptr) -> None:
+        import torch
+        if x is not None:
+            _require(x, "x", torch.float32, 2, int(self.desc.in_dim))
+        _require(coo, "coo", torch.int32, 2, 2)
+        _require(node_ptr, "node_ptr", torch.int32, 1)
+        _require(edge_ptr, "edge_ptr", torch.int32, 1)
+        if node_ptr.numel() != edge_ptr.numel() or node_ptr.numel() < 1:
+            raise GnnbError("node_ptr and edge_ptr must both have num_graphs + 1 entries")
+
     def graph_prep(self, coo, node_ptr, edge_ptr, num_nodes: int, stream=None) -> None:
+        self._check_batch(None, coo, node_ptr, edge_ptr)
         B = int(node_ptr.numel()) - 1
         self._keep = (coo, node_ptr, edge_ptr)
         _check(self.lib.gnnb_graph_prep(self._ws, _dptr(coo), _dptr(node_ptr), _dptr(edge_ptr), B,
@@ -270,6 +307,7 @@ class CompiledModel:
 
     def forward_prepared(self, x, out=None, stream=None):
         import torch
+        _require(x, "x", torch.float32, 2, int(self.desc.in_dim))
         if out is None:
             out = torch.empty((self._B, self.out_dim), dtype=torch.float32, device=x.device)
         _check(self.lib.gnnb_forward_prepared(self._model, self._ws, _dptr(x), _dptr(out), _stream_ptr(stream)))
@@ -304,6 +342,7 @@ class CompiledModel:
 
     def aggregate(self, kind: str, x, self_term=None, eps: float = 0.0, out=None, stream=None):
         import torch
+        _require(x, "x", torch.float32, 2)
         w = int(x.shape[1])
         if out is None:
             out = torch.empty((x.shape[0], 4 * w if kind == "pna" else w), dtype=torch.float32, device=x.device)
@@ -311,6 +350,29 @@ class CompiledModel:
                                        _dptr(self_term) if self_term is not None else None, _dptr(out), w,
                                        float(eps), _stream_ptr(stream)))
         return out
+
+    def edge_index_table_to_host(self, stream=None) -> np.ndarray:
+        """The reference's edge_index_table of the prepared batch: COO row of every CSR slot."""
+        eid = np.zeros(max(self._E, 1), np.int32)
+        _check(self.lib.gnnb_edge_index_table_to_host(self._ws, eid.ctypes.data_as(C.c_void_p), _stream_ptr(stream)))
+        return eid[:self._E]
+
+    def aggregate_edges(self, x, edge_term, eps: float = 0.0, out=None, stream=None):
+        """GINE aggregate: ``(1 + eps) x_i + sum_j relu(x_j + edge_term[e])``; ``edge_term`` [E, width] in COO order."""
+        import torch
+        if out is None:
+            out = torch.empty_like(x)
+        _check(self.lib.gnnb_aggregate_edges(self._ws, _dptr(x), _dptr(edge_term), _dptr(out), int(x.shape[1]),
+                                             float(eps), _stream_ptr(stream)))
+        return out
+
+    def gine_conv(self, x, edge_attr, w_edge, b_edge, w0, b0, w1, b1, eps: float = 0.0, stream=None):
+        """One GINEConv layer on the prepared batch (reference gine_conv, gnn_builder_lib.h:1640-1742):
+        edge projection (GEMM) -> GINE aggregate -> Linear -> ReLU -> Linear."""
+        pe = linear([(edge_attr, None)], w_edge, b_edge, stream=stream)
+        z = self.aggregate_edges(x, pe, eps=eps, stream=stream)
+        h = linear([(z, None)], w0, b0, act="relu", stream=stream)
+        return linear([(h, None)], w1, b1, stream=stream)
 
     def aggregate_timed(self, kind: str, xs, outs, iters: int, self_term=None, eps: float = 0.0, stream=None) -> float:
         """Mean microseconds per launch over ``iters`` back-to-back launches issued from C,

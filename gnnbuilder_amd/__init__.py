@@ -19,6 +19,7 @@ from .models import (
     GCNConv_GNNB,
     GIN_MLP,
     GINConv_GNNB,
+    GINEConv_GNNB,
     GlobalPooling,
     GNNModel,
     PNAConv_GNNB,
@@ -36,7 +37,7 @@ from .batching import GraphBatch, from_pyg_batch, pack_graphs, shard_batch, shar
 
 __all__ = [
     "Project", "FPX",
-    "MLP", "GATConv_GNNB", "GCNConv_GNNB", "GIN_MLP", "GINConv_GNNB", "GlobalPooling", "GNNModel",
+    "MLP", "GATConv_GNNB", "GCNConv_GNNB", "GIN_MLP", "GINConv_GNNB", "GINEConv_GNNB", "GlobalPooling", "GNNModel",
     "PNAConv_GNNB", "SAGEConv_GNNB",
     "compute_average_degree", "compute_average_nodes_and_edges", "compute_max_nodes_and_edges",
     "compute_median_degree", "compute_median_nodes_and_edges",

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNB_VERSION 100
+#define GNNB_VERSION 101
 
 typedef enum gnnb_status {
     GNNB_OK = 0,
@@ -53,6 +53,10 @@ typedef enum gnnb_act { GNNB_ACT_RELU = 0, GNNB_ACT_GELU = 1, GNNB_ACT_SIGMOID =
 /* gnnbuilder/models.py:317-321 (SUPPORTED_GLOBAL_POOLING_AGGRS) */
 typedef enum gnnb_pool { GNNB_POOL_ADD = 0, GNNB_POOL_MEAN = 1, GNNB_POOL_MAX = 2 } gnnb_pool;
 
+/* GNNModel.output_activation (gnnbuilder/models.py:500-502, 572-573): a module built with dim=-1, i.e. a softmax-like
+ * map over the model's output vector */
+typedef enum gnnb_out_act { GNNB_OUT_NONE = 0, GNNB_OUT_SOFTMAX = 1, GNNB_OUT_LOG_SOFTMAX = 2 } gnnb_out_act;
+
 /* What GNNModel.__init__ fixes (gnnbuilder/models.py:463-549). */
 typedef struct gnnb_model_desc {
     int32_t conv_type;      /* gnnb_conv */
@@ -70,6 +74,7 @@ typedef struct gnnb_model_desc {
     int32_t mlp_activation; /* MLP.activation (gnnb_act), between head linears only */
     float gin_eps;          /* GINConv_GNNB.eps (models.py:76) */
     float pna_delta;        /* PNAConv_GNNB.delta used verbatim as avg_deg_log (models.py:236) */
+    int32_t output_activation; /* gnnb_out_act, applied to every graph's output row */
 } gnnb_model_desc;
 
 #define GNNB_MAX_LAYERS 16
@@ -169,6 +174,16 @@ typedef enum gnnb_agg {
  * (NULL otherwise).  eps: GIN's epsilon (SUM only). */
 int gnnb_aggregate(gnnb_workspace *ws, int agg_kind, const float *x_dev, const float *self_dev,
                    float *out_dev, int width, float eps, void *stream);
+
+/* GINE aggregate (gine_conv_agg + the self term of gine_conv, gnn_builder_lib.h:1555-1742):
+ *   out_i = (1 + eps) x_i + sum_{j->i} relu(x_j + edge_term[e]),  e = the COO row of the edge j->i.
+ * edge_term_dev [E, width] holds the projected edge features W_e e + b_e in COO (input) order -- produce it with
+ * gnnb_linear over the [E, edge_dim] edge-feature matrix.  The CSR slot -> COO row map is the reference's
+ * edge_index_table (compute_neighbor_and_edge_index_tables, gnn_builder_lib.h:1126-1166), written by graph prep. */
+int gnnb_aggregate_edges(gnnb_workspace *ws, const float *x_dev, const float *edge_term_dev, float *out_dev,
+                         int width, float eps, void *stream);
+/* copy that table of the last prep to the host ([E] int32, batch-global COO rows); synchronises */
+int gnnb_edge_index_table_to_host(gnnb_workspace *ws, int32_t *edge_index_table /*[E]*/, void *stream);
 
 /* Dense update on the matrix cores: for up to 4 K-segments s,
  *   Y[M,N] = act( sum_s (rowscale_s[m] * A_s[M,K_s]) . W[:, koff_s : koff_s+K_s]^T + bias + skip )

@@ -298,6 +298,63 @@ void gnnb_oracle_pna_conv(int n, const float *x, float *out, const int32_t *offs
     free(hid);
 }
 
+/* gnn_builder_lib.h:1126-1166 (compute_neighbor_and_edge_index_tables): the neighbour table plus, per CSR slot,
+ * the COO row of its edge. */
+void gnnb_oracle_neighbor_edge_tables(const int32_t *coo, const int32_t *in_deg, int n, int e, int32_t *offsets,
+                                      int32_t *neighbors, int32_t *edge_index)
+{
+    int32_t *cursor = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    if (n > 0) {
+        offsets[0] = 0;
+        cursor[0] = 0;
+    }
+    for (int i = 1; i < n; i++) {
+        offsets[i] = offsets[i - 1] + in_deg[i - 1];
+        cursor[i] = offsets[i];
+    }
+    for (int i = 0; i < e; i++) {
+        int src = coo[2 * i], dst = coo[2 * i + 1];
+        neighbors[cursor[dst]] = src;
+        edge_index[cursor[dst]] = i;
+        cursor[dst]++;
+    }
+    free(cursor);
+}
+
+/* gnn_builder_lib.h:1555-1625 (gine_conv_agg) + :1640-1742 (gine_conv):
+ * z = sum_j relu(x_j + (We e_ij + be)) + x_i (1+eps); out = W1 relu(W0 z + b0) + b1. */
+void gnnb_oracle_gine_conv(int n, const float *x, const float *edge_attr, float *out, const int32_t *offsets,
+                           const int32_t *neighbors, const int32_t *edge_index, const int32_t *in_deg,
+                           const float *We, const float *be, const float *W0, const float *b0, const float *W1,
+                           const float *b1, float eps, int fin, int edge_dim, int hidden, int fout)
+{
+    float *z = (float *)malloc(sizeof(float) * (size_t)(fin > 0 ? fin : 1));
+    float *pe = (float *)malloc(sizeof(float) * (size_t)(fin > 0 ? fin : 1));
+    float *h = (float *)malloc(sizeof(float) * (size_t)(hidden > 0 ? hidden : 1));
+    for (int node = 0; node < n; node++) {
+        for (int i = 0; i < fin; i++)
+            z[i] = 0.0f;
+        for (int k = 0; k < in_deg[node]; k++) {
+            int j = neighbors[offsets[node] + k];
+            int e = edge_index[offsets[node] + k];
+            gnnb_oracle_linear(edge_attr + (size_t)e * edge_dim, pe, We, be, edge_dim, fin);
+            for (int i = 0; i < fin; i++) {
+                float m = x[(size_t)j * fin + i] + pe[i];
+                z[i] += m > 0.0f ? m : 0.0f;
+            }
+        }
+        for (int i = 0; i < fin; i++)
+            z[i] = z[i] + x[(size_t)node * fin + i] * (1.0f + eps);
+        gnnb_oracle_linear(z, h, W0, b0, fin, hidden);
+        for (int i = 0; i < hidden; i++)
+            h[i] = h[i] > 0.0f ? h[i] : 0.0f;
+        gnnb_oracle_linear(h, out + (size_t)node * fout, W1, b1, hidden, fout);
+    }
+    free(z);
+    free(pe);
+    free(h);
+}
+
 /* gnn_builder_lib.h:2501-2634 (simple_conv, aggregation "sum") */
 void gnnb_oracle_simple_conv(int n, const float *x, float *out, const int32_t *offsets,
                              const int32_t *neighbors, const int32_t *in_deg, int f)
@@ -500,6 +557,15 @@ int gnnb_oracle_forward(const gnnb_oracle_desc *d, const float *const *params, c
         din = dout;
     }
     memcpy(out, a, sizeof(float) * (size_t)d->mlp_out);
+    if (d->output_activation == 1 || d->output_activation == 2) { /* models.py:572-573: module(dim=-1) */
+        float mx = out[0], sum = 0.0f;
+        for (int i = 1; i < d->mlp_out; i++)
+            mx = out[i] > mx ? out[i] : mx;
+        for (int i = 0; i < d->mlp_out; i++)
+            sum += expf(out[i] - mx);
+        for (int i = 0; i < d->mlp_out; i++)
+            out[i] = d->output_activation == 1 ? expf(out[i] - mx) / sum : (out[i] - mx) - logf(sum);
+    }
 
     free(a);
     free(b);

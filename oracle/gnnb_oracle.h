@@ -60,6 +60,7 @@ typedef struct gnnb_oracle_desc {
     float pna_delta;
     int32_t pna_std_mode;
     int32_t gcn_self_loop_mode;
+    int32_t output_activation; /* 0 none, 1 softmax, 2 log_softmax over the output vector (models.py:500-502, 572-573) */
 } gnnb_oracle_desc;
 
 /* graph prep: gnn_builder_lib.h:1051-1083, :1086-1124 */
@@ -87,6 +88,13 @@ void gnnb_oracle_pna_conv(int n, const float *x, float *out, const int32_t *offs
                           const float *bpre, const float *Wpost, const float *bpost,
                           const float *Wlin, const float *blin, float delta, int std_mode, int fin,
                           int fout);
+/* GINE (gnn_builder_lib.h:1126-1166 edge-index table, :1555-1742 conv) */
+void gnnb_oracle_neighbor_edge_tables(const int32_t *coo, const int32_t *in_deg, int n, int e, int32_t *offsets,
+                                      int32_t *neighbors, int32_t *edge_index);
+void gnnb_oracle_gine_conv(int n, const float *x, const float *edge_attr, float *out, const int32_t *offsets,
+                           const int32_t *neighbors, const int32_t *edge_index, const int32_t *in_deg,
+                           const float *We, const float *be, const float *W0, const float *b0, const float *W1,
+                           const float *b1, float eps, int fin, int edge_dim, int hidden, int fout);
 /* weight-free convs with committed goldens (gnn_builder_lib.h:2350-2634) */
 void gnnb_oracle_simple_conv(int n, const float *x, float *out, const int32_t *offsets,
                              const int32_t *neighbors, const int32_t *in_deg, int f);

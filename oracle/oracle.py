@@ -44,6 +44,7 @@ class Desc(C.Structure):
         ("pna_delta", C.c_float),
         ("pna_std_mode", C.c_int32),
         ("gcn_self_loop_mode", C.c_int32),
+        ("output_activation", C.c_int32),
     ]
 
 
@@ -193,6 +194,37 @@ def conv(kind: str, x, coo, weights, *, eps: float = 0.0, delta: float = 1.0, st
     return out
 
 
+def edge_tables(coo, n: int):
+    """in_deg, offsets, neighbors, edge_index_table of ONE graph (gnn_builder_lib.h:1126-1166)."""
+    coo = _i32(coo).reshape(-1, 2)
+    e = coo.shape[0]
+    in_deg, out_deg, _, _ = tables(coo, n)
+    in_deg = _i32(in_deg)
+    offsets = np.zeros(max(n, 1), np.int32)
+    nbrs = np.zeros(max(e, 1), np.int32)
+    eidx = np.zeros(max(e, 1), np.int32)
+    lib().gnnb_oracle_neighbor_edge_tables(_p(coo), _p(in_deg), n, e, _p(offsets), _p(nbrs), _p(eidx))
+    return in_deg[:n], offsets[:n], nbrs[:e], eidx[:e]
+
+
+def gine_conv(x, coo, edge_attr, weights, eps: float = 0.0):
+    """One GINE layer on ONE graph; ``weights`` = [We, be, W0, b0, W1, b1]."""
+    x = _f32(x)
+    n, fin = x.shape
+    coo = _i32(coo).reshape(-1, 2)
+    ea = _f32(edge_attr)
+    if ea.ndim != 2:
+        ea = ea.reshape(coo.shape[0], -1)
+    in_deg, offsets, nbrs, eidx = edge_tables(coo, n)
+    w = [_f32(t) for t in weights]
+    hidden, fout = w[2].shape[0], w[4].shape[0]
+    out = np.zeros((n, fout), np.float32)
+    in_deg, offsets, nbrs, eidx = _i32(in_deg), _i32(offsets), _i32(nbrs), _i32(eidx)
+    lib().gnnb_oracle_gine_conv(n, _p(x), _p(ea), _p(out), _p(offsets), _p(nbrs), _p(eidx), _p(in_deg), _p(w[0]), _p(w[1]),
+                                _p(w[2]), _p(w[3]), _p(w[4]), _p(w[5]), C.c_float(eps), fin, ea.shape[1], hidden, fout)
+    return out
+
+
 def linear(x, W, b, use_ref: bool = False):
     x, W = _f32(x), _f32(W)
     b = _f32(b) if b is not None else np.zeros(W.shape[0], np.float32)
@@ -252,6 +284,7 @@ def make_desc(spec: dict, std: str = "pyg", self_loops: str = None) -> Desc:
     # explicit self-loop edges under GCN: PyG drops them (parity target); the reference library counts them.
     # std="hls" selects the reference library's flavour as a whole unless told otherwise.
     d.gcn_self_loop_mode = SELF_LOOPS[self_loops if self_loops is not None else std]
+    d.output_activation = {None: 0, "none": 0, "softmax": 1, "log_softmax": 2}[spec.get("output_activation")]
     return d
 
 

@@ -23,8 +23,17 @@ def test_pack_roundtrip_and_validate():
 def test_pack_accepts_edge_index_layout():
     x = np.zeros((4, 2), np.float32)
     ei = np.array([[0, 1, 2], [1, 2, 3]])  # PyG [2, E]
-    b = pack_graphs([(x, ei)])
-    assert np.array_equal(b.coo, np.array([[0, 1], [1, 2], [2, 3]], np.int32))
+    want = np.array([[0, 1], [1, 2], [2, 3]], np.int32)
+    assert np.array_equal(pack_graphs([(x, ei)], layout="edge_index").coo, want)
+    assert np.array_equal(pack_graphs([(x, ei)], layout="auto").coo, want)
+    with pytest.raises(ValueError):                       # the default is the package's own [e, 2] layout
+        pack_graphs([(x, ei)])
+    # [2, 2] is two (src, dst) rows OR a two-edge edge_index: never guessed
+    two = np.array([[0, 1], [2, 3]])
+    with pytest.raises(ValueError, match="ambiguous"):
+        pack_graphs([(x, two)], layout="auto")
+    assert np.array_equal(pack_graphs([(x, two)], layout="coo").coo, [[0, 1], [2, 3]])
+    assert np.array_equal(pack_graphs([(x, two)], layout="edge_index").coo, [[0, 2], [1, 3]])
 
 
 def test_pack_rejects_bad_input():

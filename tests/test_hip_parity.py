@@ -156,6 +156,48 @@ def test_weight_free_convs_match_reference_golden(dev, kind, golden):
         runtime.set_option("agg_variant", 0)
 
 
+def test_gine_conv_matches_reference_golden(dev):
+    """GINEConv on the reference's fixture graph with its edge features and weights against its PyG golden
+    (test.cpp:1287-1455 accepts 1e-3), and the edge-index table bit-exact against tb_edge_index_table.bin."""
+    x, coo = G.graph()
+    batch = pack_graphs([(x, coo)])
+    cm = runtime.CompiledModel.from_model(plain_model("gin", 8, 8), 1, G.N, G.E)
+    xd, cood, nptr, eptr = to_dev(batch, dev)
+    cm.graph_prep(cood, nptr, eptr, G.N)
+    assert np.array_equal(cm.edge_index_table_to_host(), G.i32("tb_edge_index_table"))
+    w = [torch.from_numpy(np.array(t)).to(dev) for t in G.gine_weights()]
+    ea = torch.from_numpy(G.edge_features()).to(dev)
+    y = cm.gine_conv(xd, ea, *w, eps=G.conv_kwargs("gine")["eps"])
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - G.f32("tb_gine_output", (G.N, G.F))).max() < 2e-6
+
+
+def test_gine_conv_on_batches_matches_oracle(dev):
+    """GINE over a batch with degenerate graphs (isolated nodes, E = 0, self loops, duplicate edges, a hub) and molhiv-
+    sized ones, widths that are / are not multiples of 4, against the oracle graph by graph."""
+    rng = np.random.default_rng(11)
+    for width, edim in ((8, 16), (32, 5), (7, 3)):
+        small = edge_case_batch()
+        big = synthetic.make_batch("molhiv", 20, seed=width)
+        graphs = [(rng.uniform(-1, 1, (small.graph(g)[0].shape[0], width)).astype(np.float32), small.graph(g)[1])
+                  for g in range(small.num_graphs)]
+        graphs += [(rng.uniform(-1, 1, (big.graph(g)[0].shape[0], width)).astype(np.float32), big.graph(g)[1])
+                   for g in range(big.num_graphs)]
+        batch = pack_graphs(graphs)
+        ea = rng.uniform(-1, 1, (batch.num_edges, edim)).astype(np.float32)
+        ws = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in ((width, edim), (width,), (16, width), (16,), (12, 16), (12,))]
+        cm = runtime.CompiledModel.from_model(plain_model("gin", width, 8), batch.num_graphs, batch.num_nodes, batch.num_edges)
+        xd, cood, nptr, eptr = to_dev(batch, dev)
+        cm.graph_prep(cood, nptr, eptr, batch.num_nodes)
+        y = cm.gine_conv(xd, torch.from_numpy(ea).to(dev), *[torch.from_numpy(t).to(dev) for t in ws], eps=0.3).cpu().numpy()
+        ref = []
+        for g in range(batch.num_graphs):
+            xg, cg = batch.graph(g)
+            if xg.shape[0]:
+                ref.append(O.gine_conv(xg, cg, ea[batch.edge_ptr[g]:batch.edge_ptr[g + 1]], ws, eps=0.3))
+        assert np.abs(y - np.concatenate(ref)).max() < 1e-5, (width, edim)
+
+
 def test_weight_free_convs_on_degenerate_and_large_graphs(dev):
     """LG / Simple / copy on isolated nodes, empty graphs, hubs and graphs beyond an LDS stage, vs the oracle."""
     batch = edge_case_batch()
@@ -367,6 +409,24 @@ def test_whole_model_matches_oracle(dev, case):
     assert np.abs(got - ref).max() < TOL, f"max err {np.abs(got - ref).max():.3e}, |ref| {np.abs(ref).max():.3e}"
 
 
+@pytest.mark.parametrize("cls", [torch.nn.Softmax, torch.nn.LogSoftmax])
+@pytest.mark.parametrize("conv,promise", [("gcn", 29), ("gcn", 0), ("sage", 0)])
+def test_output_activation(dev, cls, conv, promise):
+    """GNNModel.output_activation (softmax / log_softmax over each graph's output row) on every route of the forward."""
+    import gnnbuilder_amd as gnnb
+
+    torch.manual_seed(5)
+    from helpers import CONVS
+    model = gnnb.GNNModel(11, None, 64, 2, 64, CONVS[conv], torch.nn.ReLU, True, gnnb.GlobalPooling(["add", "mean", "max"]),
+                          gnnb.MLP(192, 19, 64, 2), cls).eval()
+    batch = synthetic.make_batch("qm9", 70, seed=2)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise)
+    out = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    cm.check()
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    assert np.abs(out - ref).max() < TOL
+
+
 def test_host_entry_and_single_graph(dev):
     """forward_batched_host (what <name>_top uses) == device entry; a graph alone == inside a batch."""
     model = make_model("gcn", hidden=64)
@@ -528,8 +588,28 @@ def test_fused_gcn_stack_equals_layerwise_and_oracle(dev, fin, h0, h1, act, pool
     assert np.abs(fused - layerwise).max() < 2e-5
 
 
+def test_wrong_tensor_layouts_are_refused(dev):
+    """A raw pointer crosses the C ABI: another dtype / layout / device would be silently reinterpreted (advisor
+    finding).  The binding refuses a PyG edge_index ([2, E] int64), CPU tensors, non-contiguous views, a feature width
+    that is not the model's."""
+    model = make_model("gcn", in_dim=11, hidden=16, layers=1)
+    batch = synthetic.make_batch("qm9", 8, seed=0)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    x, coo, nptr, eptr = to_dev(batch, dev)
+    cm.forward(x, coo, nptr, eptr)
+    for bad in ((x, coo.T.contiguous().long(), nptr, eptr),          # PyG edge_index
+                (x, coo.long(), nptr, eptr),                         # int64 rows
+                (x.cpu(), coo, nptr, eptr),                          # host tensor
+                (x[:, :9].contiguous(), coo, nptr, eptr),            # another feature width
+                (x.double(), coo, nptr, eptr),
+                (x, coo.T.contiguous().T, nptr, eptr),               # non-contiguous view
+                (x, coo, nptr[:-1], eptr)):
+        with pytest.raises(runtime.GnnbError):
+            cm.forward(*bad)
+
+
 def test_broken_max_graph_nodes_promise_is_detected(dev):
-    model = make_model("gcn", hidden=64, layers=2)
+    model = make_model("gcn", in_dim=9, hidden=64, layers=2)  # (molhiv-shaped features)
     batch = synthetic.make_batch("molhiv", 40, seed=3)  # graphs of up to 222 nodes
     assert np.diff(batch.node_ptr).max() > 29
     cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)

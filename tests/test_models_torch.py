@@ -85,3 +85,29 @@ def test_torch_forward_matches_oracle(conv, act, skip, pools, layers):
         one = m(torch.from_numpy(xg), torch.from_numpy(cg.T.astype(np.int64))).numpy()
     assert np.abs(got - ref).max() < 2e-5
     assert one.shape == (1, 5) and np.abs(one[0] - ref[5]).max() < 2e-5
+
+
+def test_output_activation_softmax_oracle_equals_torch():
+    """GNNModel(output_activation=nn.Softmax / nn.LogSoftmax) (reference models.py:500-502, 572-573): the oracle's
+    output map equals the torch module applied to each graph's row."""
+    import gnnbuilder_amd as gnnb
+    from gnnbuilder_amd import synthetic
+    from helpers import batch_vector, canon
+    from oracle import oracle as O
+
+    batch = synthetic.make_batch("qm9", 12, seed=3)
+    for cls, name in ((torch.nn.Softmax, "softmax"), (torch.nn.LogSoftmax, "log_softmax")):
+        torch.manual_seed(1)
+        model = gnnb.GNNModel(11, None, 16, 2, 16, gnnb.GCNConv_GNNB, torch.nn.ReLU, True, gnnb.GlobalPooling(["add", "max"]),
+                              gnnb.MLP(32, 5, 16, 1), cls).eval()
+        assert model.spec()["output_activation"] == name
+        with torch.no_grad():
+            want = model(torch.from_numpy(batch.x), torch.from_numpy(batch.coo.T.astype(np.int64)),
+                         torch.from_numpy(batch_vector(batch))).numpy()
+        got = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+        assert np.abs(got - want).max() < 1e-6
+        if name == "softmax":
+            assert np.abs(got.sum(1) - 1).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        gnnb.GNNModel(11, None, 16, 1, 16, gnnb.GCNConv_GNNB, torch.nn.ReLU, True, gnnb.GlobalPooling(["add"]),
+                      gnnb.MLP(16, 5, 16, 1), torch.nn.Softmin).spec()
