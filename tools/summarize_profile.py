@@ -33,18 +33,29 @@ def kernel_stats(path: Path, out: Path, title: str) -> None:
                     f"{float(r['Percentage']):.2f}\n")
 
 
-kernel_stats(src / "bench" / "bench_kernel_stats.csv", dst / f"{tag}_bench_kernel_stats.csv",
-             "python3 bench.py  (default: N=1, workload c2)")
-kernel_stats(src / "roofline" / "roofline_kernel_stats.csv", dst / f"{tag}_roofline_only_kernel_stats.csv",
-             "python3 bench.py --roofline-only  (HBM-regime gather-aggregate loop only)")
+for wdir in sorted(src.glob("bench_c*")):
+    if not wdir.is_dir():
+        continue
+    w = wdir.name.split("_", 1)[1]
+    stats = list(wdir.rglob("bench_kernel_stats.csv"))
+    if stats:
+        kernel_stats(stats[0], dst / f"{tag}_{w}_bench_kernel_stats.csv", f"python3 bench.py --workload {w} --steps 100  (N=1)")
+    lines = [l for l in (src / f"bench_{w}.log").read_text().splitlines() if l.startswith("{")]
+    if lines:
+        (dst / f"{tag}_{w}_bench.json").write_text(json.dumps(json.loads(lines[-1]), indent=1) + "\n")
+if not (src / "roofline.log").exists():
+    sys.exit(0)
+kernel_stats(next((src / "roofline").rglob("roofline_kernel_stats.csv")), dst / f"{tag}_roofline_only_kernel_stats.csv",
+             "python3 bench.py --roofline-only  (HBM-regime gather-aggregate loop + its copy calibration + the fused stack loop)")
 
 def collect(pattern):
     pmc = {}
     for sub, fname in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("pmc_l2", "l2"), ("pmc_inst", "inst"),
-                       ("pmc_busy", "busy")):
-        p = src / sub / f"{fname}_counter_collection.csv"
-        if not p.exists():
+                       ("pmc_busy", "busy"), ("pmc_wait", "wait")):
+        found = list((src / sub).rglob(f"{fname}_counter_collection.csv")) if (src / sub).exists() else []
+        if not found:
             continue
+        p = found[0]
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(p)):
             if pattern in r["Kernel_Name"]:
@@ -54,12 +65,12 @@ def collect(pattern):
     return pmc
 
 
-pmc = collect("k_aggregate")
+pmc = collect("k_aggregate_ring<0,")   # MODE 0 = GCN (the copy calibration is MODE 6)
 
 log = (src / "roofline.log").read_text().strip().splitlines()
 meas = json.loads([l for l in log if l.startswith("{")][-1])
 summary = {"command": "rocprofv3 --pmc <counter> -- python3 bench.py --roofline-only (one pass per counter)",
-           "kernel": "gnnb::k_aggregate_* <GCN, float4>, width 128, BASELINE config 2 batch",
+           "kernel": "gnnb::k_aggregate_ring<GCN, float4, nt stores, one ring per workgroup>, width 128, BASELINE config 2 batch",
            "raw_counters_per_launch": pmc,
            "algorithmic_bytes_per_launch": meas["algorithmic_bytes_per_launch"],
            "events_us_per_launch": meas["us"]}
