@@ -42,8 +42,9 @@ template_env = jinja2.Environment(
 
 
 class FPX:
-    """Fixed-point spec of the reference (code_gen.py:39-52).  Kept so scripts that pass one keep
-    working; the MI355X backend computes in fp32 only."""
+    """Fixed-point spec of the reference (code_gen.py:39-52).  ``Project(float_or_fixed="fixed", fpx=FPX(W, I))``
+    selects the layer-boundary emulation of ``ap_fixed<W, I, AP_TRN, AP_WRAP>`` (``gnnb_model_desc.fpx_w / fpx_i``,
+    include/gnnb_hip.h): inputs, weights and every layer's output on the grid, fp32 sums inside a layer."""
 
     def __init__(self, W: int = 32, I: int = 16, Q: str = "AP_TRN", O: str = "AP_WRAP"):
         self.W, self.I, self.Q, self.O = W, I, Q, O
@@ -104,9 +105,13 @@ class Project:
         if float_or_fixed not in ["float", "fixed"]:
             raise ValueError("float_or_fixed must be one of ['float', 'fixed']")
         if float_or_fixed == "fixed":
-            raise NotImplementedError(
-                "the MI355X backend computes in fp32; ap_fixed emulation is not built "
-                "(SURVEY.md 8(f) rank 4)")
+            # the MI355X backend computes in fp32; "fixed" puts inputs, weights and every layer's output on the
+            # ap_fixed<W, I> grid (AP_TRN / AP_WRAP, the reference's defaults): an accuracy-study emulation at layer
+            # boundaries (include/gnnb_hip.h, gnnb_model_desc.fpx_w), not a bit-exact ap_fixed model
+            if fpx.Q != "AP_TRN" or fpx.O != "AP_WRAP":
+                raise NotImplementedError("the fixed-point emulation implements AP_TRN / AP_WRAP (the reference's defaults)")
+            if fpx.W > 32 or fpx.W - fpx.I > 24:
+                raise NotImplementedError("the fixed-point emulation takes W <= 32 and W - I <= 24")
         self.clock_speed = clock_speed
         if self.clock_speed <= 0:
             raise ValueError("clock_speed must be > 0")
@@ -156,6 +161,8 @@ class Project:
             "mlp_out": spec["mlp_out"], "mlp_activation": ACT[spec["mlp_activation"]],
             "gin_eps": repr(float(spec["gin_eps"])), "pna_delta": repr(float(spec["pna_delta"])),
             "output_activation": OUT_ACT[spec.get("output_activation")],
+            "fpx_w": self.fpx.W if self.float_or_fixed == "fixed" else 0,
+            "fpx_i": self.fpx.I if self.float_or_fixed == "fixed" else 0,
         }
         return {
             "name": self.name,

@@ -111,6 +111,9 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
                              int h0, const float *w1, const float *b1, int h1, int act,
                              const int32_t *pools, int num_pools, float *pooled, hipStream_t s);
 
+// dst = src put on the ap_fixed<W, I> grid (truncate, wrap); dst may alias src
+hipError_t launch_quantize(const float *src, float *dst, size_t n, int W, int I, hipStream_t s);
+
 hipError_t launch_output_activation(float *out, int num_graphs, int n, int kind, hipStream_t s);
 
 hipError_t launch_global_pool(const float *x, const int32_t *node_ptr, int num_graphs, int d,

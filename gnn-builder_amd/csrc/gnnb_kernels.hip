@@ -3842,6 +3842,29 @@ hipError_t launch_output_activation(float *out, int num_graphs, int n, int kind,
     return hipGetLastError();
 }
 
+// ap_fixed<W, I, AP_TRN, AP_WRAP> grid (reference code_gen.py:39-52, model.h.jinja:41-45): truncate towards minus
+// infinity to a multiple of 2^-(W-I), wrap into [-2^(I-1), 2^(I-1)).  `inv_step` = 2^(W-I), `span` = 2^I.
+__global__ __launch_bounds__(WG) void k_quantize(const float *__restrict__ src, float *__restrict__ dst, size_t n,
+                                                 float inv_step, float step, float half_span, float span)
+{
+    for (size_t i = blockIdx.x * (size_t)WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+        float v = floorf(src[i] * inv_step) * step;
+        v = v - span * floorf((v + half_span) / span); // two's-complement wrap
+        dst[i] = v;
+    }
+}
+
+hipError_t launch_quantize(const float *src, float *dst, size_t n, int W, int I, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const float inv_step = ldexpf(1.0f, W - I), step = ldexpf(1.0f, -(W - I));
+    const float span = ldexpf(1.0f, I), half = ldexpf(1.0f, I - 1);
+    const unsigned grid = (unsigned)std::min<size_t>((n + WG - 1) / WG, 4096);
+    hipLaunchKernelGGL(k_quantize, dim3(grid), dim3(WG), 0, s, src, dst, n, inv_step, step, half, span);
+    return hipGetLastError();
+}
+
 #ifdef GNNB_PROBE
 extern "C" int gnnb_probe_read(unsigned long long *host, int count)
 {

@@ -130,6 +130,10 @@ static int validate_desc(const gnnb_model_desc *d)
         return fail(GNNB_ERR_INVALID, "pna_delta must be > 0");
     if (d->output_activation < GNNB_OUT_NONE || d->output_activation > GNNB_OUT_LOG_SOFTMAX)
         return fail(GNNB_ERR_INVALID, "unsupported output_activation %d", d->output_activation);
+    if (d->fpx_w != 0 && (d->fpx_w < 2 || d->fpx_w > 32 || d->fpx_i < 1 || d->fpx_i > 33 || d->fpx_i > d->fpx_w ||
+                          d->fpx_w - d->fpx_i > 24))
+        return fail(GNNB_ERR_INVALID, "fixed-point emulation takes 2 <= W <= 32, 1 <= I <= W, W - I <= 24 (fp32 carries the "
+                                      "grid values exactly only up to 24 fractional bits)");
     return GNNB_OK;
 }
 
@@ -262,9 +266,17 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
     const gnnb_model_desc &d = *desc;
     // host staging image: every tensor padded to a 16-byte boundary
     std::vector<float> img;
+    const bool fpx = d.fpx_w > 0;
+    const float q_inv = fpx ? ldexpf(1.0f, d.fpx_w - d.fpx_i) : 1.0f, q_step = fpx ? ldexpf(1.0f, -(d.fpx_w - d.fpx_i)) : 1.0f;
+    const float q_span = fpx ? ldexpf(1.0f, d.fpx_i) : 1.0f, q_half = fpx ? ldexpf(1.0f, d.fpx_i - 1) : 1.0f;
     auto push = [&](const float *src, size_t n) -> size_t {
         size_t off = img.size();
         img.insert(img.end(), src, src + n);
+        if (fpx) // W_TYPE = ap_fixed<W, I>: the weights live on the grid (model.h.jinja:41-45)
+            for (size_t i = off; i < off + n; i++) {
+                float v = floorf(img[i] * q_inv) * q_step;
+                img[i] = v - q_span * floorf((v + q_half) / q_span);
+            }
         while (img.size() % 4)
             img.push_back(0.0f);
         return off;
@@ -666,9 +678,20 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
     const gnnb_model_desc &d = model->desc;
     const int N = ws->t.num_nodes, B = ws->t.num_graphs;
     int rc;
+    const bool fpx = d.fpx_w > 0;
+    auto quant = [&](float *buf, size_t n) -> int { // (fixed-point emulation only: put a finished tensor on the grid)
+        if (!fpx)
+            return GNNB_OK;
+        GNNB_HIP_TRY(launch_quantize(buf, buf, n, d.fpx_w, d.fpx_i, (hipStream_t)stream));
+        return GNNB_OK;
+    };
+    if (fpx) { // the input features enter as F_TYPE values: a quantised copy (the caller's buffer is not written)
+        GNNB_HIP_TRY(launch_quantize(x_dev, ws->act[1], (size_t)N * d.in_dim, d.fpx_w, d.fpx_i, (hipStream_t)stream));
+        x_dev = ws->act[1]; // (the layer loop never writes the buffer it reads)
+    }
 
     // ---- fused path: 2-layer GCN stack + pooling in one persistent kernel, then the MLP head
-    if (d.conv_type == GNNB_CONV_GCN && d.num_layers == 2 && d.mlp_num_linear <= 8) {
+    if (!fpx && d.conv_type == GNNB_CONV_GCN && d.num_layers == 2 && d.mlp_num_linear <= 8) {
         hipError_t he = launch_gcn2_fused(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
                                           model->conv[1][0], model->conv[1][1], d.out_dim, d.activation, d.pools,
                                           d.num_pools, ws->pooled, (hipStream_t)stream);
@@ -796,12 +819,14 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
             break;
         }
         }
+        if ((rc = quant(nxt, (size_t)N * fo)))
+            return rc;
         cur = nxt;
         which ^= 1;
     }
 
     const int gw = gnn_out_width(d);
-    {
+    if (!fpx) {
         // fused readout (pooling + whole MLP head, one launch) when the head fits LDS
         HeadArgs head;
         memset(&head, 0, sizeof(head));
@@ -835,6 +860,8 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
     }
     if ((rc = gnnb_global_pool(ws, cur, gw, d.pools, d.num_pools, ws->pooled, stream)))
         return rc;
+    if ((rc = quant(ws->pooled, (size_t)B * d.num_pools * gw)))
+        return rc;
 
     const float *h = ws->pooled;
     for (int i = 0; i < d.mlp_num_linear; i++) {
@@ -844,6 +871,8 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
         float *y = last ? out_dev : ws->mlp[i & 1];
         if ((rc = linear1(h, din, din, model->head_w[i], din, model->head_b[i], nullptr, y, B, dout,
                           last ? GNNB_ACT_NONE : d.mlp_activation, stream)))
+            return rc;
+        if ((rc = quant(y, (size_t)B * dout)))
             return rc;
         h = y;
     }

@@ -57,6 +57,8 @@ class ModelDesc(C.Structure):
         ("gin_eps", C.c_float),
         ("pna_delta", C.c_float),
         ("output_activation", C.c_int32),
+        ("fpx_w", C.c_int32),
+        ("fpx_i", C.c_int32),
     ]
 
 
@@ -177,6 +179,8 @@ def make_desc(spec: dict) -> ModelDesc:
     d.gin_eps = spec.get("gin_eps", 0.0)
     d.pna_delta = spec.get("pna_delta", 1.0)
     d.output_activation = OUT_ACT[spec.get("output_activation")]
+    fpx = spec.get("fpx") or (0, 0)            # (W, I) of the reference's FPX, or None for float
+    d.fpx_w, d.fpx_i = int(fpx[0]), int(fpx[1])
     return d
 
 
@@ -237,11 +241,15 @@ class CompiledModel:
 
     @classmethod
     def from_model(cls, model, max_graphs: int, max_nodes: int, max_edges: int,
-                   max_graph_nodes: int = 0) -> "CompiledModel":
+                   max_graph_nodes: int = 0, fpx=None) -> "CompiledModel":
         """``model``: a ``gnnbuilder_amd.models.GNNModel``.  ``max_graph_nodes``: promise on the largest
         graph (0 = none); small molecules enable the LDS-resident fused kernels, and the promise is
-        validated on the device (``check()`` raises if a batch breaks it)."""
-        return cls(model.spec(), model.canonical_params(), max_graphs, max_nodes, max_edges, max_graph_nodes)
+        validated on the device (``check()`` raises if a batch breaks it).  ``fpx``: ``(W, I)`` or a
+        ``code_gen.FPX`` = layer-boundary emulation of the reference's ``ap_fixed<W, I>`` build (None: float)."""
+        spec = model.spec()
+        if fpx is not None:
+            spec["fpx"] = (int(fpx.W), int(fpx.I)) if hasattr(fpx, "W") else (int(fpx[0]), int(fpx[1]))
+        return cls(spec, model.canonical_params(), max_graphs, max_nodes, max_edges, max_graph_nodes)
 
     def set_max_graph_nodes(self, n: int) -> None:
         _check(self.lib.gnnb_workspace_set_max_graph_nodes(self._ws, int(n)))

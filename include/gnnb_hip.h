@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNB_VERSION 101
+#define GNNB_VERSION 102
 
 typedef enum gnnb_status {
     GNNB_OK = 0,
@@ -75,6 +75,15 @@ typedef struct gnnb_model_desc {
     float gin_eps;          /* GINConv_GNNB.eps (models.py:76) */
     float pna_delta;        /* PNAConv_GNNB.delta used verbatim as avg_deg_log (models.py:236) */
     int32_t output_activation; /* gnnb_out_act, applied to every graph's output row */
+    /* Fixed-point emulation of the reference's float_or_fixed = "fixed" build (code_gen.py:39-52 FPX(W, I);
+     * model.h.jinja:38-62: F_TYPE = W_TYPE = ap_fixed<W, I>, quantisation AP_TRN, overflow AP_WRAP).  fpx_w = 0: float
+     * (default).  Otherwise the input features, every weight and bias, every conv layer's output (after skip and
+     * activation), the pooled vector and every head layer's output are put on the ap_fixed<W, I> grid:
+     *     q(v) = wrap(floor(v * 2^(W-I)) / 2^(W-I))   into [-2^(I-1), 2^(I-1)).
+     * Sums inside a layer are carried in fp32 (the HLS build rounds every partial result to W bits): an accuracy-
+     * study emulation at layer boundaries, not a bit-exact ap_fixed model.  The fused kernels are not used. */
+    int32_t fpx_w;
+    int32_t fpx_i;
 } gnnb_model_desc;
 
 #define GNNB_MAX_LAYERS 16

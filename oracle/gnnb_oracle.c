@@ -452,6 +452,20 @@ static void layer_dims(const gnnb_oracle_desc *d, int layer, int *fin, int *fout
     }
 }
 
+/* ap_fixed<W, I, AP_TRN, AP_WRAP> grid (code_gen.py:39-52, model.h.jinja:41-45): truncate towards minus infinity
+ * to a multiple of 2^-(W-I), wrap into [-2^(I-1), 2^(I-1)). */
+static void quantize_fpx(float *v, size_t n, int W, int I)
+{
+    if (W <= 0)
+        return;
+    const float inv = ldexpf(1.0f, W - I), step = ldexpf(1.0f, -(W - I));
+    const float span = ldexpf(1.0f, I), half = ldexpf(1.0f, I - 1);
+    for (size_t i = 0; i < n; i++) {
+        float q = floorf(v[i] * inv) * step;
+        v[i] = q - span * floorf((q + half) / span);
+    }
+}
+
 /* gnnbuilder/models.py:551-575 (GNNModel.forward), generated counterpart
  * templates/model.cpp.jinja:151-359 (conv stack, skip :304-311, activation
  * :313-322), :413-449 (pool concat), :454-530 (MLP head, models.py:398-430). */
@@ -496,9 +510,50 @@ int gnnb_oracle_forward(const gnnb_oracle_desc *d, const float *const *params, c
     float *cur = (float *)malloc(sizeof(float) * nn * (size_t)maxd);
     float *nxt = (float *)malloc(sizeof(float) * nn * (size_t)maxd);
     memcpy(cur, x, sizeof(float) * (size_t)n * (size_t)d->in_dim);
+    quantize_fpx(cur, (size_t)n * (size_t)d->in_dim, d->fpx_w, d->fpx_i); /* F_TYPE inputs */
     int width = d->in_dim;
 
+    /* fixed-point emulation: W_TYPE weights live on the grid too -- quantised copies, same order */
     const float *const *p = params;
+    float **qparams = NULL;
+    int nparams = 0;
+    if (d->fpx_w > 0) {
+        nparams = gnnb_oracle_num_params(d);
+        qparams = (float **)malloc(sizeof(float *) * (size_t)nparams);
+        int pi = 0;
+        for (int l = 0; l < d->num_layers; l++) {
+            int fi, fo;
+            layer_dims(d, l, &fi, &fo);
+            size_t sz[6];
+            int ns = 0;
+            switch (d->conv_type) {
+            case GNNB_O_CONV_GCN: sz[0] = (size_t)fo * fi; sz[1] = fo; ns = 2; break;
+            case GNNB_O_CONV_GIN: sz[0] = (size_t)fo * fi; sz[1] = fo; sz[2] = (size_t)fo * fo; sz[3] = fo; ns = 4; break;
+            case GNNB_O_CONV_SAGE: sz[0] = (size_t)fo * fi; sz[1] = fo; sz[2] = (size_t)fo * fi; ns = 3; break;
+            default: sz[0] = (size_t)fi * 2 * fi; sz[1] = fi; sz[2] = (size_t)fo * 13 * fi; sz[3] = fo; sz[4] = (size_t)fo * fo; sz[5] = fo; ns = 6; break;
+            }
+            for (int k = 0; k < ns; k++, pi++) {
+                qparams[pi] = (float *)malloc(sizeof(float) * sz[k]);
+                memcpy(qparams[pi], params[pi], sizeof(float) * sz[k]);
+                quantize_fpx(qparams[pi], sz[k], d->fpx_w, d->fpx_i);
+            }
+        }
+        int din = d->num_pools * (d->num_layers == 0 ? d->in_dim : d->out_dim);
+        for (int l = 0; l < d->mlp_num_linear; l++) {
+            int dout = (l == d->mlp_num_linear - 1) ? d->mlp_out : d->mlp_hidden;
+            size_t sw = (size_t)din * dout;
+            qparams[pi] = (float *)malloc(sizeof(float) * sw);
+            memcpy(qparams[pi], params[pi], sizeof(float) * sw);
+            quantize_fpx(qparams[pi], sw, d->fpx_w, d->fpx_i);
+            pi++;
+            qparams[pi] = (float *)malloc(sizeof(float) * (size_t)dout);
+            memcpy(qparams[pi], params[pi], sizeof(float) * (size_t)dout);
+            quantize_fpx(qparams[pi], (size_t)dout, d->fpx_w, d->fpx_i);
+            pi++;
+            din = dout;
+        }
+        p = (const float *const *)qparams;
+    }
     for (int l = 0; l < d->num_layers; l++) {
         int fin, fout;
         layer_dims(d, l, &fin, &fout);
@@ -526,6 +581,7 @@ int gnnb_oracle_forward(const gnnb_oracle_desc *d, const float *const *params, c
                 nxt[i] = nxt[i] + cur[i];
         }
         gnnb_oracle_activation(nxt, (int64_t)n * fout, d->activation);
+        quantize_fpx(nxt, (size_t)n * (size_t)fout, d->fpx_w, d->fpx_i);
         float *t = cur;
         cur = nxt;
         nxt = t;
@@ -536,6 +592,7 @@ int gnnb_oracle_forward(const gnnb_oracle_desc *d, const float *const *params, c
     float *pooled = (float *)malloc(sizeof(float) * (size_t)pooled_dim);
     for (int k = 0; k < d->num_pools; k++)
         gnnb_oracle_global_pool(cur, n, width, d->pools[k], pooled + (size_t)k * width);
+    quantize_fpx(pooled, (size_t)pooled_dim, d->fpx_w, d->fpx_i);
 
     int hd = d->mlp_hidden > d->mlp_out ? d->mlp_hidden : d->mlp_out;
     if (pooled_dim > hd)
@@ -551,6 +608,7 @@ int gnnb_oracle_forward(const gnnb_oracle_desc *d, const float *const *params, c
         p += 2;
         if (!last)
             gnnb_oracle_activation(b, dout, d->mlp_activation);
+        quantize_fpx(b, (size_t)dout, d->fpx_w, d->fpx_i);
         float *t = a;
         a = b;
         b = t;
@@ -577,6 +635,11 @@ int gnnb_oracle_forward(const gnnb_oracle_desc *d, const float *const *params, c
     free(offsets);
     free(nbrs);
     free(noloop);
+    if (qparams) {
+        for (int i = 0; i < nparams; i++)
+            free(qparams[i]);
+        free(qparams);
+    }
     return 0;
 }
 

@@ -61,6 +61,7 @@ typedef struct gnnb_oracle_desc {
     int32_t pna_std_mode;
     int32_t gcn_self_loop_mode;
     int32_t output_activation; /* 0 none, 1 softmax, 2 log_softmax over the output vector (models.py:500-502, 572-573) */
+    int32_t fpx_w, fpx_i;      /* ap_fixed<W, I> emulation at layer boundaries (code_gen.py:39-52; 0 = float) */
 } gnnb_oracle_desc;
 
 /* graph prep: gnn_builder_lib.h:1051-1083, :1086-1124 */

@@ -45,6 +45,8 @@ class Desc(C.Structure):
         ("pna_std_mode", C.c_int32),
         ("gcn_self_loop_mode", C.c_int32),
         ("output_activation", C.c_int32),
+        ("fpx_w", C.c_int32),
+        ("fpx_i", C.c_int32),
     ]
 
 
@@ -285,6 +287,8 @@ def make_desc(spec: dict, std: str = "pyg", self_loops: str = None) -> Desc:
     # std="hls" selects the reference library's flavour as a whole unless told otherwise.
     d.gcn_self_loop_mode = SELF_LOOPS[self_loops if self_loops is not None else std]
     d.output_activation = {None: 0, "none": 0, "softmax": 1, "log_softmax": 2}[spec.get("output_activation")]
+    fpx = spec.get("fpx") or (0, 0)
+    d.fpx_w, d.fpx_i = int(fpx[0]), int(fpx[1])
     return d
 
 

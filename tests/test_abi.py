@@ -43,15 +43,15 @@ def test_library_has_gfx950_code_object(lib_path):
 
 def test_library_loads_and_reports_version(lib_path):
     lib = runtime.load_library(require_gpu=False)
-    assert lib.gnnb_version() == 101
+    assert lib.gnnb_version() == 102
     for sym in runtime.EXPORTED_SYMBOLS:
         assert hasattr(lib, sym)
 
 
 def test_struct_layout_matches_header():
-    # 16 int32/float fields + pools[3] = 18 * 4 bytes
+    # 18 int32/float fields + pools[3] = 20 * 4 bytes
     import ctypes
-    assert ctypes.sizeof(runtime.ModelDesc) == 18 * 4
+    assert ctypes.sizeof(runtime.ModelDesc) == 20 * 4
     assert ctypes.sizeof(runtime.GemmSeg) == 24
 
 

@@ -98,8 +98,13 @@ def test_constructor_validation_matches_the_reference():
         gnnb.Project("p", model, "regression", None, "/tmp", fpga_part="nope")
     with pytest.raises(ValueError):
         gnnb.Project("p", model, "regression", None, "/tmp", n_jobs=0)
+    # float_or_fixed = "fixed": the ap_fixed<W, I> emulation is rendered into the model description ...
+    fx = gnnb.Project("pfx", model, "regression", None, "/tmp", float_or_fixed="fixed", fpx=gnnb.FPX(16, 10))
+    assert fx.template_dict["desc"]["fpx_w"] == 16 and fx.template_dict["desc"]["fpx_i"] == 10
+    assert gnnb.Project("pfl", model, "regression", None, "/tmp").template_dict["desc"]["fpx_w"] == 0
+    # ... other rounding / overflow modes than the reference's defaults are not emulated
     with pytest.raises(NotImplementedError):
-        gnnb.Project("p", model, "regression", None, "/tmp", float_or_fixed="fixed")
+        gnnb.Project("p", model, "regression", None, "/tmp", float_or_fixed="fixed", fpx=gnnb.FPX(16, 10, Q="AP_RND"))
     with pytest.raises(Exception, match="I must be <= 33"):
         gnnb.FPX(64, 40)
     p = gnnb.Project("p", model, "regression", None, "/tmp")

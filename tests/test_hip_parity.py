@@ -427,6 +427,29 @@ def test_output_activation(dev, cls, conv, promise):
     assert np.abs(out - ref).max() < TOL
 
 
+@pytest.mark.parametrize("conv", ["gcn", "gin", "sage", "pna"])
+@pytest.mark.parametrize("W,I", [(32, 12), (16, 8), (12, 6)])
+def test_fixed_point_emulation(dev, conv, W, I):
+    """gnnb_model_desc.fpx_w / fpx_i (the reference's float_or_fixed = "fixed" with FPX(W, I)): the HIP forward against
+    the oracle's emulation.  Both quantise the same tensors; their fp32 sums differ in order, so a value that lands
+    within rounding of a grid line may fall one step apart (and a step apart at one layer moves later ones)."""
+    model = make_model(conv, in_dim=9, hidden=32, layers=3, task_out=3)
+    batch = synthetic.make_batch("molhiv", 24, seed=W)
+    spec = dict(model.spec(), fpx=(W, I))
+    ref = O.forward_batched(spec, canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, fpx=(W, I))
+    out = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    cm.check()
+    step = 2.0 ** -(W - I)
+    assert np.abs(out / step - np.round(out / step)).max() < 1e-3              # on the grid
+    frac_exact = np.mean(out == ref)
+    assert np.abs(out - ref).max() <= max(40 * step, 2e-4) and frac_exact > 0.5, (np.abs(out - ref).max() / step, frac_exact)
+    # fine grid == the float model
+    if W == 32:
+        flt = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+        assert np.abs(out - flt).max() < 1e-3
+
+
 def test_host_entry_and_single_graph(dev):
     """forward_batched_host (what <name>_top uses) == device entry; a graph alone == inside a batch."""
     model = make_model("gcn", hidden=64)

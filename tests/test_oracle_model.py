@@ -59,3 +59,26 @@ def test_degenerate_inputs_are_finite():
         bad[0, 0] = 3  # edge of graph 2 pointing at a node of... itself is fine; make it leave the graph
         bad[0, 0] = 99
         O.forward_batched(m.spec(), canon(m), b.x, bad, b.node_ptr, b.edge_ptr)
+
+
+@pytest.mark.parametrize("conv", ["gcn", "gin", "sage", "pna"])
+def test_fixed_point_emulation_in_the_oracle(conv):
+    """FPX(W, I) emulation (reference code_gen.py:39-52, model.h.jinja:38-62): every output lies on the
+    ap_fixed<W, I> grid, a fine grid reproduces the float result, a coarse one departs from it by a few steps per
+    layer, and wrap-around (AP_WRAP) keeps values inside [-2^(I-1), 2^(I-1))."""
+    from gnnbuilder_amd import synthetic
+    from helpers import canon, make_model
+
+    model = make_model(conv, in_dim=9, hidden=16, layers=2, task_out=3)
+    batch = synthetic.make_batch("esol", 12, seed=1)
+    args = (canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    ref = O.forward_batched(model.spec(), *args)
+    for W, I, tol in ((32, 8, 1e-3), (16, 8, 0.5)):
+        spec = dict(model.spec(), fpx=(W, I))
+        out = O.forward_batched(spec, *args)
+        step = 2.0 ** -(W - I)
+        assert np.abs(out / step - np.round(out / step)).max() < 1e-3          # on the grid
+        assert np.abs(out).max() < 2.0 ** (I - 1)
+        assert np.abs(out - ref).max() < tol, (W, I, np.abs(out - ref).max())
+    coarse = O.forward_batched(dict(model.spec(), fpx=(12, 6)), *args)
+    assert np.abs(coarse - ref).max() > 1e-3                                   # the grid really bites
