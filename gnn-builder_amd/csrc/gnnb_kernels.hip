@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 __global__ __launch_bounds__(WG) void k_linear_dma(GemmArgs g, const float *__restrict__ W, int ldw,
                                                    const float *__restrict__ bias,
                                                    const float *__restrict__ skip, float *__restrict__ Y, int M,
-                                                   int N, int act)
+                                                   int N, int act, int tiles_m, int tiles_n)
 {
     constexpr int NT = 2, BN = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1592,31 +1592,22 @@ __global__ __launch_bounds__(WG) void k_linear_dma(GemmArgs g, const float *__re
     // [2 buffers][A chunk | W chunk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int total = g.cpre[g.nseg];
-
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-        for (int ni = 0; ni < NT; ni++)
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                acc[mi][ni][i] = 0.0f;
-
-    // per-row scalers of the scaled segments (PNA: amp . A, att . A), fetched ONCE for the lane's two A rows:
-    // a load inside the chunk loop would queue behind the DMA in flight
     const int li = lane & 31, lh = lane >> 5;
-    float sc[4][2];
-#pragma unroll
-    for (int sgm = 0; sgm < 4; sgm++)
-#pragma unroll
-        for (int mi = 0; mi < 2; mi++) {
-            const int row = min(m0 + wm * 64 + mi * 32 + li, M - 1);
-            sc[sgm][mi] = (sgm < g.nseg && g.rs[sgm] != nullptr) ? g.rs[sgm][row] : 1.0f;
-        }
+    // PERSISTENT over output tiles (grid = what is resident): the chunk pipeline runs straight across tile
+    // boundaries -- the first chunk of the next tile is requested before the last chunk of this one is multiplied,
+    // so its latency and this tile's epilogue overlap (a short-lived workgroup per tile exposed one HBM latency per
+    // 16 chunks at K = 512).  Tiles sharing a row block are adjacent in the order (their A chunks hit in L2).
+    const int num_tiles = tiles_m * tiles_n;
+    // (measured: remapping block ids so that each XCD owns a contiguous run of tiles -- the two column tiles of a row
+    // block sharing one L2 -- is SLOWER here, 601 vs 573 us at the C5 shape: round-robin order spreads the rows that
+    // are in flight at one time over all HBM channels)
+    int tile = blockIdx.x;
+    if (tile >= num_tiles)
+        return;
 
-    auto issue = [&](int c, int buf) {
+    auto issue = [&](int t, int c, int buf) {
+        const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
         // segment lookup with static indexing only (keeps the kernarg struct out of scratch)
         const float *ap = g.a[0];
         int lda = g.lda[0], koff = g.koff[0], cbase = 0;
@@ -1642,79 +1633,125 @@ __global__ __launch_bounds__(WG) void k_linear_dma(GemmArgs g, const float *__re
         }
     };
 
-    issue(0, 0);
-    dma_wait_all();
-    __syncthreads();
-    for (int c = 0; c < total; c++) {
-        const int buf = c & 1;
-        if (c + 1 < total)
-            issue(c + 1, buf ^ 1);
-        float s0 = sc[0][0], s1 = sc[0][1]; // this chunk's segment (uniform), static indexing
-        bool scaled = g.rs[0] != nullptr;
-#pragma unroll
-        for (int sgm = 1; sgm < 4; sgm++)
-            if (sgm < g.nseg && c >= g.cpre[sgm]) {
-                s0 = sc[sgm][0];
-                s1 = sc[sgm][1];
-                scaled = g.rs[sgm] != nullptr;
-            }
-        const float *a = reinterpret_cast<const float *>(smem + (size_t)buf * 2 * TILE_B);
-        const float *b = reinterpret_cast<const float *>(smem + (size_t)buf * 2 * TILE_B + TILE_B);
-#pragma unroll
-        for (int kb = 0; kb < BK; kb += 8) {
-            float4 fa[2], fb[NT];
-            const int piece = (kb >> 2) + lh; // 16-B piece holding k = kb + 4 lh .. + 3
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                const int r = wm * 64 + mi * 32 + li;
-                fa[mi] = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
-            }
-            if (scaled) { // the row scaler multiplies the A operand, as in the register-staged kernel
-                fa[0].x *= s0, fa[0].y *= s0, fa[0].z *= s0, fa[0].w *= s0;
-                fa[1].x *= s1, fa[1].y *= s1, fa[1].z *= s1, fa[1].w *= s1;
-            }
-#pragma unroll
-            for (int ni = 0; ni < NT; ni++) {
-                const int r = wn * 32 * NT + ni * 32 + li;
-                fb[ni] = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
-            }
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                for (int ni = 0; ni < NT; ni++) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].x, fb[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].y, fb[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].z, fb[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
-                }
-        }
-        dma_wait_all(); // the next chunk has landed (issued a whole chunk of MFMAs ago)
-        __syncthreads(); // ... for everyone, and everyone is done reading this one
-    }
-
-    auto epilogue = [&](auto tag) {
-        constexpr int ACT = decltype(tag)::value;
+    issue(tile, 0, 0);
+    int buf = 0;
+    for (; tile < num_tiles; tile += gridDim.x) {
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        const int next_tile = tile + gridDim.x;
+        f32x16 acc[2][NT];
 #pragma unroll
         for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-            for (int ni = 0; ni < NT; ni++) {
-                const int colg = n0 + wn * 32 * NT + ni * 32 + li;
-                if (colg >= N)
-                    continue;
-                const float bv = bias ? bias[colg] : 0.0f;
+            for (int ni = 0; ni < NT; ni++)
 #pragma unroll
-                for (int reg = 0; reg < 16; reg++) {
-                    const int rowg = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                    if (rowg < M) {
-                        float v = acc[mi][ni][reg] + bv;
-                        if (skip)
-                            v += skip[(size_t)rowg * N + colg];
-                        Y[(size_t)rowg * N + colg] = act_t<ACT>(v);
-                    }
-                }
+                for (int i = 0; i < 16; i++)
+                    acc[mi][ni][i] = 0.0f;
+
+        // per-row scalers of the scaled segments (PNA: amp . A, att . A), fetched once per tile for the lane's two A rows
+        float sc[4][2];
+#pragma unroll
+        for (int sgm = 0; sgm < 4; sgm++)
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+                const int row = min(m0 + wm * 64 + mi * 32 + li, M - 1);
+                sc[sgm][mi] = (sgm < g.nseg && g.rs[sgm] != nullptr) ? g.rs[sgm][row] : 1.0f;
             }
-    };
-    GNNB_DISPATCH_ACT(act, epilogue)
+
+        for (int c = 0; c < total; c++, buf ^= 1) {
+            // this chunk has landed (it was issued a whole chunk of MFMAs ago) for everyone, and everyone is done
+            // reading the other buffer
+            dma_wait_all();
+            __syncthreads();
+            if (c + 1 < total)
+                issue(tile, c + 1, buf ^ 1);
+            else if (next_tile < num_tiles)
+                issue(next_tile, 0, buf ^ 1);
+            float s0 = sc[0][0], s1 = sc[0][1]; // this chunk's segment (uniform), static indexing
+            bool scaled = g.rs[0] != nullptr;
+#pragma unroll
+            for (int sgm = 1; sgm < 4; sgm++)
+                if (sgm < g.nseg && c >= g.cpre[sgm]) {
+                    s0 = sc[sgm][0];
+                    s1 = sc[sgm][1];
+                    scaled = g.rs[sgm] != nullptr;
+                }
+            const float *a = reinterpret_cast<const float *>(smem + (size_t)buf * 2 * TILE_B);
+            const float *b = reinterpret_cast<const float *>(smem + (size_t)buf * 2 * TILE_B + TILE_B);
+#pragma unroll
+            for (int kb = 0; kb < BK; kb += 8) {
+                float4 fa[2], fb[NT];
+                const int piece = (kb >> 2) + lh; // 16-B piece holding k = kb + 4 lh .. + 3
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++) {
+                    const int r = wm * 64 + mi * 32 + li;
+                    fa[mi] = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
+                }
+                if (scaled) { // the row scaler multiplies the A operand, as in the register-staged kernel
+                    fa[0].x *= s0, fa[0].y *= s0, fa[0].z *= s0, fa[0].w *= s0;
+                    fa[1].x *= s1, fa[1].y *= s1, fa[1].z *= s1, fa[1].w *= s1;
+                }
+#pragma unroll
+                for (int ni = 0; ni < NT; ni++) {
+                    const int r = wn * 32 * NT + ni * 32 + li;
+                    fb[ni] = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
+                }
+                // operands SWAPPED (W fragment first): the 32x32 accumulator then holds, per lane, FOUR CONSECUTIVE
+                // output columns of one row per register group -- the epilogue stores float4 instead of scalars
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ni++) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].x, fa[mi].x, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].y, fa[mi].y, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].z, fa[mi].z, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa[mi].w, acc[mi][ni], 0, 0, 0);
+                    }
+            }
+        }
+
+        // D = W_tile . A_tile^T: lane (li, lh) holds Y[row = m_base + li][col = n_base + 8 (reg >> 2) + 4 lh + (reg & 3)]
+        const bool vec = (N % 4 == 0) && (((uintptr_t)Y & 15) == 0) && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
+                         (skip == nullptr || ((uintptr_t)skip & 15) == 0);
+        auto epilogue = [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+                const int rowg = m0 + wm * 64 + mi * 32 + li;
+                if (rowg >= M)
+                    continue;
+#pragma unroll
+                for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int colg = n0 + wn * 32 * NT + ni * 32 + 8 * q + 4 * lh;
+                        if (vec && colg + 3 < N) {
+                            float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2],
+                                                   acc[mi][ni][4 * q + 3]);
+                            if (bias) {
+                                const float4 bv = *reinterpret_cast<const float4 *>(bias + colg);
+                                v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                            }
+                            if (skip) {
+                                const float4 sk = *reinterpret_cast<const float4 *>(skip + (size_t)rowg * N + colg);
+                                v.x += sk.x, v.y += sk.y, v.z += sk.z, v.w += sk.w;
+                            }
+                            v.x = act_t<ACT>(v.x), v.y = act_t<ACT>(v.y), v.z = act_t<ACT>(v.z), v.w = act_t<ACT>(v.w);
+                            *reinterpret_cast<float4 *>(Y + (size_t)rowg * N + colg) = v;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
+                                if (colg + r < N) {
+                                    float v = acc[mi][ni][4 * q + r] + (bias ? bias[colg + r] : 0.0f);
+                                    if (skip)
+                                        v += skip[(size_t)rowg * N + colg + r];
+                                    Y[(size_t)rowg * N + colg + r] = act_t<ACT>(v);
+                                }
+                        }
+                    }
+            }
+        };
+        GNNB_DISPATCH_ACT(act, epilogue)
+    }
 }
 
 // -------------------------------------------------------------------------------------
@@ -2564,8 +2601,16 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
                 if (e != hipSuccess)
                     return e;
             }
-            hipLaunchKernelGGL(k_linear_dma, dim3(gm, (N + 127) / 128), dim3(WG), lds, s, g, w, ldw, bias, skip, y, M, N,
-                               act);
+            static int num_cus = 0;
+            if (num_cus == 0) {
+                int devid = 0;
+                hipDeviceProp_t prop;
+                num_cus = (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+                              ? prop.multiProcessorCount : 256;
+            }
+            const int tn = (N + 127) / 128;
+            const int grid = std::min(gm * tn, num_cus * 2); // two 64-KB workgroups are resident per CU
+            hipLaunchKernelGGL(k_linear_dma, dim3(grid), dim3(WG), lds, s, g, w, ldw, bias, skip, y, M, N, act, gm, tn);
             return hipGetLastError();
         }
     }
