@@ -213,7 +213,7 @@ int gnnb_set_option(const char *name, int value)
         o.agg_nt_store = value;
     else if (!strcmp(name, "fuse_narrow") && value >= 0 && value <= 1)
         o.fuse_narrow = value;
-    else if (!strcmp(name, "fuse_gcn2") && value >= 0 && value <= 1)
+    else if (!strcmp(name, "fuse_gcn2") && value >= 0 && value <= 2)
         o.fuse_gcn2 = value;
     else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
         o.fuse_head = value;

@@ -743,6 +743,42 @@ def test_random_multigraphs_match_oracle(dev, conv, layers, n_max, promise, seed
     assert np.abs(got - ref).max() < TOL * scale, (np.abs(got - ref).max(), scale)
 
 
+@pytest.mark.parametrize("fin,h0,h1,act", [(11, 128, 128, "relu"), (9, 64, 64, "tanh"), (20, 32, 128, "gelu"), (11, 128, 20, "sigmoid")])
+def test_fused_gcn_stack_with_aggregation_on_the_matrix_pipe(dev, fin, h0, h1, act):
+    """`fuse_gcn2` = 2 (k_gcn2_mm: the stage's dense normalised adjacency block in LDS, A_hat . x and A_hat . H as MFMA
+    products, built with LDS float atomics): against the oracle and the gather form (`fuse_gcn2` = 1) on molecule batches
+    and on random multigraphs (hubs beyond the four inline neighbour slots, duplicate edges, empty graphs, a graph of
+    exactly the promised size)."""
+    model = make_model("gcn", in_dim=fin, hidden=h0, layers=2, out_dim=h1, act=act, task_out=5)
+    rng = np.random.default_rng(fin + h0)
+    batches = [synthetic.make_batch("qm9", 300, seed=fin),
+               pack_graphs(_random_graphs(rng, 150, 33, fin, dense=4))]
+    if fin == 11:
+        q = batches[0]
+    else:
+        q = synthetic.make_batch("qm9", 300, seed=fin)
+        q = pack_graphs([(np.random.default_rng(g).uniform(-1, 1, (q.graph(g)[0].shape[0], fin)).astype(np.float32), q.graph(g)[1])
+                         for g in range(q.num_graphs)])
+    batches[0] = q
+    try:
+        for batch in batches:
+            promise = int(np.diff(batch.node_ptr).max())
+            ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+            outs = {}
+            for variant in (2, 1):
+                runtime.set_option("fuse_gcn2", variant)
+                cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1),
+                                                      max_graph_nodes=promise)
+                outs[variant] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+                cm.check()
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert np.isfinite(outs[2]).all()
+            assert np.abs(outs[2] - ref).max() < TOL * scale
+            assert np.abs(outs[2] - outs[1]).max() < 2e-5 * scale
+    finally:
+        runtime.set_option("fuse_gcn2", 1)
+
+
 @pytest.mark.parametrize("M,N,K", [(3000, 128, 128), (777, 64, 64), (1000, 32, 32), (513, 64, 128)])
 def test_linear_bf16x6_math_is_fp32_equivalent(dev, M, N, K):
     """Opt-in math mode 1 in the register-resident-weight GEMM: six bf16 MFMA products of an exact 3-way
