@@ -37,14 +37,11 @@ constexpr int GNNB_G2_STAGE_ROWS = 48; // rows per stage of the fused 2-layer GC
 
 struct Options {
     int tile_rows;    // node-tile granularity (rows; tiles are cut at graph boundaries)
-    int agg_lds_kb;   // LDS budget of the gather-aggregate kernel: per CU (ring form) / per workgroup (one-shot form)
-    int agg_tiles_per_wg; // one-shot form: node tiles per workgroup
-    int agg_variant;   // 0 = ring form: persistent, per-wave software pipeline, no workgroup barrier (default);
-                       // 1 = one-shot form: a short-lived workgroup per tile group
-    int agg_ring_waves;   // ring form: waves per workgroup (0 = automatic: the most whose stages hold a graph)
-    int agg_ring_slots;   // ring form: LDS stages per wave
+    int agg_lds_kb;   // LDS budget of the gather-aggregate kernel per workgroup (0 = all of the CU's / workgroups per CU)
+    int agg_ring_waves;   // waves per workgroup (0 = 16)
+    int agg_ring_slots;   // LDS stages in the ring
     int agg_ring_wg_per_cu;
-    int agg_nt_store;     // ring form: non-temporal output stores
+    int agg_nt_store;     // non-temporal output stores
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
     int gemm_max_wg_per_cu;
     int gemm_dma;      // 1 = large-K GEMM through LDS-DMA when every segment is plain (default)

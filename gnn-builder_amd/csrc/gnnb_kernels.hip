@@ -854,116 +854,16 @@ __device__ inline void agg_row_direct(int node, const float *__restrict__ x, con
 }
 
 // -------------------------------------------------------------------------------------
-// One-shot LDS-staged form (agg_variant 1).  A workgroup owns `tpw` consecutive node tiles (whole graphs):
-// LDS-DMA of their feature rows + node records + dinv, one barrier, reduce from LDS with two rows in
-// flight per lane group, stream the result out, exit.  No pipeline inside the workgroup: the overlap
-// comes from several short-lived workgroups per CU (LDS ~ 0.55 KB per row).  Rows that do not fit the
-// buffer (a very large graph) take the same arithmetic straight from global memory.
-template <int MODE, int VEC>
-__global__ __launch_bounds__(WG) void k_aggregate_shot(
-    const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
-    const int4 *__restrict__ node_rec, const int32_t *__restrict__ col, const float *__restrict__ dinv,
-    const int32_t *__restrict__ tile_first, int num_tiles, int N, int tpw, int w, int glog2, int rows_cap, float eps)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ta = blockIdx.x * tpw, tb = min(ta + tpw, num_tiles);
-    // (clamped: the tile table of a malformed batch may hold stale entries; a flagged batch must still stay in range)
-    const int nb = min(tile_first[ta], N), rows = min(tile_first[tb], N) - nb;
-    if (rows <= 0)
-        return;
-    const int nvec = w / VEC;
-    const int G = 1 << glog2;
-    const int groups = WG >> glog2;
-    const int grp = tid >> glog2;
-    const int gl = tid & (G - 1);
-    if (rows <= rows_cap) { // workgroup-uniform
-        char *lrec = smem + (size_t)rows_cap * w * 4;
-        char *ldinv = lrec + (size_t)rows_cap * 32;
-        const char *gx = reinterpret_cast<const char *>(x + (size_t)nb * w);
-        const int bytes = rows * w * 4;
-        if (VEC == 4) {
-            for (int c = wave * 1024; c < bytes; c += (WG / 64) * 1024)
-                if (c + lane * 16 < bytes)
-                    dma16_to_lds_u(gx + c + lane * 16, smem + c);
-        } else {
-            dma_dwords_u(gx, smem, rows * w, wave, lane, WG / 64);
-        }
-        if (MODE != GNNB_AGG_COPY) {
-            const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)nb);
-            const int rbytes = rows * 32;
-            for (int c = wave * 1024; c < rbytes; c += (WG / 64) * 1024)
-                if (c + lane * 16 < rbytes)
-                    dma16_to_lds_u(grec + c + lane * 16, lrec + c);
-        }
-        if (MODE == GNNB_AGG_GCN)
-            dma_dwords_u(dinv + nb, ldinv, rows, wave, lane, WG / 64);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        const float *sx = reinterpret_cast<const float *>(smem);
-        const int4 *srec = reinterpret_cast<const int4 *>(lrec);
-        const float *sdinv = reinterpret_cast<const float *>(ldinv);
-        for (int r = grp; r < rows; r += 2 * groups) {
-            for (int f = gl; f < nvec; f += G) {
-                const int fo = f * VEC;
-                LdsRow<MODE, VEC> A, B;
-                A.begin(true, nb, r, sx, nullptr, srec, sdinv, selfq, w, fo);
-                B.begin(r + groups < rows, nb, r + groups, sx, nullptr, srec, sdinv, selfq, w, fo);
-                A.finish(nb, sx, srec, sdinv, col, out, w, fo, eps);
-                B.finish(nb, sx, srec, sdinv, col, out, w, fo, eps);
-            }
-        }
-        return;
-    }
-    // a graph larger than the LDS buffer: straight from global memory
-    for (int r = grp; r < rows; r += groups)
-        for (int f = gl; f < nvec; f += G)
-            agg_row_direct<MODE, VEC, false>(nb + r, x, selfq, out, node_rec, col, dinv, w, f * VEC, eps);
-}
-
-template <int MODE, int VEC>
-static hipError_t launch_aggregate_shot_t(const BatchTables &t, const float *x, const float *selfq,
-                                          float *out, int w, float eps, hipStream_t s)
-{
-    const Options &o = options();
-    const int nvec = w / VEC;
-    int glog2 = 2;
-    while ((1 << glog2) < nvec && glog2 < 6)
-        glog2++;
-    if (t.num_tiles <= 0)
-        return hipSuccess;
-    const int tpw = o.agg_tiles_per_wg > 0 ? o.agg_tiles_per_wg : 1;
-    const size_t per_row = (size_t)w * 4 + 32 + 4;
-    // rows of tpw tiles: <= tpw * tile_rows + (largest graph - 1); sized for molecule-scale graphs inside the
-    // LDS budget, anything larger takes the direct path
-    int rows_cap = (int)(((size_t)(o.agg_lds_kb > 0 ? o.agg_lds_kb : 39) * 1024) / per_row) & ~3;
-    // with the caller's promise on the largest graph the buffer is sized exactly (more workgroups per CU)
-    if (t.max_graph_nodes_hint > 0)
-        rows_cap = std::min(rows_cap, (tpw * t.tile_rows + t.max_graph_nodes_hint - 1 + 3) & ~3);
-    if (rows_cap < 8)
-        rows_cap = 8;
-    const size_t lds = (((size_t)rows_cap * per_row) + 15) & ~(size_t)15;
-    const int grid = (t.num_tiles + tpw - 1) / tpw;
-    auto kern = k_aggregate_shot<MODE, VEC>;
-    {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
-        if (e != hipSuccess)
-            return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG), lds, s, x, selfq, out, t.node_rec, t.col, t.dinv,
-                       t.tile_first, t.num_tiles, t.num_nodes, tpw, w, glog2, rows_cap, eps);
-    return hipGetLastError();
-}
-
-// -------------------------------------------------------------------------------------
-// Ring form (agg_variant 0, default): persistent, one workgroup per CU, and NO workgroup barrier -- every
-// WAVE runs its own software pipeline over a contiguous run of node tiles (whole graphs).  A wave owns a
-// ring of `nslots` LDS stages of `cap` rows; per stage it fires the LDS-DMA of the rows, node records and
-// normalisers (global_load_lds, no VGPRs), and it retires stages in order behind a COUNTED vmcnt wait
-// (VM operations retire in issue order, so "at most n younger operations outstanding" proves the stage has
-// landed while the younger stages' DMA and the previous stages' output stores stay in flight).  At the
-// BASELINE sizes a CU's whole share of the input fits its ring, so all of a wave's reads are in flight from
-// the first microsecond and the stores start as soon as the first stage lands; bigger batches cycle the ring.
-// A tile that does not fit a stage (one very large graph) is reduced straight from global memory.
+// Ring form: persistent, ONE workgroup of up to 16 waves per CU, whose waves share a ring of `nslots` big LDS stages
+// (two stages take the whole 160 KB: ~140 rows each at w = 128, so molecules and graphs of a few hundred nodes fit).
+// The workgroup walks a contiguous run of node tiles (whole graphs).  Per stage every wave fires its share of the
+// LDS-DMA of the rows, node records, normalisers and the stage's CSR slice (global_load_lds, no VGPRs); stages retire
+// in order behind a COUNTED vmcnt wait (VM operations retire in issue order, so "at most n younger operations
+// outstanding" proves the stage has landed while the next stage's DMA and the previous stage's output stores stay in
+// flight) and two barriers.  At the BASELINE sizes a CU's whole share of the input fits its ring, so all reads are in
+// flight from the first microsecond; bigger batches cycle the ring.  A tile that does not fit a stage (one very large
+// graph) is reduced straight from global memory.  Forms measured and dropped this round: a short-lived
+// workgroup per tile group (round 1's default), one ring per wave.
 static constexpr int RING_MAX_SLOTS = 4;
 
 // Diagnostic build: wave 0 of every workgroup logs wall-clock stamps of its stage events (100 MHz ticks)
@@ -981,8 +881,8 @@ static constexpr int RING_MAX_SLOTS = 4;
 #define RING_EV(code) do { } while (0)
 #endif
 
-template <int MODE, int VEC, bool NT, bool COOP>
-__global__ __launch_bounds__(COOP ? 1024 : 512) void k_aggregate_ring(
+template <int MODE, int VEC, bool NT>
+__global__ __launch_bounds__(1024) void k_aggregate_ring(
     const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
     const int4 *__restrict__ node_rec, const int32_t *__restrict__ col, const float *__restrict__ dinv,
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_edge, int num_tiles, int N, int E, int w,
@@ -994,20 +894,17 @@ __global__ __launch_bounds__(COOP ? 1024 : 512) void k_aggregate_ring(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
-    // COOP: the workgroup's waves share ONE ring of big stages (each wave issues 1/nw of a stage's DMA and reduces
-    // 1/nw of its rows; two barriers per stage); otherwise every wave owns a ring and a tile range of its own
-    const int pw = COOP ? 0 : wave, pn = COOP ? 1 : nw;   // this wave's share of a stage's work: index, count ...
-    const int sw = COOP ? wave : 0, sn = COOP ? nw : 1;   // ... and of the tile ranges
-    const int gw = blockIdx.x * pn + pw, tw = gridDim.x * pn;
-    const int t0 = (int)(((long long)gw * num_tiles) / tw), t1 = (int)(((long long)(gw + 1) * num_tiles) / tw);
+    // the workgroup's waves share the ring: wave sw of sn issues 1/sn of a stage's DMA and reduces 1/sn of its rows
+    const int sw = wave, sn = nw;
+    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
     if (t0 >= t1)
-        return; // (COOP: workgroup-uniform)
+        return; // (workgroup-uniform)
 #ifdef GNNB_PROBE
     int pev = 0;
     if (threadIdx.x == 0 && blockIdx.x < 2048)
         g_probe[blockIdx.x * 64] = wall_clock64();
 #endif
-    char *wbase = smem + (size_t)pw * nslots * slot_bytes;
+    char *wbase = smem;
     const int off_q = cap * w * 4;
     const int off_rec = off_q + (HASQ ? cap * w * 4 : 0);
     const int off_dinv = off_rec + cap * 32;
@@ -1164,13 +1061,11 @@ __global__ __launch_bounds__(COOP ? 1024 : 512) void k_aggregate_ring(
         // ---- retire the oldest stage: everything issued after its DMA may stay in flight
         RING_EV(2000000 + f_rows[0]); // waiting for the oldest stage
         vmcnt_wait_n(min(vm - f_mark[0], 63));
-        if (COOP)
-            asm volatile("s_barrier" ::: "memory"); // every wave's share of the stage has landed
+        asm volatile("s_barrier" ::: "memory"); // every wave's share of the stage has landed
         RING_EV(3000000 + f_rows[0]); // landed
         vm += compute(head_slot, f_nb[0], f_rows[0], f_e0[0]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // its LDS reads are done before the slot is refilled
-        if (COOP)
-            asm volatile("s_barrier" ::: "memory"); // ... by every wave
+        asm volatile("s_barrier" ::: "memory"); // ... by every wave
         RING_EV(4000000 + f_rows[0]); // reduced, stores issued
 #pragma unroll
         for (int i = 0; i + 1 < RING_MAX_SLOTS; i++) {
@@ -1184,7 +1079,7 @@ __global__ __launch_bounds__(COOP ? 1024 : 512) void k_aggregate_ring(
     }
 }
 
-template <int MODE, int VEC, bool COOP>
+template <int MODE, int VEC>
 static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, const float *selfq,
                                           float *out, int w, float eps, hipStream_t s)
 {
@@ -1210,33 +1105,17 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
     const size_t budget = (size_t)(o.agg_lds_kb > 0 ? std::min(std::max(o.agg_lds_kb, 8), 158) : 158 / wgs) * 1024;
     int ns = std::min(std::max(o.agg_ring_slots, 1), RING_MAX_SLOTS);
     int nw = o.agg_ring_waves;
-    int cap;
-    if (COOP) {
-        // one ring per workgroup: stages as large as the budget allows (whole graphs of a few hundred nodes fit)
-        if (nw <= 0)
-            nw = 16; // (measured: 16 waves issue a stage's DMA and drain its stores faster than 8)
-        nw = std::min(std::max(nw, 1), 16);
-        cap = (int)((budget / ns) / per_row);
-    } else {
-        // one ring per wave.  A stage must hold a whole tile = up to tile_rows - 1 rows of slack + one graph; with
-        // the caller's promise the bound is known, otherwise aim at molecule-sized graphs
-        const int want = t.max_graph_nodes_hint > 0 ? t.tile_rows - 1 + t.max_graph_nodes_hint : 36;
-        auto cap_of = [&](int nw_, int ns_) { return (int)((budget / nw_ / ns_) / per_row); };
-        if (nw <= 0) { // automatic: the most waves (8, 4, 2, 1) whose stages still hold `want` rows
-            nw = 8;
-            ns = 1;
-            while (nw > 1 && cap_of(nw, ns) < want)
-                nw >>= 1;
-        }
-        nw = std::min(std::max(nw, 1), 8);
-        cap = cap_of(nw, ns);
-    }
+    // one ring per workgroup: stages as large as the budget allows
+    if (nw <= 0)
+        nw = 16; // (measured: 16 waves issue a stage's DMA and drain its stores faster than 8)
+    nw = std::min(std::max(nw, 1), 16);
+    int cap = (int)((budget / ns) / per_row);
     cap = std::min(std::max(cap, 1), 4096);
     const int slot_bytes = (int)((((size_t)cap * per_row) + 15) & ~(size_t)15);
-    const size_t lds = (size_t)(COOP ? 1 : nw) * ns * slot_bytes;
+    const size_t lds = (size_t)ns * slot_bytes;
     // persistent: `wgs` workgroups per CU; fewer when the batch has fewer tiles than rings
     int grid = num_cus * wgs;
-    grid = std::min(grid, COOP ? t.num_tiles : (t.num_tiles + nw - 1) / nw);
+    grid = std::min(grid, t.num_tiles);
     if (grid < 1)
         grid = 1;
     auto launch = [&](auto kern) -> hipError_t {
@@ -1251,8 +1130,8 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
         return hipGetLastError();
     };
     if (o.agg_nt_store)
-        return launch(k_aggregate_ring<MODE, VEC, true, COOP>);
-    return launch(k_aggregate_ring<MODE, VEC, false, COOP>);
+        return launch(k_aggregate_ring<MODE, VEC, true>);
+    return launch(k_aggregate_ring<MODE, VEC, false>);
 }
 
 // -------------------------------------------------------------------------------------
@@ -1316,17 +1195,10 @@ hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, cons
 {
     const bool v4 = (width % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0) &&
                     (selfq == nullptr || ((uintptr_t)selfq & 15) == 0);
-    const bool shot = options().agg_variant == 1, perwave = options().agg_variant == 2;
 #define GNNB_AGG_CASE(K)                                                                         \
     case K:                                                                                      \
-        if (shot)                                                                                \
-            return v4 ? launch_aggregate_shot_t<K, 4>(t, x, selfq, out, width, eps, s)           \
-                      : launch_aggregate_shot_t<K, 1>(t, x, selfq, out, width, eps, s);          \
-        if (perwave)                                                                             \
-            return v4 ? launch_aggregate_ring_t<K, 4, false>(t, x, selfq, out, width, eps, s)    \
-                      : launch_aggregate_ring_t<K, 1, false>(t, x, selfq, out, width, eps, s);   \
-        return v4 ? launch_aggregate_ring_t<K, 4, true>(t, x, selfq, out, width, eps, s)         \
-                  : launch_aggregate_ring_t<K, 1, true>(t, x, selfq, out, width, eps, s);
+        return v4 ? launch_aggregate_ring_t<K, 4>(t, x, selfq, out, width, eps, s)               \
+                  : launch_aggregate_ring_t<K, 1>(t, x, selfq, out, width, eps, s);
     switch (kind) {
         GNNB_AGG_CASE(GNNB_AGG_GCN)
         GNNB_AGG_CASE(GNNB_AGG_SUM)

@@ -52,8 +52,7 @@ static int env_int(const char *name, int dflt)
 Options &options()
 {
     static Options o = {env_int("GNNB_TILE_ROWS", 8), env_int("GNNB_AGG_LDS_KB", 0),
-                        env_int("GNNB_AGG_TILES_PER_WG", 1),  env_int("GNNB_AGG_VARIANT", 0),
-                        env_int("GNNB_AGG_RING_WAVES", 0),    env_int("GNNB_AGG_RING_SLOTS", 2),
+                                                env_int("GNNB_AGG_RING_WAVES", 0),    env_int("GNNB_AGG_RING_SLOTS", 2),
                         env_int("GNNB_AGG_RING_WG_PER_CU", 1), env_int("GNNB_AGG_NT_STORE", 1),
                         env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_GEMM_DMA", 1),
@@ -199,10 +198,6 @@ int gnnb_set_option(const char *name, int value)
         o.tile_rows = value;
     else if (!strcmp(name, "agg_lds_kb") && value >= 0 && value <= 160)
         o.agg_lds_kb = value; // 0 = default of the selected form
-    else if (!strcmp(name, "agg_tiles_per_wg") && value >= 1)
-        o.agg_tiles_per_wg = value;
-    else if (!strcmp(name, "agg_variant") && value >= 0 && value <= 2)
-        o.agg_variant = value;
     else if (!strcmp(name, "agg_ring_waves") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16))
         o.agg_ring_waves = value;
     else if (!strcmp(name, "agg_ring_slots") && value >= 1 && value <= 4)

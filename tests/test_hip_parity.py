@@ -147,13 +147,13 @@ def test_weight_free_convs_match_reference_golden(dev, kind, golden):
     cm.graph_prep(cood, nptr, eptr, G.N)
     want = G.f32(golden).reshape(G.N, 8)
     try:
-        for variant in (0, 1):
-            runtime.set_option("agg_variant", variant)
+        for waves in (0, 2):
+            runtime.set_option("agg_ring_waves", waves)
             got = cm.aggregate(kind, xd).cpu().numpy()
-            assert np.abs(got - want).max() < 2e-6, (kind, variant)
+            assert np.abs(got - want).max() < 2e-6, (kind, waves)
             assert np.abs(got - O.conv(kind, x, coo, [])).max() < 2e-6
     finally:
-        runtime.set_option("agg_variant", 0)
+        runtime.set_option("agg_ring_waves", 0)
 
 
 def test_gine_conv_matches_reference_golden(dev):
@@ -210,14 +210,15 @@ def test_weight_free_convs_on_degenerate_and_large_graphs(dev):
     for kind in ("simple", "lg"):
         ref = np.concatenate([O.conv(kind, *both.graph(g), []) for g in range(both.num_graphs) if both.graph(g)[0].shape[0]])
         try:
-            for opts in (dict(), dict(agg_lds_kb=8), dict(agg_variant=1)):
+            for opts in (dict(), dict(agg_lds_kb=8), dict(agg_ring_waves=2, agg_ring_slots=3)):
                 for k, v in opts.items():
                     runtime.set_option(k, v)
                 got = cm.aggregate(kind, xd).cpu().numpy()
                 assert np.abs(got - ref).max() < 2e-6, (kind, opts)
         finally:
             runtime.set_option("agg_lds_kb", 0)
-            runtime.set_option("agg_variant", 0)
+            runtime.set_option("agg_ring_waves", 0)
+            runtime.set_option("agg_ring_slots", 2)
     assert torch.equal(cm.aggregate("copy", xd), xd)
 
 
@@ -494,19 +495,14 @@ def test_full_size_config2_properties(dev):
 
 
 AGG_OPTION_SETS = [
-    # ring forms: 0 = one ring per workgroup (cooperative, default), 2 = one ring per wave.  Waves per workgroup,
-    # stages per ring, LDS budget (small budgets push tiles to the direct path), tile granularity, workgroups per CU,
-    # non-temporal stores
-    dict(agg_variant=2), dict(agg_variant=2, agg_ring_waves=1), dict(agg_variant=2, agg_ring_waves=4, agg_ring_slots=2),
-    dict(agg_variant=2, agg_lds_kb=8), dict(agg_variant=2, agg_ring_slots=3, agg_ring_waves=2, tile_rows=4),
-    dict(), dict(agg_ring_waves=1), dict(agg_ring_waves=2), dict(agg_ring_waves=4), dict(agg_ring_waves=16),
+    # launch geometries of the ring-form gather-aggregate kernel: waves per workgroup, stages in the ring, LDS budget
+    # (small budgets push tiles to the direct-from-L2 path and make the ring cycle), tile granularity, workgroups per CU,
+    # plain / non-temporal stores
+    dict(), dict(agg_ring_waves=1), dict(agg_ring_waves=2), dict(agg_ring_waves=4), dict(agg_ring_waves=8),
     dict(agg_ring_slots=1), dict(agg_ring_slots=3), dict(agg_ring_slots=4, agg_ring_waves=2),
     dict(agg_lds_kb=8), dict(agg_lds_kb=24, agg_ring_waves=4), dict(agg_lds_kb=150, agg_ring_waves=1, agg_ring_slots=1),
-    dict(tile_rows=4), dict(tile_rows=8, agg_ring_slots=3), dict(tile_rows=64), dict(agg_ring_wg_per_cu=2, agg_lds_kb=64),
-    dict(agg_nt_store=1), dict(agg_nt_store=1, agg_ring_waves=2, tile_rows=4),
-    # one-shot form
-    dict(agg_variant=1), dict(agg_variant=1, agg_lds_kb=8), dict(agg_variant=1, tile_rows=64, agg_tiles_per_wg=2),
-    dict(agg_variant=1, agg_lds_kb=150, agg_tiles_per_wg=3), dict(agg_variant=1, tile_rows=4),
+    dict(tile_rows=4), dict(tile_rows=16, agg_ring_slots=3), dict(tile_rows=64), dict(agg_ring_wg_per_cu=2),
+    dict(agg_ring_wg_per_cu=4, agg_ring_waves=4, agg_lds_kb=20), dict(agg_nt_store=0), dict(agg_nt_store=0, agg_ring_waves=2, tile_rows=4),
 ]
 
 
@@ -522,8 +518,7 @@ def _tiling_case(dev, opt, conv):
     model = make_model(conv, in_dim=9, hidden=48 if conv == "gcn" else 32, layers=3, task_out=1)  # (GCN: wide enough for the aggregate kernel)
     batch = synthetic.make_batch("molhiv", 64, seed=11)
     ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
-    defaults = dict(tile_rows=16, agg_tiles_per_wg=1, agg_lds_kb=0, agg_variant=0, agg_ring_waves=0, agg_ring_slots=2,
-                    agg_ring_wg_per_cu=1, agg_nt_store=0)
+    defaults = dict(tile_rows=8, agg_lds_kb=0, agg_ring_waves=0, agg_ring_slots=2, agg_ring_wg_per_cu=1, agg_nt_store=1)
     try:
         for k, v in opt.items():
             runtime.set_option(k, v)

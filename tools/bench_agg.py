@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--kind", default="gcn")
-    ap.add_argument("--sets", default="", help='JSON list of option dicts, e.g. [{"agg_variant":0,"agg_ring_waves":2}]')
+    ap.add_argument("--sets", default="", help='JSON list of option dicts, e.g. [{"agg_ring_waves":8}]')
     args = ap.parse_args()
     w = bench.WORKLOADS[args.workload]
     width = args.width or w["hidden"]
@@ -33,15 +33,10 @@ def main():
     batch = synthetic.make_batch(w["shape"], w["batch"], seed=0)
     cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
     bd = tuple(torch.from_numpy(a).to(dev) for a in (batch.x, batch.coo, batch.node_ptr, batch.edge_ptr))
-    defaults = dict(tile_rows=8, agg_tiles_per_wg=1, agg_lds_kb=0, agg_variant=0, agg_ring_waves=0, agg_ring_slots=2,
-                    agg_ring_wg_per_cu=1, agg_nt_store=1)
+    defaults = dict(tile_rows=8, agg_lds_kb=0, agg_ring_waves=0, agg_ring_slots=2, agg_ring_wg_per_cu=1, agg_nt_store=1)
     sets = json.loads(args.sets) if args.sets else (
-        [{"agg_variant": 1, "tile_rows": 16}, {"agg_variant": 2}, {}, {"agg_nt_store": 0},
-         {"agg_ring_waves": 4}, {"agg_ring_waves": 16}, {"agg_ring_slots": 3}, {"agg_ring_slots": 4},
-         {"agg_ring_waves": 16, "agg_ring_slots": 3}, {"agg_ring_waves": 16, "agg_ring_slots": 4},
-         {"agg_ring_wg_per_cu": 2}, {"agg_ring_wg_per_cu": 2, "agg_ring_waves": 4},
-         {"agg_ring_wg_per_cu": 2, "agg_ring_slots": 3}, {"agg_ring_wg_per_cu": 3, "agg_ring_waves": 4},
-         {"agg_ring_wg_per_cu": 4, "agg_ring_waves": 4}, {"tile_rows": 4}, {"tile_rows": 16}])
+        [{}, {"agg_nt_store": 0}, {"agg_ring_waves": 8}, {"agg_ring_waves": 4}, {"agg_ring_slots": 3}, {"agg_ring_slots": 4},
+         {"agg_ring_wg_per_cu": 2}, {"agg_ring_wg_per_cu": 2, "agg_ring_waves": 8}, {"tile_rows": 4}, {"tile_rows": 16}])
     for opts in sets:
         for k, v in {**defaults, **opts}.items():
             runtime.set_option(k, v)
