@@ -300,14 +300,14 @@ class GlobalPooling(nn.Module):
         self.aggrs = aggrs
         self.mode = mode
         if aggrs == []:
-            raise ValueError("Aggregation list is empty.")
+            raise ValueError("GlobalPooling needs at least one aggregation (add / mean / max)")
         for a in self.aggrs:
             if a not in SUPPORTED_GLOBAL_POOLING_AGGRS:
                 raise NotImplementedError(
-                    f"Aggregation {a} is not supported. Supported aggregations are {SUPPORTED_GLOBAL_POOLING_AGGRS}.")
+                    f"unknown pooling aggregation {a!r}; choose from {SUPPORTED_GLOBAL_POOLING_AGGRS}")
         if self.mode not in SUPPORTED_GLOBAL_POOLING_MODE:
             raise NotImplementedError(
-                f"Mode {self.mode} is not supported. Supported modes are {SUPPORTED_GLOBAL_POOLING_MODE}.")
+                f"unknown pooling mode {self.mode!r}; choose from {SUPPORTED_GLOBAL_POOLING_MODE}")
 
     def forward(self, x: Tensor, index: Optional[Tensor] = None, dim_size: Optional[int] = None) -> Tensor:
         if index is None:  # one graph: [N, d] -> [1, k*d]
@@ -356,11 +356,11 @@ class MLP(nn.Module):
         self.activation = activation
         self.norm_layer = norm_layer
         if self.activation not in SUPPORTED_ACTIVATIONS:
-            raise ValueError(f"activation {activation} not supported")
+            raise ValueError(f"MLP activation must be one of {SUPPORTED_ACTIVATIONS}, got {activation}")
         if self.norm_layer is not None:
-            raise NotImplementedError("norm not supported yet")
+            raise NotImplementedError("MLP norm_layer: no normalisation layer has a native path (the reference has none either)")
         if hidden_layers < 0:
-            raise ValueError("hidden_layers must be >= 0")
+            raise ValueError(f"MLP hidden_layers cannot be negative (got {hidden_layers})")
         self.p_in = p_in
         self.p_hidden = p_hidden
         self.p_out = p_out
@@ -418,10 +418,10 @@ class GNNModel(nn.Module):
         self.gnn_output_dim = gnn_output_dim
         self.gnn_conv = gnn_conv
         if self.gnn_conv not in SUPPORTED_GNN_CONVS:
-            raise ValueError(f"gnn_conv must be one of {SUPPORTED_GNN_CONVS}")
+            raise ValueError(f"gnn_conv {gnn_conv} is not a *_GNNB conv class of this package: {SUPPORTED_GNN_CONVS}")
         self.gnn_activation = gnn_activation
         if self.gnn_activation not in SUPPORTED_ACTIVATIONS:
-            raise ValueError(f"gnn_activation must be one of {SUPPORTED_ACTIVATIONS}")
+            raise ValueError(f"gnn_activation {gnn_activation} has no native kernel; choose from {SUPPORTED_ACTIVATIONS}")
         self.gnn_skip_connection = gnn_skip_connection
 
         self.global_pooling = global_pooling
@@ -440,8 +440,8 @@ class GNNModel(nn.Module):
         L = self.gnn_num_layers
         if L == 0 and self.graph_input_feature_dim != self.gnn_output_dim:
             raise ValueError(
-                f"You specified gnn_num_layers=0, but (gnn_output_dim={self.gnn_output_dim}) !="
-                f" (graph_input_feature_dim={self.graph_input_feature_dim}).")
+                f"a model without conv layers passes the node features straight to the pooling: gnn_output_dim "
+                f"({self.gnn_output_dim}) must equal graph_input_feature_dim ({self.graph_input_feature_dim})")
         for i in range(L):
             if L == 1:
                 dims = (self.graph_input_feature_dim, self.gnn_output_dim, self.gnn_p_in, self.gnn_p_out)

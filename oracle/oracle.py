@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-ORACLE_SO = HERE / "libgnnb_oracle.so"
+ORACLE_SO = Path(os.environ.get("GNNB_ORACLE_SO", HERE / "libgnnb_oracle.so"))  # (override: the sanitizer build of the tests)
 REF_SO = HERE / "_ref" / "libgnnb_ref.so"
 
 CONV = {"gcn": 0, "gin": 1, "sage": 2, "pna": 3}
