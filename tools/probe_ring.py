@@ -53,3 +53,33 @@ for e in range(nev):
     print(f"  ev{e:2d} {names[int(np.median(code)) // 1000000]:8s} rows {np.median(code % 1000000):5.0f}   t = {np.median(t):6.2f} us (p10 {np.percentile(t, 10):6.2f}, p90 {np.percentile(t, 90):6.2f})")
 end = np.array([r[2 + 2 * (int(r[1]) - 1)] for r in a]) - t0
 print(f"last event: median {np.median(end) / 100:.2f} us, max {end.max() / 100:.2f} us")
+ends = np.array([r[2 + 2 * (int(r[1]) - 1)] for r in a]) - t0
+starts = a[:, 0] - t0
+idx = np.arange(a.shape[0])
+for xcd in range(8):
+    m = idx % 8 == xcd
+    print(f"  xcd {xcd}: start median {np.median(starts[m]) / 100:.2f}, end median {np.median(ends[m]) / 100:.2f} max {ends[m].max() / 100:.2f} us")
+order = np.argsort(ends)[-12:]
+print("  latest workgroups:", [(int(i), round(float(ends[i]) / 100, 2)) for i in order])
+for i in order[-4:]:
+    r = a[i]
+    print(f"  wg {int(i)}: {int(r[1])} events:", [(names[int(r[3 + 2 * e]) // 1000000][:3], int(r[3 + 2 * e]) % 1000000, round(float(r[2 + 2 * e] - t0) / 100, 2)) for e in range(int(r[1]))])
+# per-workgroup work (rows, edges, rows of degree > 4) against its end time
+TR = 8
+ntiles = (batch.num_nodes + TR - 1) // TR
+nptr_h, eptr_h = batch.node_ptr.astype(np.int64), batch.edge_ptr.astype(np.int64)
+tf = nptr_h[np.searchsorted(nptr_h, np.arange(ntiles + 1) * TR, side="left").clip(max=len(nptr_h) - 1)]
+tf[-1] = batch.num_nodes
+gidx = np.searchsorted(nptr_h, tf, side="left")
+te = eptr_h[gidx.clip(max=len(eptr_h) - 1)]
+deg = np.bincount(batch.coo[:, 1] if kind != "x" else batch.coo[:, 0], minlength=batch.num_nodes)
+nwg = a.shape[0]
+wt0 = (np.arange(nwg) * ntiles) // nwg
+wt1 = ((np.arange(nwg) + 1) * ntiles) // nwg
+rows = tf[wt1] - tf[wt0]
+edges = te[wt1] - te[wt0]
+cdeg = np.concatenate([[0], np.cumsum(deg > 4)])
+big = cdeg[tf[wt1]] - cdeg[tf[wt0]]
+print(f"  rows/wg {rows.min()}..{rows.max()}, edges/wg {edges.min()}..{edges.max()}, deg>4 rows/wg {big.min()}..{big.max()}")
+for nm, v in (("rows", rows), ("edges", edges), ("deg>4", big), ("wg index", idx)):
+    print(f"  corr(end, {nm}) = {np.corrcoef(ends, v)[0, 1]:.2f}")
