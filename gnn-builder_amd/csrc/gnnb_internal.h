@@ -57,6 +57,7 @@ struct Options {
     int math;          // 0 = fp32 MFMA everywhere (default); 1 = the wide update of the fused GCN stack and the
                        //     K <= 128 GEMMs as six bf16 MFMA products of an exact 3-way split of both operands
                        //     (fp32-equivalent, opt-in)
+    int gemm_tail_split; // 1 = k_linear_dma hands the last, partial round of tiles out as row slices (default)
 };
 Options &options();
 

@@ -599,6 +599,15 @@ __device__ inline void dma16_to_lds_u(const void *gsrc_lane, void *lds_wave_base
     const uint32_t a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_vptr)lds_wave_base);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(gsrc_lane) : "memory");
 }
+// scalar-base form: address = wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset; the LDS
+// destination is a wave-uniform LDS byte address.  Keeps a streaming kernel's per-chunk address arithmetic on the
+// scalar unit (fp32 MFMA and VALU instructions share one issue port).
+__device__ inline void dma16_to_lds_s(const void *gbase_uniform, uint32_t lane_byte_off, uint32_t lds_addr_uniform)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr_uniform), "v"(lane_byte_off),
+                 "s"(gbase_uniform)
+                 : "memory");
+}
 __device__ inline void dma4_to_lds_u(const void *gsrc_lane, void *lds_wave_base)
 {
     const uint32_t a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_vptr)lds_wave_base);
@@ -1448,38 +1457,61 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 // LDS-DMA form of the tiled GEMM above for the regular case -- rows 16-B aligned, segment widths whole
 // 32-wide chunks (GraphSAGE at d = 256: [mean | x] . [Wl | Wr]^T, K = 2 x 256; PNA at d = 128: 13 x 128 with
 // two row-scaled segments, the scaler applied to the A fragments).
-// Same 128 x 128 workgroup tile and 32x32x2 MFMA schedule, but the A and W chunks go global -> LDS
-// directly (untracked global_load_lds, no VGPR staging, no ds_write): each wave issues eight 1-KB
-// DMA instructions per chunk, the next chunk's while the matrix cores work on the current one.  LDS rows are
-// unpadded [row][32 floats]; 16-B pieces are XOR-swizzled through the DMA *source* address
-// (slot = piece ^ (row & 7)), which keeps the ds_read_b128 fragment reads conflict-free.
-__global__ __launch_bounds__(WG) void k_linear_dma(GemmArgs g, const float *__restrict__ W, int ldw,
-                                                   const float *__restrict__ bias,
-                                                   const float *__restrict__ skip, float *__restrict__ Y, int M,
-                                                   int N, int act, int tiles_m, int tiles_n)
+// Same 32x32x2 MFMA schedule (and summation order) as k_linear, but the A and W chunks go global -> LDS directly
+// (untracked global_load_lds, no VGPR staging, no ds_write).  LDS rows are unpadded [row][32 floats]; 16-B pieces
+// are XOR-swizzled through the DMA *source* address (slot = piece ^ (row & 7)), which keeps the ds_read_b128
+// fragment reads conflict-free.
+//
+// Shape: two 4-wave workgroups per CU (they fill each other's barrier gaps: ONE 8-wave workgroup with a 256 x 128
+// tile and a three-deep chunk ring was built and measured -- 696 vs 600 us at the C4 shape, every barrier idles
+// the whole CU), 128 x 128 output tile, two chunk buffers.  Measured: without its chunk DMA the kernel runs at 84 %
+// of the fp32 MFMA peak, with it at 65 %: a chunk requested one chunk ahead lands late (A comes from HBM, one
+// 128-B line per row and chunk) -- see the note on compiler-tracked loads in the item body.
+static constexpr int DM = 128, DN = 128, DWG = 256, DNBUF = 2, DNW = DWG / 64;
+static constexpr int DBUF_B = (DM + DN) * BK * 4; // 32 KB: A chunk | W chunk
+__global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__restrict__ W, int ldw,
+                                                    const float *__restrict__ bias,
+                                                    const float *__restrict__ skip, float *__restrict__ Y, int M,
+                                                    int N, int act, int tiles_m, int tiles_n, int split_from, int split)
 {
-    constexpr int NT = 2, BN = 64 * NT;
+    constexpr int NT = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE_B = BM * BK * 4; // 16 KB: one operand chunk
-    // [2 buffers][A chunk | W chunk]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1; // 2 x 2 waves: 64 rows x 64 columns each
     const int total = g.cpre[g.nseg];
     const int li = lane & 31, lh = lane >> 5;
-    // PERSISTENT over output tiles (grid = what is resident): the chunk pipeline runs straight across tile
-    // boundaries -- the first chunk of the next tile is requested before the last chunk of this one is multiplied,
-    // so its latency and this tile's epilogue overlap (a short-lived workgroup per tile exposed one HBM latency per
-    // 16 chunks at K = 512).  Tiles sharing a row block are adjacent in the order (their A chunks hit in L2).
-    const int num_tiles = tiles_m * tiles_n;
-    // (measured: remapping block ids so that each XCD owns a contiguous run of tiles -- the two column tiles of a row
-    // block sharing one L2 -- is SLOWER here, 601 vs 573 us at the C5 shape: round-robin order spreads the rows that
-    // are in flight at one time over all HBM channels)
-    int tile = blockIdx.x;
-    if (tile >= num_tiles)
-        return;
+    const uint32_t smem_a = (uint32_t)(uintptr_t)(lds_vptr)smem;
+    // DMA lane geometry: an instruction covers 8 rows x eight 16-B pieces; LDS slot p of row r holds piece p ^ (r & 7)
+    const int drow = lane >> 3;
+    const uint32_t dpiece_b = (uint32_t)(((lane & 7) ^ drow) << 4);
 
-    auto issue = [&](int t, int c, int buf) {
-        const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    // PERSISTENT over work items (grid = what is resident: two workgroups per CU); the chunk pipeline runs straight
+    // across item boundaries.  TAIL SPLIT: tiles / CUs is rarely whole (PNA at C4: 1153 tiles on 256 CUs = 4.5 per CU,
+    // paid as 5).  Tiles from `split_from` on -- the last, partial round -- are handed out as `split` (2 or 4) row
+    // slices each, so that the round costs a half or a quarter tile.  A slice keeps the tile's MFMA order per output
+    // element: 64 rows = one 32-row accumulator block per wave instead of two, 32 rows = the same on half of the waves.
+    const int num_tiles = tiles_m * tiles_n;
+    const int num_items = split_from + split * (num_tiles - split_from);
+    if ((int)blockIdx.x >= num_items)
+        return;
+    auto decode = [&](int it, int &m0, int &n0, int &mrows) {
+        const bool part = it >= split_from;
+        const int j = it - split_from;
+        const int t = part ? split_from + j / split : it;
+        mrows = part ? DM / split : DM;
+        m0 = (t / tiles_n) * DM + (part ? (j % split) * mrows : 0);
+        n0 = (t % tiles_n) * DN;
+    };
+
+    // issue cursor: runs two chunks ahead of the multiply cursor, across item boundaries
+    int iss_item = blockIdx.x, iss_c = 0, iss_buf = 0;
+    int vm = 0; // vector-memory instructions this wave has issued (DMA + epilogue stores): for the counted waits
+    auto issue_next = [&]() -> int { // returns vm after the chunk's DMA (its "mark"), or -1 when nothing is left
+        if (iss_item >= num_items)
+            return -1;
+        int m0, n0, mrows;
+        decode(iss_item, m0, n0, mrows);
+        const int c = iss_c;
         // segment lookup with static indexing only (keeps the kernarg struct out of scratch)
         const float *ap = g.a[0];
         int lda = g.lda[0], koff = g.koff[0], cbase = 0;
@@ -1493,102 +1525,154 @@ __global__ __launch_bounds__(WG) void k_linear_dma(GemmArgs g, const float *__re
             }
         }
         const int kk = (c - cbase) * BK;
-        char *abase = smem + (size_t)buf * 2 * TILE_B, *wbase = abase + TILE_B;
+        // scalar bases (tile origin, clamped into the matrix) + per-lane 32-bit offsets: the address arithmetic stays
+        // on the scalar unit
+#ifdef GNNB_EXP_SAMECHUNK
+        const int m0c = 128 * (blockIdx.x & 255), n0c = min(n0, N - 1);
+        const float *ga = ap + (size_t)m0c * lda + (kk & 31);
+#else
+        const int m0c = min(m0, M - 1), n0c = min(n0, N - 1);
+        const float *ga = ap + (size_t)m0c * lda + kk;
+#endif
+        const float *gw = W + (size_t)n0c * ldw + koff + kk;
+        const int ra_max = M - 1 - m0c, rw_max = N - 1 - n0c; // rows past M / N re-read the last valid row (never stored)
+        const uint32_t la = smem_a + (uint32_t)iss_buf * DBUF_B, lw = la + DM * BK * 4;
+        const uint32_t lda_b = (uint32_t)lda * 4, ldw_b = (uint32_t)ldw * 4;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int L0 = (wave * 4 + i) * 64; // piece index of lane 0: 8 rows x 8 pieces per instruction
-            const int L = L0 + lane, row = L >> 3, piece = (L & 7) ^ (row & 7);
-            // rows past M / N re-read the last valid row (never stored)
-            const int ra = min(m0 + row, M - 1), rw = min(n0 + row, N - 1);
-            dma16_to_lds_u(ap + (size_t)ra * lda + kk + piece * 4, abase + (size_t)L0 * 16);
-            dma16_to_lds_u(W + (size_t)rw * ldw + koff + kk + piece * 4, wbase + (size_t)L0 * 16);
+        for (int i = 0; i < DM / 8 / DNW; i++) { // A: DM / 8 instructions per chunk
+            const int r0 = (wave * (DM / 8 / DNW) + i) * 8;
+            if (r0 < mrows) {
+                dma16_to_lds_s(ga, (uint32_t)min(r0 + drow, ra_max) * lda_b + dpiece_b, la + (uint32_t)r0 * 128);
+                vm++;
+            }
         }
+#pragma unroll
+        for (int i = 0; i < DN / 8 / DNW; i++) { // W: DN / 8 instructions per chunk
+            const int r0 = (wave * (DN / 8 / DNW) + i) * 8;
+            dma16_to_lds_s(gw, (uint32_t)min(r0 + drow, rw_max) * ldw_b + dpiece_b, lw + (uint32_t)r0 * 128);
+            vm++;
+        }
+        iss_buf = iss_buf + 1 == DNBUF ? 0 : iss_buf + 1;
+        if (++iss_c == total) {
+            iss_c = 0;
+            iss_item += gridDim.x;
+        }
+        return vm;
     };
 
-    issue(tile, 0, 0);
+    // marks of the chunks in flight (DNBUF - 1 of them): mk0 = the chunk multiplied next, mk1 = the one after it
+    int mk0 = issue_next(), mk1 = DNBUF > 2 ? issue_next() : -1;
     int buf = 0;
-    for (; tile < num_tiles; tile += gridDim.x) {
-        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-        const int next_tile = tile + gridDim.x;
-        f32x16 acc[2][NT];
+    const bool vec = (N % 4 == 0) && (((uintptr_t)Y & 15) == 0) && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
+                     (skip == nullptr || ((uintptr_t)skip & 15) == 0);
+
+    // one work item with MC 32-row accumulator blocks per wave (2 = whole tile, 1 = a slice, 0 = a wave that only
+    // keeps the chunk pipeline going).  A compile-time MC: with a run-time block count the accumulators of the
+    // conditional block leave the AGPRs at every loop header.
+    auto run_item = [&](auto mtag, int m0, int n0, int rbase) {
+        constexpr int MC = decltype(mtag)::value;
+        f32x16 acc[MC > 0 ? MC : 1][NT];
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++)
+        for (int mi = 0; mi < (MC > 0 ? MC : 1); mi++)
 #pragma unroll
             for (int ni = 0; ni < NT; ni++)
 #pragma unroll
                 for (int i = 0; i < 16; i++)
                     acc[mi][ni][i] = 0.0f;
 
-        // per-row scalers of the scaled segments (PNA: amp . A, att . A), fetched once per tile for the lane's two A rows
-        float sc[4][2];
+        // per-row scalers of the scaled segments (PNA: amp . A, att . A), fetched once per item for the lane's A rows
+        float sc[4][MC > 0 ? MC : 1];
+        if (MC > 0) {
 #pragma unroll
-        for (int sgm = 0; sgm < 4; sgm++)
+            for (int sgm = 0; sgm < 4; sgm++)
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                const int row = min(m0 + wm * 64 + mi * 32 + li, M - 1);
-                sc[sgm][mi] = (sgm < g.nseg && g.rs[sgm] != nullptr) ? g.rs[sgm][row] : 1.0f;
-            }
-
-        for (int c = 0; c < total; c++, buf ^= 1) {
-            // this chunk has landed (it was issued a whole chunk of MFMAs ago) for everyone, and everyone is done
-            // reading the other buffer
-            dma_wait_all();
-            __syncthreads();
-            if (c + 1 < total)
-                issue(tile, c + 1, buf ^ 1);
-            else if (next_tile < num_tiles)
-                issue(next_tile, 0, buf ^ 1);
-            float s0 = sc[0][0], s1 = sc[0][1]; // this chunk's segment (uniform), static indexing
-            bool scaled = g.rs[0] != nullptr;
-#pragma unroll
-            for (int sgm = 1; sgm < 4; sgm++)
-                if (sgm < g.nseg && c >= g.cpre[sgm]) {
-                    s0 = sc[sgm][0];
-                    s1 = sc[sgm][1];
-                    scaled = g.rs[sgm] != nullptr;
+                for (int mi = 0; mi < MC; mi++) {
+                    const int row = min(m0 + rbase + mi * 32 + li, M - 1);
+                    sc[sgm][mi] = (sgm < g.nseg && g.rs[sgm] != nullptr) ? g.rs[sgm][row] : 1.0f;
                 }
-            const float *a = reinterpret_cast<const float *>(smem + (size_t)buf * 2 * TILE_B);
-            const float *b = reinterpret_cast<const float *>(smem + (size_t)buf * 2 * TILE_B + TILE_B);
+            // these are loads the compiler tracks: left pending, their first use INSIDE the chunk loop is guarded by
+            // s_waitcnt vmcnt(0) in every iteration -- which also waits for the chunk DMA just issued, i.e. serialises
+            // "request the next chunk" and "multiply this one" (found in round 2: the kernel had been running that
+            // way).  Consumed here, once per item; the chunk loop then has no tracked load in flight.
 #pragma unroll
-            for (int kb = 0; kb < BK; kb += 8) {
-                float4 fa[2], fb[NT];
-                const int piece = (kb >> 2) + lh; // 16-B piece holding k = kb + 4 lh .. + 3
+            for (int sgm = 0; sgm < 4; sgm++)
 #pragma unroll
-                for (int mi = 0; mi < 2; mi++) {
-                    const int r = wm * 64 + mi * 32 + li;
-                    fa[mi] = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
-                }
-                if (scaled) { // the row scaler multiplies the A operand, as in the register-staged kernel
-                    fa[0].x *= s0, fa[0].y *= s0, fa[0].z *= s0, fa[0].w *= s0;
-                    fa[1].x *= s1, fa[1].y *= s1, fa[1].z *= s1, fa[1].w *= s1;
-                }
-#pragma unroll
-                for (int ni = 0; ni < NT; ni++) {
-                    const int r = wn * 32 * NT + ni * 32 + li;
-                    fb[ni] = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
-                }
-                // operands SWAPPED (W fragment first): the 32x32 accumulator then holds, per lane, FOUR CONSECUTIVE
-                // output columns of one row per register group -- the epilogue stores float4 instead of scalars
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                    for (int ni = 0; ni < NT; ni++) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].x, fa[mi].x, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].y, fa[mi].y, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].z, fa[mi].z, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa[mi].w, acc[mi][ni], 0, 0, 0);
-                    }
-            }
+                for (int mi = 0; mi < MC; mi++)
+                    asm volatile("" : "+v"(sc[sgm][mi]));
         }
 
+        for (int c = 0; c < total; c++) {
+            // this chunk has landed for this wave when at most the operations issued after it are outstanding (VM
+            // operations retire in order; loads the compiler tracks itself only make the wait stricter) ...
+            vmcnt_wait_n(min(vm - mk0, 63));
+            __syncthreads(); // ... and for everyone; and everyone is done reading the buffer refilled next
+#ifndef GNNB_EXP_NODMA
+            if (DNBUF > 2) {
+                mk0 = mk1;
+                mk1 = issue_next();
+            } else {
+                mk0 = issue_next();
+            }
+#endif
+            const float *a = reinterpret_cast<const float *>(smem + (size_t)buf * DBUF_B);
+            const float *b = reinterpret_cast<const float *>(smem + (size_t)buf * DBUF_B + DM * BK * 4);
+            buf = buf + 1 == DNBUF ? 0 : buf + 1;
+            if (MC > 0) {
+                float s[MC > 0 ? MC : 1]; // this chunk's segment (uniform), static indexing
+                bool scaled = g.rs[0] != nullptr;
+#pragma unroll
+                for (int mi = 0; mi < MC; mi++)
+                    s[mi] = sc[0][mi];
+#pragma unroll
+                for (int sgm = 1; sgm < 4; sgm++)
+                    if (sgm < g.nseg && c >= g.cpre[sgm]) {
+#pragma unroll
+                        for (int mi = 0; mi < MC; mi++)
+                            s[mi] = sc[sgm][mi];
+                        scaled = g.rs[sgm] != nullptr;
+                    }
+#pragma unroll
+                for (int kb = 0; kb < BK; kb += 8) {
+                    float4 fa[MC > 0 ? MC : 1], fb[NT];
+                    const int piece = (kb >> 2) + lh; // 16-B piece holding k = kb + 4 lh .. + 3
+#pragma unroll
+                    for (int mi = 0; mi < MC; mi++) {
+                        const int r = rbase + mi * 32 + li;
+                        fa[mi] = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
+                    }
+                    if (scaled) { // the row scaler multiplies the A operand, as in the register-staged kernel
+#pragma unroll
+                        for (int mi = 0; mi < MC; mi++)
+                            fa[mi].x *= s[mi], fa[mi].y *= s[mi], fa[mi].z *= s[mi], fa[mi].w *= s[mi];
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NT; ni++) {
+                        const int r = wn * 32 * NT + ni * 32 + li;
+                        fb[ni] = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
+                    }
+                    // operands SWAPPED (W fragment first): the 32x32 accumulator then holds, per lane, FOUR
+                    // CONSECUTIVE output columns of one row per register group -- the epilogue stores float4
+#pragma unroll
+                    for (int mi = 0; mi < MC; mi++)
+#pragma unroll
+                        for (int ni = 0; ni < NT; ni++) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].x, fa[mi].x, acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].y, fa[mi].y, acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].z, fa[mi].z, acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa[mi].w, acc[mi][ni], 0, 0, 0);
+                        }
+                }
+            }
+        }
+        if (MC == 0)
+            return;
+
         // D = W_tile . A_tile^T: lane (li, lh) holds Y[row = m_base + li][col = n_base + 8 (reg >> 2) + 4 lh + (reg & 3)]
-        const bool vec = (N % 4 == 0) && (((uintptr_t)Y & 15) == 0) && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
-                         (skip == nullptr || ((uintptr_t)skip & 15) == 0);
         auto epilogue = [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                const int rowg = m0 + wm * 64 + mi * 32 + li;
+            for (int mi = 0; mi < MC; mi++) {
+                const int rowg = m0 + rbase + mi * 32 + li;
                 if (rowg >= M)
                     continue;
 #pragma unroll
@@ -1623,6 +1707,28 @@ __global__ __launch_bounds__(WG) void k_linear_dma(GemmArgs g, const float *__re
             }
         };
         GNNB_DISPATCH_ACT(act, epilogue)
+        // the stores just issued sit between the prefetched chunk and the next waits: count them, or the first wait
+        // of the next item would drain them.  Only blocks that certainly issued all eight 16-B stores are counted (an
+        // under-count merely makes the next waits stricter; an over-count would let a wait return early).
+        if (vec && n0 + wn * 64 + 64 <= N) {
+#pragma unroll
+            for (int mi = 0; mi < MC; mi++)
+                if (m0 + rbase + mi * 32 + 32 <= M)
+                    vm += 8;
+        }
+    };
+
+    for (int item = blockIdx.x; item < num_items; item += gridDim.x) {
+        int m0, n0, mrows;
+        decode(item, m0, n0, mrows);
+        const int rpw = max(mrows / (DM / 64), 32); // rows per wave: 64, or 32 in a slice
+        const int rbase = wm * rpw;                 // the wave's first row inside the item
+        if (rbase >= mrows)                         // (a 32-row slice keeps half of the waves busy)
+            run_item(IntTag<0>{}, m0, n0, rbase);
+        else if (rpw == 64)
+            run_item(IntTag<2>{}, m0, n0, rbase);
+        else
+            run_item(IntTag<1>{}, m0, n0, rbase);
     }
 }
 
@@ -2467,7 +2573,7 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
         for (int sg = 0; sg < g.nseg && plain; sg++)
             plain = g.avec[sg] && g.wvec[sg] && (g.k[sg] % BK == 0) && (g.koff[sg] % 4 == 0);
         if (plain) {
-            const size_t lds = 2 * 2 * (size_t)BM * BK * 4;
+            const size_t lds = (size_t)DNBUF * DBUF_B;
             {
                 hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_linear_dma), lds);
                 if (e != hipSuccess)
@@ -2480,9 +2586,18 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
                 num_cus = (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
                               ? prop.multiProcessorCount : 256;
             }
-            const int tn = (N + 127) / 128;
-            const int grid = std::min(gm * tn, num_cus * 2); // two 64-KB workgroups are resident per CU
-            hipLaunchKernelGGL(k_linear_dma, dim3(grid), dim3(WG), lds, s, g, w, ldw, bias, skip, y, M, N, act, gm, tn);
+            const int tm = (M + DM - 1) / DM, tn = (N + DN - 1) / DN, tiles = tm * tn;
+            // two 64-KB workgroups are resident per CU and share its matrix pipe: what has to come out even is the
+            // work per CU.  The last, partial round of tiles (all of them when there are fewer tiles than CUs) goes out
+            // in 2 or 4 row slices per tile when those still fit one round (see the kernel)
+            const int rem = tiles % num_cus;
+            int split = 1;
+            if (options().gemm_tail_split && rem > 0)
+                split = 4 * rem <= 2 * num_cus ? 4 : (2 * rem <= 2 * num_cus ? 2 : 1);
+            const int split_from = split > 1 ? tiles - rem : tiles;
+            const int grid = std::min(split_from + split * (tiles - split_from), 2 * num_cus);
+            hipLaunchKernelGGL(k_linear_dma, dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, tn,
+                               split_from, split);
             return hipGetLastError();
         }
     }

@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0)};
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 1)};
     return o;
 }
 
@@ -222,6 +222,8 @@ int gnnb_set_option(const char *name, int value)
         o.gemm_variant = value;
     else if (!strcmp(name, "gemm_dma") && value >= 0 && value <= 1)
         o.gemm_dma = value;
+    else if (!strcmp(name, "gemm_tail_split") && value >= 0 && value <= 1)
+        o.gemm_tail_split = value;
     else if (!strcmp(name, "gemm_wlds") && value >= 0 && value <= 1)
         o.gemm_wlds = value;
     else if (!strcmp(name, "gemm_wlds_slots") && value >= 1 && value <= 4)

@@ -845,6 +845,31 @@ def test_linear_dma_path_segments_rowscale_and_ragged_edges(dev, M, N, F):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 300 - 5, 256, 64), (256 * 561 + 70, 128, 96), (256 * 265, 200, 32),
+                                   (256 * 40 + 3, 128, 160), (256 * 100 - 130, 256, 64)])
+def test_linear_dma_tail_split_is_bit_identical(dev, M, N, K):
+    """Tiles of the last, partial round go out as two 128-row or four 64-row slices (600 = 2 x 256 + 88 tiles -> halves,
+    562 = 2 x 256 + 50 -> quarters, 530 = 2 x 256 + 18 -> quarters, 41 and 200 tiles < 256 CUs -> all tiles sliced):
+    same MFMA order per output element, so bit-identical to the unsplit launch, and right against a float64
+    product; ragged M (the last slices are partly or wholly past M), skip + activation."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.rand(M, K, generator=g) - 0.5
+    w = (torch.rand(N, K, generator=g) - 0.5) / K ** 0.5
+    b, skip = torch.rand(N, generator=g), torch.rand(M, N, generator=g) - 0.5
+    ad, wd, bd, sd = a.to(dev), w.to(dev), b.to(dev), skip.to(dev)
+    outs = []
+    try:
+        for split in (1, 0):
+            runtime.set_option("gemm_tail_split", split)
+            outs.append(runtime.linear([(ad, None)], wd, bd, skip=sd, act="relu").cpu())
+    finally:
+        runtime.set_option("gemm_tail_split", 1)
+    rows = torch.cat([torch.arange(0, min(4096, M)), torch.arange(max(M - 70000, 0), M)])     # head + the whole tail round
+    ref = torch.relu(a[rows].double() @ w.double().T + b.double() + skip[rows].double())
+    assert (outs[0][rows].double() - ref).abs().max().item() < 2e-5
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("promise", [34, 40, 45, 46])
 def test_fused_gcn_stack_takes_graphs_up_to_45_nodes(dev, promise):
     """Graphs of 34..45 nodes still fit one 48-row stage when the node tiles are finer (8 or 4 rows): graph prep
