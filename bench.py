@@ -18,7 +18,7 @@ The timed region (K steps between barrier + synchronize on both sides, MAX over 
 Prints ONE JSON line on rank 0 (contract in the task prompt) with these extra objects:
   roofline      -- the kernel that dominates the timed step.  c2 (2-layer GCN with a max_graph_nodes
                    promise) runs the fused stack kernel k_gcn2_fused: bound = fp32 MFMA.  c3: the
-                   K=N=128 update GEMM (k_linear_reg); c4 / c5: the large-K segmented GEMM (k_linear_dma);
+                   K=N=128 update GEMM (k_linear_wlds); c4 / c5: the large-K segmented GEMM (k_linear_dma);
                    all bound = fp32 MFMA, flops / launch duration from HIP events on the launch stream.
   roofline_gather_aggregate -- the GCN gather-aggregate kernel at the full feature width (the
                    north-star kernel; every layer-by-layer model runs it): algorithmic bytes (SURVEY.md
@@ -628,7 +628,7 @@ def main():
         }
         fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w["hidden"],
                                                         len(w["pools"]))) if w["conv"] == "gcn" and w["layers"] == 2 else None
-        upd = dict(kernel="k_linear_reg (fp32 MFMA), full-width layer update", bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS,
+        upd = dict(kernel="k_linear_wlds (fp32 MFMA, weights in LDS), full-width layer update", bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS,
                    unit="TFLOP/s", traffic=None, **measure_update_mfma(w, batches[0].num_nodes, dev))
         if fused is not None:
             # the step runs the fused stack: that kernel dominates it and is bound by the fp32 matrix rate

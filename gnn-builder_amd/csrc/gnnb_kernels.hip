@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 // the whole CU), 128 x 128 output tile, two chunk buffers.  Measured: without its chunk DMA the kernel runs at 84 %
 // of the fp32 MFMA peak, with it at 65 %: a chunk requested one chunk ahead lands late (A comes from HBM, one
 // 128-B line per row and chunk) -- see the note on compiler-tracked loads in the item body.
-static constexpr int DM = 128, DN = 128, DWG = 256, DNBUF = 2, DNW = DWG / 64;
+static constexpr int DM = 128, DN = 128, DWG = 256, DNBUF = 2, DNW = DWG / 64, DWGPC = 2;
 static constexpr int DBUF_B = (DM + DN) * BK * 4; // 32 KB: A chunk | W chunk
 __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__restrict__ W, int ldw,
                                                     const float *__restrict__ bias,
@@ -1506,11 +1506,22 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     // issue cursor: runs two chunks ahead of the multiply cursor, across item boundaries
     int iss_item = blockIdx.x, iss_c = 0, iss_buf = 0;
     int vm = 0; // vector-memory instructions this wave has issued (DMA + epilogue stores): for the counted waits
-    auto issue_next = [&]() -> int { // returns vm after the chunk's DMA (its "mark"), or -1 when nothing is left
-        if (iss_item >= num_items)
-            return -1;
-        int m0, n0, mrows;
-        decode(iss_item, m0, n0, mrows);
+    // The next chunk's DMA goes out in FOUR parts, one per k step of the chunk being multiplied (a burst of eight
+    // instructions behind the barrier kept every wave of the workgroup off the matrix pipe at the same moment):
+    // issue_begin() resolves the addresses on the scalar unit, issue_part(j) fires part j, issue_end() moves the cursor.
+    struct IssueCtx {
+        const float *ga, *gw;
+        uint32_t la, lw, lda_b, ldw_b;
+        int ra_max, rw_max, mrows;
+        bool valid;
+    };
+    auto issue_begin = [&]() -> IssueCtx {
+        IssueCtx ic;
+        ic.valid = iss_item < num_items;
+        if (!ic.valid)
+            return ic;
+        int m0, n0;
+        decode(iss_item, m0, n0, ic.mrows);
         const int c = iss_c;
         // segment lookup with static indexing only (keeps the kernarg struct out of scratch)
         const float *ap = g.a[0];
@@ -1527,37 +1538,48 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         const int kk = (c - cbase) * BK;
         // scalar bases (tile origin, clamped into the matrix) + per-lane 32-bit offsets: the address arithmetic stays
         // on the scalar unit
-#ifdef GNNB_EXP_SAMECHUNK
-        const int m0c = 128 * (blockIdx.x & 255), n0c = min(n0, N - 1);
-        const float *ga = ap + (size_t)m0c * lda + (kk & 31);
-#else
         const int m0c = min(m0, M - 1), n0c = min(n0, N - 1);
-        const float *ga = ap + (size_t)m0c * lda + kk;
-#endif
-        const float *gw = W + (size_t)n0c * ldw + koff + kk;
-        const int ra_max = M - 1 - m0c, rw_max = N - 1 - n0c; // rows past M / N re-read the last valid row (never stored)
-        const uint32_t la = smem_a + (uint32_t)iss_buf * DBUF_B, lw = la + DM * BK * 4;
-        const uint32_t lda_b = (uint32_t)lda * 4, ldw_b = (uint32_t)ldw * 4;
-#pragma unroll
-        for (int i = 0; i < DM / 8 / DNW; i++) { // A: DM / 8 instructions per chunk
-            const int r0 = (wave * (DM / 8 / DNW) + i) * 8;
-            if (r0 < mrows) {
-                dma16_to_lds_s(ga, (uint32_t)min(r0 + drow, ra_max) * lda_b + dpiece_b, la + (uint32_t)r0 * 128);
+        ic.ga = ap + (size_t)m0c * lda + kk;
+        ic.gw = W + (size_t)n0c * ldw + koff + kk;
+        ic.ra_max = M - 1 - m0c, ic.rw_max = N - 1 - n0c; // rows past M / N re-read the last valid row (never stored)
+        ic.la = smem_a + (uint32_t)iss_buf * DBUF_B, ic.lw = ic.la + DM * BK * 4;
+        ic.lda_b = (uint32_t)lda * 4, ic.ldw_b = (uint32_t)ldw * 4;
+        return ic;
+    };
+    constexpr int DPARTS = BK / 8, DA_PER = DM / 8 / DNW, DW_PER = DN / 8 / DNW; // A / W instructions per wave and chunk
+    static_assert(DA_PER <= DPARTS && DW_PER <= DPARTS, "one A and one W instruction per part at most");
+    auto issue_part = [&](const IssueCtx &ic, int i) {
+        if (!ic.valid)
+            return;
+        if (i < DA_PER) {
+            const int r0 = (wave * DA_PER + i) * 8;
+            if (r0 < ic.mrows) {
+                dma16_to_lds_s(ic.ga, (uint32_t)min(r0 + drow, ic.ra_max) * ic.lda_b + dpiece_b, ic.la + (uint32_t)r0 * 128);
                 vm++;
             }
         }
-#pragma unroll
-        for (int i = 0; i < DN / 8 / DNW; i++) { // W: DN / 8 instructions per chunk
-            const int r0 = (wave * (DN / 8 / DNW) + i) * 8;
-            dma16_to_lds_s(gw, (uint32_t)min(r0 + drow, rw_max) * ldw_b + dpiece_b, lw + (uint32_t)r0 * 128);
+        if (i < DW_PER) {
+            const int r0 = (wave * DW_PER + i) * 8;
+            dma16_to_lds_s(ic.gw, (uint32_t)min(r0 + drow, ic.rw_max) * ic.ldw_b + dpiece_b, ic.lw + (uint32_t)r0 * 128);
             vm++;
         }
+    };
+    auto issue_end = [&](const IssueCtx &ic) -> int { // returns vm after the chunk's DMA (its "mark"), -1 when there was none
+        if (!ic.valid)
+            return -1;
         iss_buf = iss_buf + 1 == DNBUF ? 0 : iss_buf + 1;
         if (++iss_c == total) {
             iss_c = 0;
             iss_item += gridDim.x;
         }
         return vm;
+    };
+    auto issue_next = [&]() -> int {
+        const IssueCtx ic = issue_begin();
+#pragma unroll
+        for (int i = 0; i < DPARTS; i++)
+            issue_part(ic, i);
+        return issue_end(ic);
     };
 
     // marks of the chunks in flight (DNBUF - 1 of them): mk0 = the chunk multiplied next, mk1 = the one after it
@@ -1606,14 +1628,12 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
             // operations retire in order; loads the compiler tracks itself only make the wait stricter) ...
             vmcnt_wait_n(min(vm - mk0, 63));
             __syncthreads(); // ... and for everyone; and everyone is done reading the buffer refilled next
-#ifndef GNNB_EXP_NODMA
-            if (DNBUF > 2) {
-                mk0 = mk1;
-                mk1 = issue_next();
-            } else {
-                mk0 = issue_next();
+            const IssueCtx ic = issue_begin();
+            if (MC == 0) {
+#pragma unroll
+                for (int i = 0; i < DPARTS; i++)
+                    issue_part(ic, i);
             }
-#endif
             const float *a = reinterpret_cast<const float *>(smem + (size_t)buf * DBUF_B);
             const float *b = reinterpret_cast<const float *>(smem + (size_t)buf * DBUF_B + DM * BK * 4);
             buf = buf + 1 == DNBUF ? 0 : buf + 1;
@@ -1631,6 +1651,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             s[mi] = sc[sgm][mi];
                         scaled = g.rs[sgm] != nullptr;
                     }
+                // (requesting the fragments of k step j + 1 before the MFMAs of step j -- two register sets -- was
+                // measured: 601 vs 583 us at the C4 shape)
 #pragma unroll
                 for (int kb = 0; kb < BK; kb += 8) {
                     float4 fa[MC > 0 ? MC : 1], fb[NT];
@@ -1650,6 +1672,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                         const int r = wn * 32 * NT + ni * 32 + li;
                         fb[ni] = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
                     }
+                    issue_part(ic, kb / 8); // (behind this step's fragment reads, in front of its MFMAs)
                     // operands SWAPPED (W fragment first): the 32x32 accumulator then holds, per lane, FOUR
                     // CONSECUTIVE output columns of one row per register group -- the epilogue stores float4
 #pragma unroll
@@ -1662,6 +1685,13 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa[mi].w, acc[mi][ni], 0, 0, 0);
                         }
                 }
+            }
+            // the marks move on: mk0 = the chunk multiplied next
+            if (DNBUF > 2) {
+                mk0 = mk1;
+                mk1 = issue_end(ic);
+            } else {
+                mk0 = issue_end(ic);
             }
         }
         if (MC == 0)
@@ -2593,9 +2623,9 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             const int rem = tiles % num_cus;
             int split = 1;
             if (options().gemm_tail_split && rem > 0)
-                split = 4 * rem <= 2 * num_cus ? 4 : (2 * rem <= 2 * num_cus ? 2 : 1);
+                split = 4 * rem <= DWGPC * num_cus ? 4 : (2 * rem <= DWGPC * num_cus ? 2 : 1);
             const int split_from = split > 1 ? tiles - rem : tiles;
-            const int grid = std::min(split_from + split * (tiles - split_from), 2 * num_cus);
+            const int grid = std::min(split_from + split * (tiles - split_from), DWGPC * num_cus);
             hipLaunchKernelGGL(k_linear_dma, dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, tn,
                                split_from, split);
             return hipGetLastError();
@@ -3572,7 +3602,10 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                     acc[t] += xv[t][q] * c[q];
             }
             if (active) {
-                for (int k = r0.x + 4; k < r0.x + deg; k++) { // degree > 4: rare in molecules
+                // (degree > 4: rare in molecules.  The tracked global read makes the compiler drain vmcnt, i.e. the wave
+                // also waits for the next stage's DMA; measured bound of staging the CSR slice in LDS instead: the kernel
+                // without this loop altogether is 55.2 vs 57.0 us)
+                for (int k = r0.x + 4; k < r0.x + deg; k++) {
                     const int j = col[k] - nb;
                     const float cj = di * sdinv[j];
 #pragma unroll
