@@ -33,7 +33,8 @@ struct BatchTables {
     int32_t num_tiles;
 };
 
-constexpr int GNNB_G2_STAGE_ROWS = 48; // rows per stage of the fused 2-layer GCN kernel (3 MFMA units)
+constexpr int GNNB_G2_STAGE_ROWS = 64;     // rows per stage of the fused 2-layer GCN kernel (4 MFMA units)
+constexpr int GNNB_G2_STAGE_ROWS_BF6 = 48; // ... in the opt-in bf16x6 math mode (3 units)
 
 struct Options {
     int tile_rows;    // node-tile granularity (rows; tiles are cut at graph boundaries)
@@ -48,8 +49,7 @@ struct Options {
     int gemm_wlds;     // 1 = K, N in {64,128}, no skip operand: weights-in-LDS, barrier-free kernel (default); 0 = register-resident weights
     int gemm_wlds_slots; // ... its ring depth per wave (capped by what fits beside W in LDS)
     int fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
-    int fuse_gcn2;     // fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it: 2 = aggregation on the
-                       // matrix pipe (k_gcn2_mm), 1 = aggregation by LDS row gathers (k_gcn2_fused), 0 = layer by layer
+    int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it (k_gcn2_fused), 0 = layer by layer
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
     int head_small;    // 1 = readout on a pooled matrix with the small-footprint kernel that co-resides with the
                        //     conv-stack kernel of the next batch in flight (default); 0 = weights-in-LDS kernel

@@ -3200,10 +3200,12 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
 // HBM traffic = x + tables in, [B, np*d] out: ~5 MB instead of ~270 MB at C2; the kernel is bound by
 // the fp32 matrix cores.  Needs: num_layers == 2, F0 <= 32, h0 in {32,64,128}, h1 <= 128 (h1 % 4 == 0)
 // and the caller's promise max_graph_nodes <= 48 - (tile_rows - 1) (validated by graph prep).
-static constexpr int G2_UNITS = 3;
-static constexpr int G2_CAP = 16 * G2_UNITS; // rows per stage
-static_assert(G2_CAP == GNNB_G2_STAGE_ROWS, "graph prep picks the tile size against this");
-static constexpr int G2_TCAP = 256;          // tile-table entries a workgroup keeps in LDS
+// rows per stage: FOUR 16-row MFMA units (64 rows) -- a stage costs ~13 k cycles of barriers and latency chains whatever
+// it holds, and three molecules fill 54 of 64 rows where two filled 36 of 48.  The bf16x6 mode keeps three units (its A1
+// is three bf16 planes: 1.5x the bytes, and two workgroups must stay resident per CU).
+__host__ __device__ constexpr int g2_units(int math) { return math ? 3 : 4; }
+static_assert(16 * g2_units(0) == GNNB_G2_STAGE_ROWS && 16 * g2_units(1) == GNNB_G2_STAGE_ROWS_BF6, "graph prep picks the tile size against these");
+static constexpr int G2_TCAP = 64;           // tile-table entries a workgroup keeps in LDS
 static constexpr int G2_WG = 512;            // 8 waves; two workgroups per CU = 4 waves per SIMD
 static constexpr int G2_NW = G2_WG / 64;
 
@@ -3345,19 +3347,24 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int G2_UNITS = g2_units(MATH), G2_CAP = 16 * G2_UNITS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    // ---- LDS carve (bytes, every region 16-B aligned)
+    // ---- LDS carve (bytes, every region 16-B aligned):
+    //   rows  xs | srec                ONE buffer: read by P0 only, refilled right behind P0
+    //   small sdinv | node_ptr of <= 64 graphs (+ end)   TWO buffers (P1 and the pooling still read them)
+    //   H | A1 (A0 lives in the head of A1: P0 writes it, M0 reads it, P1 overwrites it) | REC | tile tables
     const int xs_b = ((G2_CAP * f0 * 4) + 15) & ~15;
-    const int in_b = xs_b + G2_CAP * 32 + G2_CAP * 4 + 272; // xs | srec | sdinv | node_ptr of <= 64 graphs (+ end)
+    const int rows_b = xs_b + G2_CAP * 32;
+    const int small_b = G2_CAP * 4 + 272;
     const int ldh = (h0 > h1 ? h0 : h1) + 4;          // padded H row (floats)
     // NOTE: LDS pointers are always derived arithmetically from `smem`.  Indexing an array of LDS
     // pointers with a runtime value makes the compiler lose the address space and emit FLAT loads,
     // whose s_waitcnt vmcnt(0) also waits for the in-flight DMA of the next stage.
     constexpr int LD0 = 16 * KQ0; // A0 row: F0 values zero-padded to whole 16-wide MFMA k blocks
-    float *A0 = reinterpret_cast<float *>(smem + 2 * in_b);
-    float *H = A0 + G2_CAP * LD0;
+    float *H = reinterpret_cast<float *>(smem + rows_b + 2 * small_b);
     float *A1 = H + G2_CAP * ldh;
+    float *A0 = A1;
     // per-row aggregation record written by P0, read by P1: {byte offsets of the 4 inline neighbour rows in H}
     // {coefficients dinv_i dinv_j, 0 past the degree} {dinv_i^2, rp0, deg, dinv_i}
     // (MATH 1: A1 is three bf16 planes [G2_CAP][h0] instead of one fp32 matrix: 1.5x the bytes)
@@ -3405,32 +3412,39 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         st.gb = max(tb == num_tiles ? num_graphs : sgraph[tb - t0], st.ga);
         return st;
     };
-    auto issue = [&](const G2Stage &st, int bb, int lane, int wave) { // (lane, wave: see `tv` below)
+    // the stage's rows (x, node records) -> the single rows buffer: behind P0 of the stage before
+    auto issue_rows = [&](const G2Stage &st, int lane, int wave) { // (lane, wave: see `tv` below)
+        if (st.ta >= t1)
+            return;
+        dma_dwords_u(x + (size_t)st.nb * f0, smem, st.rows * f0, wave, lane, G2_NW);
+        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
+        const int rbytes = st.rows * 32;
+        if (wave * 1024 + lane * 16 < rbytes) // <= 64 rows * 32 B = 2 KiB: waves 0 and 1
+            dma16_to_lds_u(grec + wave * 1024 + lane * 16, smem + xs_b + wave * 1024);
+    };
+    // its normalisers and graph boundaries -> small buffer bb: at the top of the stage before
+    auto issue_small = [&](const G2Stage &st, int bb, int lane, int wave) {
         if (st.ta >= t1)
             return;
         // (a stage may have NO rows and still own graphs: empty graphs behind a graph that ends on the
         // tile edge -- their boundaries are still needed by the pooling phase)
-        char *base = smem + (size_t)bb * in_b;
-        dma_dwords_u(x + (size_t)st.nb * f0, base, st.rows * f0, wave, lane, G2_NW);
-        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
-        const int rbytes = st.rows * 32;
-        if (wave * 1024 + lane * 16 < rbytes) // <= 48 rows * 32 B = 1.5 KiB: waves 0 and 1
-            dma16_to_lds_u(grec + wave * 1024 + lane * 16, base + xs_b + wave * 1024);
+        char *base = smem + rows_b + (size_t)bb * small_b;
         if (wave == 2 && lane < st.rows)
-            dma4_to_lds_u(dinv + st.nb + lane, base + xs_b + G2_CAP * 32);
+            dma4_to_lds_u(dinv + st.nb + lane, base);
         // graph boundaries of the stage for the pooling phase (first 64 graphs; more only if empty
         // graphs pile up, those are read from global memory)
         const int ng = min(st.gb - st.ga, 64) + 1;
         if (wave == 3 && lane < ng)
-            dma4_to_lds_u(node_ptr + st.ga + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4);
+            dma4_to_lds_u(node_ptr + st.ga + lane, base + G2_CAP * 4);
         if (wave == 4 && lane + 64 < ng)
-            dma4_to_lds_u(node_ptr + st.ga + 64 + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4 + 256);
+            dma4_to_lds_u(node_ptr + st.ga + 64 + lane, base + G2_CAP * 4 + 256);
     };
 
     // the first stage's inputs start their way to LDS before the weights are fetched (both are waited for
     // together below), instead of after them
     G2Stage cur = plan(t0);
-    issue(cur, 0, lane, wave);
+    issue_small(cur, 0, lane, wave);
+    issue_rows(cur, lane, wave);
 
 
     // ---- wave roles: layer L has ncs_L = pow2ceil(h_L / 16) column slices of 16 and nrg_L = 8 / ncs_L
@@ -3541,11 +3555,11 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         stores_behind_dma = 0;
         g2_barrier(); // (1) everyone's DMA is in; everyone is done with the previous stage
         G2_PT(0);
-        const char *ibase = smem + (size_t)b * in_b;
-        const float *xs = reinterpret_cast<const float *>(ibase);
-        const int4 *srec = reinterpret_cast<const int4 *>(ibase + xs_b);
-        const float *sdinv = reinterpret_cast<const float *>(ibase + xs_b + G2_CAP * 32);
-        const int32_t *sgp = reinterpret_cast<const int32_t *>(ibase + xs_b + G2_CAP * 32 + G2_CAP * 4);
+        const char *sbase = smem + rows_b + (size_t)b * small_b;
+        const float *xs = reinterpret_cast<const float *>(smem);
+        const int4 *srec = reinterpret_cast<const int4 *>(smem + xs_b);
+        const float *sdinv = reinterpret_cast<const float *>(sbase);
+        const int32_t *sgp = reinterpret_cast<const int32_t *>(sbase + G2_CAP * 4);
         const int rows = cur.rows, nb = cur.nb;
         const int units = (rows + 15) >> 4;
         // The thread index is re-made OPAQUE every stage and every per-lane quantity below is derived from
@@ -3558,11 +3572,11 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         const int n0c = (wv & ((1 << cs0l) - 1)) * 16 + li, n1c = (wv & ((1 << cs1l) - 1)) * 16 + li;
         const int rg0 = wv >> cs0l;
         const int grp = tv >> glog2, gl = tv & (Gl - 1);
-        issue(nxt, b ^ 1, tv & 63, wv);
+        issue_small(nxt, b ^ 1, tv & 63, wv);
         G2_PT(1);
 
         // ---- P0: A0[i][f] = sum_j x_j[f] dinv_i dinv_j + x_i[f] dinv_i^2   (CSR order, self last)
-        // Eight lanes per row, lane l8 takes features l8, l8 + 8, ...: all <= 48 rows in ONE pass of the 512
+        // Eight lanes per row, lane l8 takes features l8, l8 + 8, ...: all <= 64 rows in ONE pass of the 512
         // threads (lanes f >= F0 write the zero padding).  Every LDS load is unconditional -- unused neighbour
         // slots alias the row itself, inactive threads read row 0 -- and the degree only selects: a
         // lane-divergent guard around a load makes the compiler wait at every join.
@@ -3628,6 +3642,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         }
         G2_PT(2);
         g2_barrier(); // (2)
+        issue_rows(nxt, tv & 63, wv); // (P0 was the last reader of the rows buffer)
         G2_PT(3);
 
         // ---- M0: H = act(A0 . W0^T + b0)   (wave: column slice x row group)
@@ -3645,7 +3660,9 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                             H[((rg0 + k * nrg0) * 16 + lg * 4 + r) * ldh + n0c] = v[k][r];
                 }
             };
-            if (nu == 3)
+            if (G2_UNITS > 3 && nu == 4)
+                m0(IntTag<G2_UNITS>{});
+            else if (nu == 3)
                 m0(IntTag<3>{});
             else if (nu == 2)
                 m0(IntTag<2>{});
@@ -3669,7 +3686,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 rc = REC[3 * grp + 1];
                 rd = REC[3 * grp + 2];
             }
-            // (at most 3 passes: groups >= 16 and rows <= 48; fixed-count loop, no derived trip count)
+            // (at most G2_UNITS passes: groups >= 16; fixed-count loop, no derived trip count)
 #pragma unroll 1
             for (int pass = 0; pass < G2_UNITS; pass++) {
                 const int rA = grp + pass * groups;
@@ -3775,444 +3792,9 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 for (int gi = nlds; gi < ngr; gi++) // a pile of empty graphs
                     pool_graph(gi, node_ptr[cur.ga + gi], node_ptr[cur.ga + gi + 1]);
             };
-            if (units == 3)
-                m1(IntTag<3>{});
-            else if (units == 2)
-                m1(IntTag<2>{});
-            else
-                m1(IntTag<1>{});
-        } else if (units == 0 && wv == 0) {
-            // a stage without rows (empty graphs behind the last node of a tile): zeros
-            stores_behind_dma = 1 << 20; // (full drain)
-            for (int e = tv; e < (cur.gb - cur.ga) * np * h1; e += 64)
-                pooled[(size_t)cur.ga * np * h1 + e] = 0.0f;
-        }
-        G2_PT(10);
-#ifdef GNNB_PROBE
-        nst++;
-#endif
-        cur = nxt;
-        b ^= 1;
-    }
-#ifdef GNNB_PROBE
-    if (lane == 0 && blockIdx.x < 512) {
-        unsigned long long *o = g_probe + 8 * 8192 + (blockIdx.x * 8 + wave) * 16; // second half: other kernels stamp the first
-        o[0] = pw0;
-        o[1] = wall_clock64();
-        for (int i = 0; i < 11; i++)
-            o[2 + i] = pt[i];
-        o[13] = clock64() - pt0;
-        o[14] = (unsigned long long)nst;
-    }
-#endif
-}
-
-// -------------------------------------------------------------------------------------
-// k_gcn2_mm: the fused 2-layer GCN stack with BOTH AGGREGATIONS ON THE MATRIX PIPE (round 2).
-// Same stages, DMA, M0 / M1 and in-register pooling as k_gcn2_fused; what changes is how A_hat . x and A_hat . H are
-// computed.  k_gcn2_fused gathers rows by index from LDS (P0, P1): little work, but each is a chain of dependent LDS
-// round trips behind a barrier, and the probe shows a third of the wave-cycles parked there while the matrix pipe
-// idles (profiles/r02_gcn2_phases.json).  Here a stage first builds its dense normalised adjacency block A_hat
-// [48][48] in LDS (a molecule stage: ~5 nonzeros per row), and the aggregations become two small MFMA products
-//     A0 = A_hat . x        (K = rows of the stage, N = F0)            36 MFMA per stage on waves 0..2
-//     A1 = A_hat . H        (K = rows, N = h0; wave w owns columns 16 w ..)  <= 36 MFMA per wave
-// with swapped operands so that results land as ds_write_b128 rows of the next phase's A operand; M0 writes H
-// transposed (its accumulator holds four consecutive rows of a column: one ds_write_b128 into H^T).  +37 % MFMA work,
-// issued where the pipe was idle; no per-row records, no index arithmetic, degree > 4 and multigraphs cost nothing
-// extra in the aggregation.  Zeros of A_hat meet leftover rows of earlier stages in whole 16-row k blocks, so those
-// LDS regions are zeroed once at kernel start (0 . NaN would be NaN).
-template <int ACT, int KQ0, int KQ1>
-__global__ __launch_bounds__(G2_WG, 4) void k_gcn2_mm(
-    const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
-    const int32_t *__restrict__ col, const float *__restrict__ dinv,
-    const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_edge, const int32_t *__restrict__ tile_graph,
-    const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, int N, int E, const float *__restrict__ W0,
-    const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ b1,
-    int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-    // ---- LDS carve (bytes, every region 16-B aligned)
-    const int xs_b = ((G2_CAP * f0 * 4) + 15) & ~15;
-    constexpr int ECAP = 256; // CSR entries of a stage kept in LDS (rows of degree > 4 read them; more: global memory)
-    const int in_b = xs_b + G2_CAP * 32 + G2_CAP * 4 + 272 + ECAP * 4; // xs | srec | sdinv | node_ptr of <= 64 graphs (+ end) | col slice
-    // NOTE: LDS pointers are always derived arithmetically from `smem`.  Indexing an array of LDS
-    // pointers with a runtime value makes the compiler lose the address space and emit FLAT loads,
-    // whose s_waitcnt vmcnt(0) also waits for the in-flight DMA of the next stage.
-    constexpr int LD0 = 16 * KQ0 + 4; // A0 row: F0 values padded to whole 16-wide MFMA k blocks (+4: bank spread)
-    constexpr int LDA = G2_CAP + 4;   // row of the stage's dense aggregation operator / of H^T (floats)
-    float *A0 = reinterpret_cast<float *>(smem + 2 * in_b);
-    float *HT = A0 + G2_CAP * LD0;                 // H^T [h0][LDA]: layer-0 output, TRANSPOSED (B operand of A_hat . H)
-    float *AH = HT + h0 * LDA;                     // A_hat [G2_CAP][LDA]: dinv_i dinv_j per edge + dinv_i^2 on the diagonal
-    const int lda1 = h0 + 4;
-    float *A1 = AH + G2_CAP * LDA;                 // A1 = A_hat . H, row-major: the A operand of M1
-    int32_t *stile = reinterpret_cast<int32_t *>(A1 + G2_CAP * lda1);
-    int32_t *sgraph = stile + (G2_TCAP + 1);
-    int32_t *sedge = sgraph + (G2_TCAP + 1);
-
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
-    if (t1 <= t0)
-        return;
-    // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
-    for (int i = tid; i <= t1 - t0; i += G2_WG) {
-        stile[i] = min(max(tile_first[t0 + i], 0), N);
-        sgraph[i] = min(max(tile_graph[t0 + i], 0), num_graphs);
-        sedge[i] = min(max(tile_edge[t0 + i], 0), E);
-    }
-    // x stages and H^T are multiplied by A_hat over whole 16-row k blocks: rows past a stage's end meet exact zeros of
-    // A_hat, so whatever those bytes hold must be FINITE (0 . NaN is NaN).  Zeroed once; afterwards they only ever hold
-    // finite values of earlier stages.
-    for (int i = tid; i < (2 * in_b) / 4; i += G2_WG)
-        reinterpret_cast<float *>(smem)[i] = 0.0f;
-    for (int i = tid; i < h0 * LDA; i += G2_WG)
-        HT[i] = 0.0f;
-    __syncthreads();
-
-    auto plan = [&](int ta) {
-        G2Stage st;
-        st.ta = ta;
-        st.tb = ta;
-        st.nb = 0;
-        st.rows = 0;
-        st.ga = 0;
-        st.gb = 0;
-        if (ta >= t1)
-            return st;
-        st.nb = stile[ta - t0];
-        int tb = ta + 1;
-        while (tb < t1 && stile[tb + 1 - t0] - st.nb <= G2_CAP)
-            tb++;
-        st.tb = tb;
-        st.rows = max(min(stile[tb - t0] - st.nb, G2_CAP), 0); // (> CAP only if the max_graph_nodes promise is broken)
-        st.ga = sgraph[ta - t0];
-        // (empty graphs after the last node belong to the last stage: when N is a multiple of the tile
-        // size the first of them already owns tile_graph[num_tiles])
-        st.gb = max(tb == num_tiles ? num_graphs : sgraph[tb - t0], st.ga);
-        return st;
-    };
-    auto issue = [&](const G2Stage &st, int bb, int lane, int wave) { // (lane, wave: see `tv` below)
-        if (st.ta >= t1)
-            return;
-        // (a stage may have NO rows and still own graphs: empty graphs behind a graph that ends on the
-        // tile edge -- their boundaries are still needed by the pooling phase)
-        char *base = smem + (size_t)bb * in_b;
-        dma_dwords_u(x + (size_t)st.nb * f0, base, st.rows * f0, wave, lane, G2_NW);
-        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
-        const int rbytes = st.rows * 32;
-        if (wave * 1024 + lane * 16 < rbytes) // <= 48 rows * 32 B = 1.5 KiB: waves 0 and 1
-            dma16_to_lds_u(grec + wave * 1024 + lane * 16, base + xs_b + wave * 1024);
-        if (wave == 2 && lane < st.rows)
-            dma4_to_lds_u(dinv + st.nb + lane, base + xs_b + G2_CAP * 32);
-        // graph boundaries of the stage for the pooling phase (first 64 graphs; more only if empty
-        // graphs pile up, those are read from global memory)
-        // the stage's CSR slice (tracked global reads of `col` in the build phase would drain this DMA)
-        {
-            const int e0 = sedge[st.ta - t0], ne = min(max(sedge[st.tb - t0] - e0, 0), ECAP);
-            if (wave * 64 + lane < ne)
-                dma4_to_lds_u(col + e0 + wave * 64 + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4 + 272 + wave * 256);
-        }
-        const int ng = min(st.gb - st.ga, 64) + 1;
-        if (wave == 3 && lane < ng)
-            dma4_to_lds_u(node_ptr + st.ga + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4);
-        if (wave == 4 && lane + 64 < ng)
-            dma4_to_lds_u(node_ptr + st.ga + 64 + lane, base + xs_b + G2_CAP * 32 + G2_CAP * 4 + 256);
-    };
-
-    // the first stage's inputs start their way to LDS before the weights are fetched (both are waited for
-    // together below), instead of after them
-    G2Stage cur = plan(t0);
-    issue(cur, 0, lane, wave);
-
-
-    // ---- wave roles: layer L has ncs_L = pow2ceil(h_L / 16) column slices of 16 and nrg_L = 8 / ncs_L
-    // row groups; wave w owns slice (w mod ncs) for the units rg, rg + nrg, ... with rg = w / ncs
-    int cs0l = 0, cs1l = 0;
-    while ((16 << cs0l) < h0)
-        cs0l++;
-    while ((16 << cs1l) < h1)
-        cs1l++; // h1 <= 128 -> <= 3
-    const int nrg0 = G2_NW >> cs0l, n0c = (wave & ((1 << cs0l) - 1)) * 16 + li;
-    const int n1c = (wave & ((1 << cs1l) - 1)) * 16 + li;
-
-    // ---- weight slices -> registers (16 output columns x K per layer and wave)
-    float w0r[KQ0 * 4], w1r[KQ1 * 4];
-#pragma unroll
-    for (int q = 0; q < KQ0; q++) {
-        const int k = 16 * q + 4 * lg;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0c < h0)
-            v = load4_guard(W0 + (size_t)n0c * f0 + k, f0 - k, false);
-        w0r[q * 4 + 0] = v.x;
-        w0r[q * 4 + 1] = v.y;
-        w0r[q * 4 + 2] = v.z;
-        w0r[q * 4 + 3] = v.w;
-    }
-#pragma unroll
-    for (int q = 0; q < KQ1; q++) {
-        const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n1c < h1)
-            v = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + k);
-        w1r[q * 4 + 0] = v.x;
-        w1r[q * 4 + 1] = v.y;
-        w1r[q * 4 + 2] = v.z;
-        w1r[q * 4 + 3] = v.w;
-    }
-    float bias0 = (n0c < h0 && b0) ? b0[n0c] : 0.0f;
-    float bias1 = (n1c < h1 && b1) ? b1[n1c] : 0.0f;
-    // Pin every weight register through an (empty) asm: the compiler must finish the loads HERE.  Left
-    // alone it keeps them "possibly in flight" around the stage loop's back edge and guards their first
-    // use in M0 / M1 with s_waitcnt vmcnt(0) -- which also waits for the next stage's DMA issued just
-    // before, i.e. exposes the full memory latency in every stage.
-#pragma unroll
-    for (int q = 0; q < KQ0 * 4; q++)
-        asm volatile("" : "+v"(w0r[q]));
-#pragma unroll
-    for (int q = 0; q < KQ1 * 4; q++)
-        asm volatile("" : "+v"(w1r[q]));
-    asm volatile("" : "+v"(bias0), "+v"(bias1));
-    __syncthreads();
-
-    const int pools[3] = {p0, p1, p2};
-
-#ifdef GNNB_PROBE
-    unsigned long long pt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = clock64(), pw0 = wall_clock64(), pt_last = pt0;
-    int nst = 0;
-#define G2_PT(i) do { const unsigned long long _n = clock64(); pt[i] += _n - pt_last; pt_last = _n; } while (0)
-#else
-#define G2_PT(i) do { } while (0)
-#endif
-    int b = 0;
-    int stores_behind_dma = 0; // wave-uniform: store INSTRUCTIONS this wave issued since its last DMA issue
-    while (cur.ta < t1) {
-        const G2Stage nxt = plan(cur.tb);
-        // Stage `cur` has landed (untracked DMA: the wait is ours).  Vector-memory operations retire in
-        // order and the previous stage's pooled stores were issued AFTER this DMA, so waiting for
-        // "at most <that many> outstanding" proves the DMA done and leaves the stores in flight.
-        vmcnt_wait_upto(stores_behind_dma);
-        stores_behind_dma = 0;
-        g2_barrier(); // (1) everyone's DMA is in; everyone is done with the previous stage
-        G2_PT(0);
-        const char *ibase = smem + (size_t)b * in_b;
-        const float *xs = reinterpret_cast<const float *>(ibase);
-        const int4 *srec = reinterpret_cast<const int4 *>(ibase + xs_b);
-        const float *sdinv = reinterpret_cast<const float *>(ibase + xs_b + G2_CAP * 32);
-        const int32_t *sgp = reinterpret_cast<const int32_t *>(ibase + xs_b + G2_CAP * 32 + G2_CAP * 4);
-        const int32_t *scol = reinterpret_cast<const int32_t *>(ibase + xs_b + G2_CAP * 32 + G2_CAP * 4 + 272);
-        const int e0s = sedge[cur.ta - t0];
-        const int rows = cur.rows, nb = cur.nb;
-        const int units = (rows + 15) >> 4;
-        // The thread index is re-made OPAQUE every stage and every per-lane quantity below is derived from
-        // it again (a dozen VALU ops).  Otherwise the compiler hoists ~50 loop-invariant LDS offsets out of
-        // the stage loop, runs out of its 128 registers and parks them in scratch -- whose reloads are
-        // vector-memory operations that queue behind the next stage's DMA.
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-        const int li = tv & 15, lg = (tv >> 4) & 3, wv = tv >> 6;
-        const int n0c = (wv & ((1 << cs0l) - 1)) * 16 + li, n1c = (wv & ((1 << cs1l) - 1)) * 16 + li;
-        const int rg0 = wv >> cs0l;
-        issue(nxt, b ^ 1, tv & 63, wv);
-        G2_PT(1);
-
-        // ---- BUILD + P0' (waves 0 .. units-1, one 16-row unit each; no barrier between the two: a wave's LDS
-        // operations execute in program order).
-        // BUILD: the unit's rows of the stage's dense aggregation operator A_hat [rows][rows] in LDS:
-        //   A_hat[i][j] = sum over edges j -> i of dinv_i dinv_j,   A_hat[i][i] += dinv_i^2      (gcn_conv_agg, lib:1223-1289)
-        // Both aggregations of the stack then run on the MATRIX pipe (A_hat . x, A_hat . H): no row gathers, no per-row
-        // records.  Four lanes per row: zero the row, then drop in the coefficients -- in parallel when the row's <= 4
-        // sources are distinct (every molecule), by one lane with read-modify-write when sources repeat (multigraphs)
-        // or the degree exceeds the inline four.
-        // P0': A0 = A_hat . x for the unit's rows, operands swapped (x fragment first) so that a lane ends up with four
-        // consecutive features of one row.
-        if (wv < units) {
-            const int rl = (tv >> 2) & 15, l4 = tv & 3;
-            const int i = wv * 16 + rl;
-            const int ic = i < rows ? i : 0;
-            const int4 r0 = srec[2 * ic], r1 = srec[2 * ic + 1];
-            const int deg = i < rows ? r0.y : 0;
-            const int jl[4] = {r0.z - nb, r0.w - nb, r1.x - nb, r1.y - nb};
-            const float di = sdinv[ic];
-            float *row = AH + i * LDA;
-#pragma unroll
-            for (int pz = 0; pz < 4; pz++) // LDA = 52 floats = 13 float4 over 4 lanes
-                if (pz * 4 + l4 < LDA / 4)
-                    *reinterpret_cast<float4 *>(row + 4 * (pz * 4 + l4)) = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < rows) {
-                // every in-edge adds its coefficient with an LDS float atomic (ds_add_f32): repeated sources of a
-                // multigraph accumulate, and a row of any degree is spread over the row's four lanes.  The first four
-                // sources come inline in the node record, the rest from the stage's CSR slice.
-                const int ka = r0.x, kb = r0.x + deg;
-                for (int kk = ka + l4; kk < kb; kk += 4) {
-                    int j;
-                    if (kk - ka < 4)
-                        j = l4 == 0 ? jl[0] : (l4 == 1 ? jl[1] : (l4 == 2 ? jl[2] : jl[3]));
-                    else if (kk >= e0s && kk - e0s < ECAP)
-                        j = scol[kk - e0s] - nb;
-                    else
-                        j = -1 - kk; // (a stage with more than ECAP edges: fetched from global memory below)
-                    if (j >= 0 && j < G2_CAP)
-                        atomicAdd(row + j, di * sdinv[j]);
-                    else if (j < 0 && kk - ka >= 4) {
-                        const int jg = col[kk] - nb;
-                        if (jg >= 0 && jg < G2_CAP)
-                            atomicAdd(row + jg, di * sdinv[jg]);
-                    }
-                }
-                if (l4 == 0)
-                    atomicAdd(row + i, di * di); // the self term (gcn_conv_agg, lib:1266-1278)
-            }
-            // ---- P0'
-#pragma unroll
-            for (int nt = 0; nt < KQ0; nt++) {
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const int f = 16 * nt + li;
-                const int fc = f < f0 ? f : 0;
-                for (int q = 0; q < units; q++) { // k blocks that hold rows of the stage
-                    const float4 ah = *reinterpret_cast<const float4 *>(AH + (wv * 16 + li) * LDA + 16 * q + 4 * lg);
-                    const int k0 = 16 * q + 4 * lg;
-                    // x[k][f], k = k0 .. k0 + 3 (rows past the stage: finite leftovers times exact zeros of A_hat)
-                    const float x0 = xs[(k0 + 0) * f0 + fc], x1 = xs[(k0 + 1) * f0 + fc], x2 = xs[(k0 + 2) * f0 + fc],
-                                x3 = xs[(k0 + 3) * f0 + fc];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f < f0 ? x0 : 0.0f, ah.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f < f0 ? x1 : 0.0f, ah.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f < f0 ? x2 : 0.0f, ah.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f < f0 ? x3 : 0.0f, ah.w, acc, 0, 0, 0);
-                }
-                // D[f][m]: lane (li = m, lg) holds features 16 nt + 4 lg .. + 3 of row wv * 16 + li
-                *reinterpret_cast<float4 *>(A0 + (wv * 16 + li) * LD0 + 16 * nt + 4 * lg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            }
-        }
-        G2_PT(2);
-        g2_barrier(); // (2) A_hat and A0 are complete
-        G2_PT(3);
-
-        // ---- M0: H = act(A0 . W0^T + b0)   (wave: column slice x row group), written TRANSPOSED: the accumulator
-        // holds four consecutive ROWS of one column per lane -- one ds_write_b128 into H^T[col][unit * 16 + 4 lg]
-        {
-            const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
-            auto m0 = [&](auto nutag) {
-                constexpr int NU = decltype(nutag)::value;
-                float v[NU][4];
-                g2_mma<ACT, KQ0, NU, false>(A0, LD0, 1, w0r, bias0, rg0, nrg0, li, lg, v);
-                if (n0c < h0) {
-#pragma unroll
-                    for (int k = 0; k < NU; k++)
-                        *reinterpret_cast<float4 *>(HT + n0c * LDA + (rg0 + k * nrg0) * 16 + lg * 4) =
-                            make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
-                }
-            };
-            if (nu == 3)
-                m0(IntTag<3>{});
-            else if (nu == 2)
-                m0(IntTag<2>{});
-            else if (nu == 1)
-                m0(IntTag<1>{});
-        }
-        G2_PT(6);
-        g2_barrier(); // (3b) H^T is complete
-        G2_PT(7);
-
-        // ---- P1': A1 = A_hat . H on the matrix pipe.  Wave w owns the 16-column slice w of H (h0 / 16 slices) for
-        // every row unit; operands swapped (H^T fragment first): the lane ends up with A1[16 u + li][16 w + 4 lg .. + 3]
-        // -- one ds_write_b128 per unit into the row-major A1 that M1 reads.
-        if (wv * 16 < h0 && units > 0) {
-            auto p1 = [&](auto nutag) {
-                constexpr int NU = decltype(nutag)::value;
-                f32x4 acc[NU];
-#pragma unroll
-                for (int u = 0; u < NU; u++)
-                    acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < NU; q++) { // k blocks that hold rows of the stage
-                    const float4 hf = *reinterpret_cast<const float4 *>(HT + (wv * 16 + li) * LDA + 16 * q + 4 * lg);
-                    float4 af[NU];
-#pragma unroll
-                    for (int u = 0; u < NU; u++)
-                        af[u] = *reinterpret_cast<const float4 *>(AH + (u * 16 + li) * LDA + 16 * q + 4 * lg);
-#pragma unroll
-                    for (int sk = 0; sk < 4; sk++) {
-                        const float hv = sk == 0 ? hf.x : (sk == 1 ? hf.y : (sk == 2 ? hf.z : hf.w));
-#pragma unroll
-                        for (int u = 0; u < NU; u++) {
-                            const float av = sk == 0 ? af[u].x : (sk == 1 ? af[u].y : (sk == 2 ? af[u].z : af[u].w));
-                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv, av, acc[u], 0, 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < NU; u++)
-                    *reinterpret_cast<float4 *>(A1 + (u * 16 + li) * lda1 + wv * 16 + 4 * lg) =
-                        make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
-            };
-            if (units == 3)
-                p1(IntTag<3>{});
-            else if (units == 2)
-                p1(IntTag<2>{});
-            else
-                p1(IntTag<1>{});
-        }
-        G2_PT(8);
-        g2_barrier(); // (4) A1 is complete
-        G2_PT(9);
-
-        // ---- M1 + pooling: out = act(A1 . W1^T + b1) stays in the accumulators (the wave owns its 16
-        // columns for ALL rows of the stage; waves beyond h1/16 slices idle) and is pooled per graph in
-        // registers: masked add / max over the lane's 4 rows per unit, then across the four 16-lane groups.
-        // (reference global_add/mean/max_pool, gnn_builder_lib.h:2709-2803; rows in order within a lane,
-        // lane groups combined pairwise)
-        if (wv < (1 << cs1l) && units > 0) {
-            auto m1 = [&](auto nutag) {
-                constexpr int NU = decltype(nutag)::value;
-                float v[NU][4];
-                g2_mma<ACT, KQ1, NU, false>(A1, lda1, 1, w1r, bias1, 0, 1, li, lg, v);
-                const int ngr = cur.gb - cur.ga;
-                // (one store instruction per graph and pool; none if the whole slice is past h1; the rare
-                // paths below that read global memory only make the count conservative -- see the wait)
-                stores_behind_dma = wv * 16 < h1 ? ngr * np : 0;
-                auto pool_graph = [&](int gi, int r0g, int r1g) { // wave-uniform row range of graph ga + gi
-                    r0g = __builtin_amdgcn_readfirstlane(r0g) - nb;
-                    r1g = min(__builtin_amdgcn_readfirstlane(r1g) - nb, G2_CAP);
-                    float sum = 0.0f, mx = -INFINITY;
-#pragma unroll
-                    for (int k = 0; k < NU; k++) {
-                        if (r1g > k * 16 && r0g < k * 16 + 16) { // uniform: the unit overlaps the graph
-#pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const int row = k * 16 + lg * 4 + r;
-                                const bool in = row >= r0g && row < r1g;
-                                sum += in ? v[k][r] : 0.0f;
-                                mx = fmaxf(mx, in ? v[k][r] : -INFINITY);
-                            }
-                        }
-                    }
-                    sum = rows4_sum(sum);
-                    mx = rows4_max(mx);
-                    const int n = r1g - r0g;
-                    if (lg == 0 && n1c < h1) {
-#pragma unroll
-                        for (int kk = 0; kk < 3; kk++) {
-                            if (kk >= np)
-                                break;
-                            float rr = sum;
-                            if (pools[kk] == GNNB_POOL_MEAN)
-                                rr = n > 0 ? sum / (float)n : 0.0f;
-                            else if (pools[kk] == GNNB_POOL_MAX)
-                                rr = n > 0 ? mx : 0.0f;
-                            pooled[((size_t)(cur.ga + gi) * np + kk) * h1 + n1c] = rr;
-                        }
-                    }
-                };
-                // two loops, not one with a choice inside: a select between the LDS table and global
-                // memory is if-converted into flat loads (+ a full vmcnt/lgkmcnt drain per graph)
-                const int nlds = min(ngr, 64);
-                for (int gi = 0; gi < nlds; gi++)
-                    pool_graph(gi, sgp[gi], sgp[gi + 1]);
-                for (int gi = nlds; gi < ngr; gi++) // a pile of empty graphs
-                    pool_graph(gi, node_ptr[cur.ga + gi], node_ptr[cur.ga + gi + 1]);
-            };
-            if (units == 3)
+            if (G2_UNITS > 3 && units == 4)
+                m1(IntTag<G2_UNITS>{});
+            else if (units == 3)
                 m1(IntTag<3>{});
             else if (units == 2)
                 m1(IntTag<2>{});
@@ -4251,71 +3833,25 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     const Options &o = options();
     if (!o.fuse_gcn2 || t.num_nodes <= 0)
         return hipErrorNotSupported;
-    if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > G2_CAP)
+    const int math = o.math ? 1 : 0;
+    const int cap = 16 * g2_units(math);
+    if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > cap)
         return hipErrorNotSupported; // no promise that whole graphs fit a stage
     if (f0 < 1 || f0 > 32 || !(h0 == 32 || h0 == 64 || h0 == 128) || h1 < 4 || h1 > 128 || (h1 & 3))
         return hipErrorNotSupported;
     if ((((uintptr_t)w1) & 15) || (((uintptr_t)pooled) & 15) || (((uintptr_t)x) & 3))
         return hipErrorNotSupported;
     // every stage must hold at least one tile: workgroups need ceil(T / grid) + 1 <= G2_TCAP table entries
-    const int math = o.math ? 1 : 0;
-    const int xs_b = ((G2_CAP * f0 * 4) + 15) & ~15;
-    const int in_b = xs_b + G2_CAP * 32 + G2_CAP * 4 + 272;
+    // (LDS carve: see the kernel)
+    const int xs_b = ((cap * f0 * 4) + 15) & ~15;
+    const int rows_b = xs_b + cap * 32, small_b = cap * 4 + 272;
     const int ldh = (h0 > h1 ? h0 : h1) + 4;
-    const size_t lds = 2 * (size_t)in_b + (size_t)G2_CAP * 16 * (f0 <= 16 ? 1 : 2) * 4 + (size_t)G2_CAP * ldh * 4 +
-                       (size_t)G2_CAP * (math ? 3 * (h0 * 2 + 16) : (h0 + 4) * 4) + (size_t)G2_CAP * 48 + 2 * (size_t)(G2_TCAP + 1) * 4;
+    const size_t a1_b = std::max((size_t)cap * (math ? 3 * (h0 * 2 + 16) : (h0 + 4) * 4), (size_t)cap * 16 * (f0 <= 16 ? 1 : 2) * 4);
+    const size_t lds = (size_t)rows_b + 2 * (size_t)small_b + (size_t)cap * ldh * 4 + a1_b + (size_t)cap * 48 +
+                       2 * (size_t)(G2_TCAP + 1) * 4;
     const int kq0 = f0 <= 16 ? 1 : 2, kq1 = h0 / 16;
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
     hipError_t rc = hipErrorNotSupported;
-    if (o.fuse_gcn2 >= 2 && !math) {
-        // aggregation on the matrix pipe (k_gcn2_mm)
-        const int ld0 = 16 * kq0 + 4, lda = G2_CAP + 4;
-        const size_t in_mm = (size_t)in_b + 256 * 4; // + the stage's CSR slice
-        const size_t lds_mm = 2 * in_mm + ((size_t)G2_CAP * ld0 + (size_t)h0 * lda + (size_t)G2_CAP * lda +
-                                           (size_t)G2_CAP * (h0 + 4)) * 4 + 3 * (size_t)(G2_TCAP + 1) * 4;
-        auto gomm = [&](auto atag, auto q0tag, auto q1tag) {
-            constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
-            auto kern = k_gcn2_mm<ACT, KQ0, KQ1>;
-            if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_mm) != hipSuccess) {
-                rc = hipErrorNotSupported;
-                return;
-            }
-            static size_t lds_set = 0;
-            static int blocks = 0, cus = 256;
-            if (lds_set != lds_mm) {
-                int nb = 0, devid = 0;
-                hipDeviceProp_t prop;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G2_WG, lds_mm) != hipSuccess || nb < 1)
-                    nb = 1;
-                if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
-                    cus = prop.multiProcessorCount;
-                blocks = nb > 2 ? 2 : nb;
-                lds_set = lds_mm;
-            }
-            long long grid = (long long)cus * blocks;
-            if (grid > t.num_tiles)
-                grid = t.num_tiles;
-            const long long min_grid = ((long long)t.num_tiles + G2_TCAP - 2) / (G2_TCAP - 1);
-            if (grid < min_grid) {
-                rc = hipErrorNotSupported;
-                return;
-            }
-            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_WG), lds_mm, s, x, f0, t.node_rec, t.col, t.dinv,
-                               t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes,
-                               t.num_edges, w0, b0, h0, w1, b1, h1, p0, p1, p2, num_pools, pooled);
-            rc = hipGetLastError();
-        };
-        auto gomm_q = [&](auto atag) {
-            if (kq0 == 1 && kq1 == 8) gomm(atag, IntTag<1>{}, IntTag<8>{});
-            else if (kq0 == 1 && kq1 == 4) gomm(atag, IntTag<1>{}, IntTag<4>{});
-            else if (kq0 == 1 && kq1 == 2) gomm(atag, IntTag<1>{}, IntTag<2>{});
-            else if (kq0 == 2 && kq1 == 8) gomm(atag, IntTag<2>{}, IntTag<8>{});
-            else if (kq0 == 2 && kq1 == 4) gomm(atag, IntTag<2>{}, IntTag<4>{});
-            else gomm(atag, IntTag<2>{}, IntTag<2>{});
-        };
-        GNNB_DISPATCH_ACT(act, gomm_q)
-        return rc;
-    }
     auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto mtag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
         constexpr int MATH = decltype(mtag)::value;

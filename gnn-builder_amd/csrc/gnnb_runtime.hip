@@ -208,7 +208,7 @@ int gnnb_set_option(const char *name, int value)
         o.agg_nt_store = value;
     else if (!strcmp(name, "fuse_narrow") && value >= 0 && value <= 1)
         o.fuse_narrow = value;
-    else if (!strcmp(name, "fuse_gcn2") && value >= 0 && value <= 2)
+    else if (!strcmp(name, "fuse_gcn2") && value >= 0 && value <= 1)
         o.fuse_gcn2 = value;
     else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
         o.fuse_head = value;
@@ -481,10 +481,12 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     t.max_graph_nodes_hint = ws->max_graph_nodes;
     t.tile_rows = std::max(options().tile_rows, 4);
     // A 2-layer GCN with a promise takes the fused stack only if a whole tile (tile_rows - 1 + largest graph) fits
-    // one 48-row stage: for graphs of 34..45 nodes finer tiles (8, 4) keep that path open
-    if (options().fuse_gcn2 && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && ws->max_graph_nodes > 0)
-        while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > GNNB_G2_STAGE_ROWS)
+    // one 64-row stage (48 in the bf16x6 mode): for graphs of 50..61 nodes finer tiles (8, 4) keep that path open
+    if (options().fuse_gcn2 && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && ws->max_graph_nodes > 0) {
+        const int stage_rows = options().math ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
+        while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > stage_rows)
             t.tile_rows >>= 1;
+    }
     t.num_tiles = (num_nodes + t.tile_rows - 1) / t.tile_rows;
     if (!(pna_delta > 0.0f))
         pna_delta = 1.0f;

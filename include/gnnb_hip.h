@@ -124,7 +124,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
 void gnnb_workspace_destroy(gnnb_workspace *ws);
 size_t gnnb_workspace_bytes(const gnnb_workspace *ws);
 /* Promise that no graph of the batches run on this workspace has more than `n` nodes (0 = no
- * promise, the default).  Small molecules (n <= 45) let whole graphs be staged in LDS, which enables
+ * promise, the default).  Small molecules (n <= 61; 45 in the opt-in bf16x6 math mode) let whole graphs be staged in LDS, which enables
  * the fused conv-stack kernels.  The promise is VALIDATED on the device by every graph prep: a
  * larger graph makes gnnb_workspace_check() return GNNB_ERR_GRAPH (the reference's MAX_NODES, by
  * contrast, is never checked: model.cpp.jinja:5-22). */

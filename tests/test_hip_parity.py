@@ -738,42 +738,6 @@ def test_random_multigraphs_match_oracle(dev, conv, layers, n_max, promise, seed
     assert np.abs(got - ref).max() < TOL * scale, (np.abs(got - ref).max(), scale)
 
 
-@pytest.mark.parametrize("fin,h0,h1,act", [(11, 128, 128, "relu"), (9, 64, 64, "tanh"), (20, 32, 128, "gelu"), (11, 128, 20, "sigmoid")])
-def test_fused_gcn_stack_with_aggregation_on_the_matrix_pipe(dev, fin, h0, h1, act):
-    """`fuse_gcn2` = 2 (k_gcn2_mm: the stage's dense normalised adjacency block in LDS, A_hat . x and A_hat . H as MFMA
-    products, built with LDS float atomics): against the oracle and the gather form (`fuse_gcn2` = 1) on molecule batches
-    and on random multigraphs (hubs beyond the four inline neighbour slots, duplicate edges, empty graphs, a graph of
-    exactly the promised size)."""
-    model = make_model("gcn", in_dim=fin, hidden=h0, layers=2, out_dim=h1, act=act, task_out=5)
-    rng = np.random.default_rng(fin + h0)
-    batches = [synthetic.make_batch("qm9", 300, seed=fin),
-               pack_graphs(_random_graphs(rng, 150, 33, fin, dense=4))]
-    if fin == 11:
-        q = batches[0]
-    else:
-        q = synthetic.make_batch("qm9", 300, seed=fin)
-        q = pack_graphs([(np.random.default_rng(g).uniform(-1, 1, (q.graph(g)[0].shape[0], fin)).astype(np.float32), q.graph(g)[1])
-                         for g in range(q.num_graphs)])
-    batches[0] = q
-    try:
-        for batch in batches:
-            promise = int(np.diff(batch.node_ptr).max())
-            ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
-            outs = {}
-            for variant in (2, 1):
-                runtime.set_option("fuse_gcn2", variant)
-                cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1),
-                                                      max_graph_nodes=promise)
-                outs[variant] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
-                cm.check()
-            scale = max(1.0, float(np.abs(ref).max()))
-            assert np.isfinite(outs[2]).all()
-            assert np.abs(outs[2] - ref).max() < TOL * scale
-            assert np.abs(outs[2] - outs[1]).max() < 2e-5 * scale
-    finally:
-        runtime.set_option("fuse_gcn2", 1)
-
-
 @pytest.mark.parametrize("M,N,K", [(3000, 128, 128), (777, 64, 64), (1000, 32, 32), (513, 64, 128)])
 def test_linear_bf16x6_math_is_fp32_equivalent(dev, M, N, K):
     """Opt-in math mode 1 in the register-resident-weight GEMM: six bf16 MFMA products of an exact 3-way
@@ -870,10 +834,11 @@ def test_linear_dma_tail_split_is_bit_identical(dev, M, N, K):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("promise", [34, 40, 45, 46])
-def test_fused_gcn_stack_takes_graphs_up_to_45_nodes(dev, promise):
-    """Graphs of 34..45 nodes still fit one 48-row stage when the node tiles are finer (8 or 4 rows): graph prep
-    picks the tile size from the promise.  46 is past the limit: the layer-by-layer path answers, same numbers."""
+@pytest.mark.parametrize("promise,math", [(34, 0), (50, 0), (55, 0), (57, 0), (58, 0), (61, 0), (62, 0), (41, 1), (45, 1), (46, 1)])
+def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math):
+    """Graphs of up to 57 nodes fit one 64-row stage with the default 8-row node tiles, up to 61 with 4-row tiles (graph
+    prep picks the tile size from the promise): ESOL-sized molecules (n_max 55) take the fused stack.  62 is past the
+    limit: the layer-by-layer path answers, same numbers.  The opt-in bf16x6 mode keeps 48-row stages (limit 45)."""
     model = make_model("gcn", in_dim=9, hidden=128, layers=2, out_dim=128, act="relu", pools=("add", "mean", "max"), task_out=4)
     rng = np.random.default_rng(promise)
     graphs = []
@@ -885,17 +850,47 @@ def test_fused_gcn_stack_takes_graphs_up_to_45_nodes(dev, promise):
     graphs.append((rng.uniform(-1, 1, (promise, 9)).astype(np.float32), np.zeros((0, 2), np.int32)))  # one of the largest size
     batch = pack_graphs(graphs)
     ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
-    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
+    try:
+        runtime.set_option("math", math)
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
+        got = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+        cm.check()
+        assert np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
+        # which path ran: the fused stack's timed entry refuses when it is not eligible
+        xd = torch.from_numpy(batch.x).to(dev)
+        if promise <= (45 if math else 61):
+            assert cm.gcn_stack_timed(xd, 2) > 0.0
+        else:
+            with pytest.raises(runtime.GnnbError):
+                cm.gcn_stack_timed(xd, 2)
+    finally:
+        runtime.set_option("math", 0)
+
+
+def test_config1_esol_takes_the_fused_stack(dev):
+    """BASELINE config 1 (2-layer GCN d=64, ESOL: graphs of up to 55 nodes) with the reference's MAX_NODES as the promise:
+    the 64-row stages take it on the fused stack (one graph of exactly 55 nodes included), same numbers as the oracle and as
+    the layer-by-layer path."""
+    model = make_model("gcn", in_dim=9, hidden=64, layers=2, out_dim=64, act="relu", pools=("add", "mean", "max"), task_out=1)
+    rng = np.random.default_rng(55)
+    base = synthetic.make_batch("esol", 600, seed=1)
+    graphs = [base.graph(g) for g in range(base.num_graphs)]
+    ring = np.stack([np.arange(55), (np.arange(55) + 1) % 55], 1)
+    graphs.insert(300, (rng.uniform(-1, 1, (55, 9)).astype(np.float32), np.concatenate([ring, ring[:, ::-1]]).astype(np.int32)))
+    batch = pack_graphs(graphs)
+    assert int(np.diff(batch.node_ptr).max()) == 55
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=55)
     got = cm.forward(*to_dev(batch, dev)).cpu().numpy()
     cm.check()
+    assert cm.gcn_stack_timed(torch.from_numpy(batch.x).to(dev), 2) > 0.0          # the fused stack is what ran
     assert np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
-    # which path ran: the fused stack's timed entry refuses when it is not eligible
-    xd = torch.from_numpy(batch.x).to(dev)
-    if promise <= 45:
-        assert cm.gcn_stack_timed(xd, 2) > 0.0
-    else:
-        with pytest.raises(runtime.GnnbError):
-            cm.gcn_stack_timed(xd, 2)
+    try:
+        runtime.set_option("fuse_gcn2", 0)
+        lw = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+        assert np.abs(lw.forward(*to_dev(batch, dev)).cpu().numpy() - got).max() < 2e-5 * max(1.0, float(np.abs(ref).max()))
+    finally:
+        runtime.set_option("fuse_gcn2", 1)
 
 
 # --------------------------------------------------------------------------- BASELINE configs 3, 4, 5 at full size
