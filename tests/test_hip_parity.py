@@ -867,6 +867,40 @@ def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math):
         runtime.set_option("math", 0)
 
 
+@pytest.mark.parametrize("conv,shape,promise", [("gcn", "qm9", True), ("gin", "molhiv", False), ("pna", "qm9", False)])
+def test_forward_is_graph_capturable(dev, conv, shape, promise):
+    """The whole batched forward (graph prep included) is enqueued on the caller's stream without host synchronisation,
+    allocation or host-side reads: it can be captured into a HIP graph and replayed.  The replay on NEW inputs written
+    into the captured buffers gives the oracle's numbers (fused GCN stack and layer-by-layer paths)."""
+    fin = synthetic.SHAPES[shape]["f_in"]
+    model = make_model(conv, in_dim=fin, hidden=64, layers=2, out_dim=64, act="relu", pools=("add", "max"), task_out=3)
+    b0, b1 = synthetic.make_batch(shape, 96, seed=1), synthetic.make_batch(shape, 96, seed=2)
+    # the captured buffers are sized for the larger batch; graph boundaries / sizes of a replay must equal the capture's,
+    # so the second batch reuses the first one's topology with new features
+    x1 = np.random.default_rng(5).uniform(-1, 1, b0.x.shape).astype(np.float32)
+    kw = dict(max_graph_nodes=int(np.diff(b0.node_ptr).max())) if promise else {}
+    cm = runtime.CompiledModel.from_model(model, b0.num_graphs, b0.num_nodes, b0.num_edges, **kw)
+    xd, coo, nptr, eptr = to_dev(b0, dev)
+    out = torch.empty((b0.num_graphs, cm.out_dim), dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        cm.forward(xd, coo, nptr, eptr, out=out)          # warm-up outside the capture (kernel attributes, caches)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cm.forward(xd, coo, nptr, eptr, out=out)
+    for xs in (b0.x, x1):
+        xd.copy_(torch.from_numpy(xs))
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ref = O.forward_batched(model.spec(), canon(model), xs, b0.coo, b0.node_ptr, b0.edge_ptr)
+        assert np.abs(out.cpu().numpy() - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
+    cm.check()
+
+
 def test_config1_esol_takes_the_fused_stack(dev):
     """BASELINE config 1 (2-layer GCN d=64, ESOL: graphs of up to 55 nodes) with the reference's MAX_NODES as the promise:
     the 64-row stages take it on the fused stack (one graph of exactly 55 nodes included), same numbers as the oracle and as
