@@ -825,6 +825,7 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
     }
 
     const int gw = gnn_out_width(d);
+    bool pooled_done = false;
     if (!fpx) {
         // fused readout (pooling + whole MLP head, one launch) when the head fits LDS
         HeadArgs head;
@@ -855,9 +856,23 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
                 return GNNB_OK;
             if (he != hipErrorNotSupported)
                 return fail(GNNB_ERR_HIP, "fused readout launch failed: %s", hipGetErrorString(he));
+            // The head's weights do not fit LDS (SAGE d = 256 with three pools: 768 x 64 floats): pooling pass, then
+            // the small readout that takes its weights from L2 as MFMA operands -- one launch over B / 16 workgroups
+            // instead of a chain of GEMMs with M = B rows (64 workgroups of the 128-row tile at B = 8192: 51 us)
+            if (!options().head_split && options().head_small) {
+                if ((rc = gnnb_global_pool(ws, cur, gw, d.pools, d.num_pools, ws->pooled, stream)))
+                    return rc;
+                he = launch_pool_mlp(nullptr, ws->t.graph_ptr, B, gw, d.pools, d.num_pools, head, d.mlp_activation, out_dev,
+                                     (hipStream_t)stream, ws->pooled);
+                if (he == hipSuccess)
+                    return GNNB_OK;
+                if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "readout launch failed: %s", hipGetErrorString(he));
+                pooled_done = true;
+            }
         }
     }
-    if ((rc = gnnb_global_pool(ws, cur, gw, d.pools, d.num_pools, ws->pooled, stream)))
+    if (!pooled_done && (rc = gnnb_global_pool(ws, cur, gw, d.pools, d.num_pools, ws->pooled, stream)))
         return rc;
     if ((rc = quant(ws->pooled, (size_t)B * d.num_pools * gw)))
         return rc;
