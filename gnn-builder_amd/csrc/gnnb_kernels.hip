@@ -1453,6 +1453,50 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 }
 
 
+// ---- fp32 product through the bf16 matrix cores ("bf16x6").  x = h + m + l EXACTLY, each piece a bf16
+// (8 significant bits each: truncate, subtract, truncate, subtract -- every step is exact in fp32), so
+// a.b = sum of nine bf16 x bf16 products, each exact in fp32.  The six with i + j <= 2 are kept
+// (hh, hm, mh, hl, lh, mm); the three dropped ones are below 2^-24 |a||b|, i.e. below what fp32 resolves of
+// the product.  Accumulation is fp32 inside v_mfma_f32_16x16x32_bf16.  Cost: 6 MFMA of 4 passes per
+// 32-wide k block instead of 8 fp32 MFMA of 8 passes -- 2.4x fewer pipe cycles, and fp32 MFMA runs at
+// the vector-FMA rate on this chip (tools/micro/mfma_valu_overlap.hip).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m)); // <= 8 significant bits left: its upper half is exact
+}
+// two fp32 bit patterns -> their upper halves packed as {bf16(a) in bits 0..15, bf16(b) in bits 16..31}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v)
+{
+    union {
+        u32x4 u;
+        bf16x8 b;
+    } c;
+    c.u = v;
+    return c.b;
+}
+
+// split 8 consecutive fp32 values (two float4) into the three bf16x8 pieces of an MFMA operand
+__device__ __forceinline__ void split3x8(const float4 &f0, const float4 &f1, u32x4 &h, u32x4 &m, u32x4 &l)
+{
+    const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split3(v[2 * i], h0, m0, l0);
+        split3(v[2 * i + 1], h1, m1, l1);
+        h[i] = pack_hi16(h0, h1);
+        m[i] = pack_hi16(m0, m1);
+        l[i] = pack_hi16(l0, l1);
+    }
+}
+
+
 // -------------------------------------------------------------------------------------
 // LDS-DMA form of the tiled GEMM above for the regular case -- rows 16-B aligned, segment widths whole
 // 32-wide chunks (GraphSAGE at d = 256: [mean | x] . [Wl | Wr]^T, K = 2 x 256; PNA at d = 128: 13 x 128 with
@@ -1469,6 +1513,10 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 // 128-B line per row and chunk) -- see the note on compiler-tracked loads in the item body.
 static constexpr int DM = 128, DN = 128, DWG = 256, DNBUF = 2, DNW = DWG / 64, DWGPC = 2;
 static constexpr int DBUF_B = (DM + DN) * BK * 4; // 32 KB: A chunk | W chunk
+// MATH 1 (opt-in, gnnb_set_option("math", 1)): the same chunks, but each 16-wide k block is multiplied as six
+// v_mfma_f32_32x32x16_bf16 products of an exact 3-way bf16 split of BOTH operands (see split3), the fragments split in
+// the wave after the LDS read -- 24 MFMA of 8 passes instead of 32 of 16 per k block and accumulator quartet.
+template <int MATH>
 __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__restrict__ W, int ldw,
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ skip, float *__restrict__ Y, int M,
@@ -1651,6 +1699,46 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             s[mi] = sc[sgm][mi];
                         scaled = g.rs[sgm] != nullptr;
                     }
+                if (MATH) {
+                    // lane (li, lh) of a 32x32x16 bf16 MFMA holds k = 8 lh .. + 7 of row / column li for both operands:
+                    // two 16-B pieces per fragment and k block
+#pragma unroll
+                    for (int kb2 = 0; kb2 < BK / 16; kb2++) {
+                        u32x4 ah[MC > 0 ? MC : 1], am[MC > 0 ? MC : 1], al[MC > 0 ? MC : 1], wh[NT], wm[NT], wl[NT];
+                        const int piece = 4 * kb2 + 2 * lh;
+#pragma unroll
+                        for (int mi = 0; mi < MC; mi++) {
+                            const int r = rbase + mi * 32 + li;
+                            float4 f0 = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
+                            float4 f1 = *reinterpret_cast<const float4 *>(a + r * BK + (((piece + 1) ^ (r & 7)) << 2));
+                            if (scaled) {
+                                f0.x *= s[mi], f0.y *= s[mi], f0.z *= s[mi], f0.w *= s[mi];
+                                f1.x *= s[mi], f1.y *= s[mi], f1.z *= s[mi], f1.w *= s[mi];
+                            }
+                            split3x8(f0, f1, ah[mi], am[mi], al[mi]);
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < NT; ni++) {
+                            const int r = wn * 32 * NT + ni * 32 + li;
+                            const float4 f0 = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
+                            const float4 f1 = *reinterpret_cast<const float4 *>(b + r * BK + (((piece + 1) ^ (r & 7)) << 2));
+                            split3x8(f0, f1, wh[ni], wm[ni], wl[ni]);
+                        }
+                        issue_part(ic, 2 * kb2);
+                        issue_part(ic, 2 * kb2 + 1);
+                        // six partial products, smallest first; W piece first (swapped operands, float4 epilogue)
+#define GNNB_DMA_BF6(WP, AP)                                                                                       \
+    _Pragma("unroll") for (int mi = 0; mi < MC; mi++) _Pragma("unroll") for (int ni = 0; ni < NT; ni++)             \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(WP[ni]), as_bf16x8(AP[mi]), acc[mi][ni], 0, 0, 0);
+                        GNNB_DMA_BF6(wm, am)
+                        GNNB_DMA_BF6(wh, al)
+                        GNNB_DMA_BF6(wl, ah)
+                        GNNB_DMA_BF6(wh, am)
+                        GNNB_DMA_BF6(wm, ah)
+                        GNNB_DMA_BF6(wh, ah)
+#undef GNNB_DMA_BF6
+                    }
+                } else {
                 // (requesting the fragments of k step j + 1 before the MFMAs of step j -- two register sets -- was
                 // measured: 601 vs 583 us at the C4 shape)
 #pragma unroll
@@ -1684,6 +1772,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].z, fa[mi].z, acc[mi][ni], 0, 0, 0);
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa[mi].w, acc[mi][ni], 0, 0, 0);
                         }
+                }
                 }
             }
             // the marks move on: mk0 = the chunk multiplied next
@@ -1792,49 +1881,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define GNNB_LR_COUNTED_WAIT "s_waitcnt vmcnt(" GNNB_STR(GNNB_LR_NSTORES) ") lgkmcnt(0)\n\ts_barrier"
 
-
-// ---- fp32 product through the bf16 matrix cores ("bf16x6").  x = h + m + l EXACTLY, each piece a bf16
-// (8 significant bits each: truncate, subtract, truncate, subtract -- every step is exact in fp32), so
-// a.b = sum of nine bf16 x bf16 products, each exact in fp32.  The six with i + j <= 2 are kept
-// (hh, hm, mh, hl, lh, mm); the three dropped ones are below 2^-24 |a||b|, i.e. below what fp32 resolves of
-// the product.  Accumulation is fp32 inside v_mfma_f32_16x16x32_bf16.  Cost: 6 MFMA of 4 passes per
-// 32-wide k block instead of 8 fp32 MFMA of 8 passes -- 2.4x fewer pipe cycles, and fp32 MFMA runs at
-// the vector-FMA rate on this chip (tools/micro/mfma_valu_overlap.hip).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l)
-{
-    h = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xffff0000u;
-    l = __float_as_uint(r1 - __uint_as_float(m)); // <= 8 significant bits left: its upper half is exact
-}
-// two fp32 bit patterns -> their upper halves packed as {bf16(a) in bits 0..15, bf16(b) in bits 16..31}
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v)
-{
-    union {
-        u32x4 u;
-        bf16x8 b;
-    } c;
-    c.u = v;
-    return c.b;
-}
-
-// split 8 consecutive fp32 values (two float4) into the three bf16x8 pieces of an MFMA operand
-__device__ __forceinline__ void split3x8(const float4 &f0, const float4 &f1, u32x4 &h, u32x4 &m, u32x4 &l)
-{
-    const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        uint32_t h0, m0, l0, h1, m1, l1;
-        split3(v[2 * i], h0, m0, l0);
-        split3(v[2 * i + 1], h1, m1, l1);
-        h[i] = pack_hi16(h0, h1);
-        m[i] = pack_hi16(m0, m1);
-        l[i] = pack_hi16(l0, l1);
-    }
-}
 
 // Optional fused gather: when `rec` is set the A stage is not copied from memory but PRODUCED -- the
 // workgroup aggregates its destination rows (GCN / sum / mean semantics of k_aggregate_*) from the
@@ -2605,7 +2651,7 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
         if (plain) {
             const size_t lds = (size_t)DNBUF * DBUF_B;
             {
-                hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_linear_dma), lds);
+                hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(options().math ? k_linear_dma<1> : k_linear_dma<0>), lds);
                 if (e != hipSuccess)
                     return e;
             }
@@ -2626,8 +2672,12 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
                 split = 4 * rem <= DWGPC * num_cus ? 4 : (2 * rem <= DWGPC * num_cus ? 2 : 1);
             const int split_from = split > 1 ? tiles - rem : tiles;
             const int grid = std::min(split_from + split * (tiles - split_from), DWGPC * num_cus);
-            hipLaunchKernelGGL(k_linear_dma, dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, tn,
-                               split_from, split);
+            if (options().math)
+                hipLaunchKernelGGL(k_linear_dma<1>, dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, tn,
+                                   split_from, split);
+            else
+                hipLaunchKernelGGL(k_linear_dma<0>, dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, tn,
+                                   split_from, split);
             return hipGetLastError();
         }
     }

@@ -758,6 +758,35 @@ def test_linear_bf16x6_math_is_fp32_equivalent(dev, M, N, K):
     assert e_split < 2e-6 and e_split < 2.0 * e_exact + 1e-7, (e_split, e_exact)
 
 
+@pytest.mark.parametrize("M,N,F", [(4000, 256, 32), (70000, 128, 32), (2000, 200, 64)])
+def test_large_k_gemm_bf16x6_math_is_fp32_equivalent(dev, M, N, F):
+    """Opt-in math mode 1 in the LDS-DMA GEMM (the SAGE / PNA shapes): four segments of width F .. 4F, two of them
+    row-scaled (the PNA update), bias + skip + tanh; six v_mfma_f32_32x32x16_bf16 products of an exact 3-way split of both
+    operands per 16-wide k block.  Against a float64 product it must be as good as the native fp32-MFMA kernel; tail
+    slices (M = 70 000: 547 tiles) included."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.rand(M, F, generator=g) - 0.5
+    A = torch.rand(M, 4 * F, generator=g) - 0.5
+    amp, att = torch.rand(M, generator=g) + 0.5, torch.rand(M, generator=g) + 0.5
+    w = (torch.rand(N, 13 * F, generator=g) - 0.5) / (13 * F) ** 0.5
+    b, skip = torch.rand(N, generator=g), torch.rand(M, N, generator=g) - 0.5
+    rows = torch.cat([torch.arange(0, min(M, 3000)), torch.arange(max(M - 3000, 0), M)])
+    cat = torch.cat([x, A, A * amp[:, None], A * att[:, None]], 1)[rows].double()
+    ref = torch.tanh(cat @ w.double().T + b.double() + skip[rows].double())
+    Ad = A.to(dev)
+    segs = [(x.to(dev), None), (Ad, None), (Ad, amp.to(dev)), (Ad, att.to(dev))]
+    wd, bd, sd = w.to(dev), b.to(dev), skip.to(dev)
+    try:
+        runtime.set_option("math", 1)
+        split = runtime.linear(segs, wd, bd, skip=sd, act="tanh").cpu()
+    finally:
+        runtime.set_option("math", 0)
+    exact = runtime.linear(segs, wd, bd, skip=sd, act="tanh").cpu()
+    e_split = (split[rows].double() - ref).abs().max().item()
+    e_exact = (exact[rows].double() - ref).abs().max().item()
+    assert e_split < 2e-6 and e_split < 2.0 * e_exact + 1e-7, (e_split, e_exact)
+
+
 @pytest.mark.parametrize("mlp_hidden,mlp_layers,task_out,pools,h1", [
     (64, 2, 19, ("add", "mean", "max"), 128), (16, 1, 1, ("max",), 64), (128, 3, 33, ("add", "max"), 32),
     (50, 2, 7, ("mean",), 64), (64, 0, 5, ("add", "mean", "max"), 20), (100, 2, 3, ("add",), 128)])
