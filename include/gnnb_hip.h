@@ -245,10 +245,16 @@ void gnnb_free(void *dev);
 int gnnb_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
 int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
 
-/* tuning knobs (also read from the environment at load: GNNB_TILE_ROWS, GNNB_AGG_LDS_KB, ...).
- * "math": 0 (default) = native fp32 MFMA everywhere; 1 = the wide update of the fused GCN stack and the
- * K <= 128 GEMMs as six bf16 MFMA products of an exact 3-way bf16 split of both fp32 operands, fp32
- * accumulate (results at fp32 rounding level; GNNB_MATH=1). */
+/* tuning knobs (also read from the environment at load as GNNB_<NAME>): they select between parity-tested forms of the
+ * same computation and never change results beyond fp32 rounding.
+ *   tile_rows (>= 4, default 8)  node-tile size of graph prep         agg_lds_kb, agg_ring_waves / _slots / _wg_per_cu,
+ *   agg_nt_store                 launch shape of the gather-aggregate  gemm_variant, gemm_dma, gemm_tail_split,
+ *   gemm_wlds, gemm_wlds_slots, gemm_max_wg_per_cu  which GEMM kernel   fuse_narrow, fuse_gcn2, fuse_head, head_small,
+ *   head_split                   which launches are fused (0 = layer by layer / separate readout)
+ * "math": 0 (default) = native fp32 MFMA everywhere; 1 = every wide update (the fused GCN stack's A1.W1^T, the
+ * K <= 128 GEMMs, the large-K segmented GEMM) as six bf16 MFMA products of an exact 3-way bf16 split of both fp32
+ * operands, fp32 accumulate (results at fp32 rounding level; GNNB_MATH=1).  Unknown names or values
+ * out of range return GNNB_ERR_INVALID. */
 int gnnb_set_option(const char *name, int value);
 
 #ifdef __cplusplus
