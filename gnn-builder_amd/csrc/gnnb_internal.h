@@ -25,6 +25,7 @@ struct BatchTables {
     int32_t *tile_graph; // [T+1] index of the graph that starts at tile_first[t] (B past the end)
     int32_t max_graph_nodes_hint; // caller's promise (0 = unknown); validated on device by prep
     int32_t *err;        // [1]   != 0 when the batch was malformed
+    int32_t *err_host_dev; // device-visible address of the host-mapped copy of "flagged" (nullptr: none)
     const int32_t *node_ptr; // [B+1] caller's graph_node_ptr (device): read by graph prep ONLY
     int32_t *graph_ptr;      // [B+1] the same clamped to [0, N] by graph prep: what every later kernel reads, so
                              //       that a malformed node_ptr cannot send a pooling loop out of the buffers

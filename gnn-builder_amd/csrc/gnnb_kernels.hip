@@ -84,10 +84,22 @@ __device__ unsigned long long g_probe[16 * 8192];
 static constexpr int PREP_REG_CHUNKS = 4;
 
 // General path (any graph size): lane = destination node, edges scanned one at a time.
+
+// Batch-validation flag: the authoritative word lives in device memory (read and reset by gnnb_workspace_check); a
+// copy of "something was flagged" is also dropped into a host-mapped word, which the NEXT entry call on the workspace
+// reads without synchronising (lazy detection for callers that never call the check).
+__device__ __forceinline__ void flag_batch(int32_t *err, int32_t *err_host, int bits)
+{
+    atomicOr(err, bits);
+    if (err_host)
+        *reinterpret_cast<volatile int32_t *>(err_host) = bits;
+}
+
 __device__ void prep_graph_scan(
     const int2 *__restrict__ coo, int n0, int n1, int e0, int e1, int32_t *__restrict__ row_ptr,
     int32_t *__restrict__ col, int32_t *__restrict__ eid, int4 *__restrict__ node_rec, float *__restrict__ dinv,
-    float *__restrict__ amp, float *__restrict__ att, float delta, int drop_self, int32_t *__restrict__ err)
+    float *__restrict__ amp, float *__restrict__ att, float delta, int drop_self, int32_t *__restrict__ err,
+    int32_t *__restrict__ err_host)
 {
     const int lane = threadIdx.x & 63;
 
@@ -212,7 +224,7 @@ __device__ void prep_graph_scan(
         base += __shfl(incl, 63, 64);
     }
     if (bad)
-        atomicOr(err, 4);
+        flag_batch(err, err_host, 4);
 }
 
 
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     float *__restrict__ amp, float *__restrict__ att, float delta,
     int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int32_t *__restrict__ tile_graph,
     int32_t *__restrict__ graph_ptr, int tile_rows, int num_tiles, int max_graph_nodes_hint, int drop_self,
-    int32_t *__restrict__ err)
+    int32_t *__restrict__ err, int32_t *__restrict__ err_host)
 {
     __shared__ int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node
     const int lane = threadIdx.x & 63;
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         if (lane == 0) {
             row_ptr[N] = E;
             if (last != N || edge_ptr[B] != E || first != 0 || edge_ptr[0] != 0)
-                atomicOr(err, 1);
+                flag_batch(err, err_host, 1);
         }
         if (first > 0)
             empty_rows(0, min(first, N));
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     int e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
     if (n0 > n1 || e0 > e1 || n1 > N || e1 > E || n0 < 0 || e0 < 0) {
         if (lane == 0)
-            atomicOr(err, 2);
+            flag_batch(err, err_host, 2);
         n0 = min(max(n0, 0), N);
         n1 = min(max(n1, 0), N);
         e0 = min(max(e0, 0), E);
@@ -309,9 +321,9 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     }
     const int n = n1 - n0, ne = e1 - e0;
     if (max_graph_nodes_hint > 0 && n > max_graph_nodes_hint && lane == 0)
-        atomicOr(err, 8); // the caller's max_graph_nodes promise does not hold for this batch
+        flag_batch(err, err_host, 8); // the caller's max_graph_nodes promise does not hold for this batch
     if (n > PREP_FAST_NODES || ne > PREP_FAST_EDGES) { // wave-uniform
-        prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, eid, node_rec, dinv, amp, att, delta, drop_self, err);
+        prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, eid, node_rec, dinv, amp, att, delta, drop_self, err, err_host);
         return;
     }
 
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     }
     GNNB_STAMP_END(3);
     if (bad)
-        atomicOr(err, 4);
+        flag_batch(err, err_host, 4);
 }
 
 hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
@@ -455,12 +467,12 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
         hipLaunchKernelGGL(k_graph_prep<64>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err);
+                           t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err, t.err_host_dev);
     else
         hipLaunchKernelGGL(k_graph_prep<256>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err);
+                           t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err, t.err_host_dev);
     return hipGetLastError();
 }
 

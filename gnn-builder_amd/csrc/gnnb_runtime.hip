@@ -164,6 +164,7 @@ struct gnnb_workspace {
     bool prepared = false;
     int max_graph_nodes = 0; // caller's promise (0 = none)
     int device = 0;
+    int32_t *err_host = nullptr; // host-mapped word the prep kernel drops "flagged" into (lazy detection, see gnnb_graph_prep)
     char *stage = nullptr;   // device staging of the host-buffer entry (x | coo | node_ptr | edge_ptr | out), sized for
     size_t stage_bytes = 0;  // the workspace's capacities; allocated by the first gnnb_forward_batched_host call
 };
@@ -435,6 +436,17 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->mlp[0] = (float *)(b + o_m0);
     ws->mlp[1] = (float *)(b + o_m1);
     (void)hipMemset(ws->t.err, 0, sizeof(int32_t));
+    // best effort: without the mapped word only gnnb_workspace_check reports a malformed batch
+    ws->t.err_host_dev = nullptr;
+    if (hipHostMalloc((void **)&ws->err_host, 64, hipHostMallocMapped) == hipSuccess && ws->err_host) {
+        *ws->err_host = 0;
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, ws->err_host, 0) == hipSuccess)
+            ws->t.err_host_dev = (int32_t *)dp;
+    } else {
+        ws->err_host = nullptr;
+        (void)hipGetLastError();
+    }
     *out_ws = ws;
     return GNNB_OK;
 }
@@ -447,6 +459,8 @@ void gnnb_workspace_destroy(gnnb_workspace *ws)
         (void)hipFree(ws->blob);
     if (ws->stage)
         (void)hipFree(ws->stage);
+    if (ws->err_host)
+        (void)hipHostFree(ws->err_host);
     delete ws;
 }
 
@@ -473,6 +487,14 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
         return fail(GNNB_ERR_CAPACITY,
                     "batch (%d graphs, %d nodes, %d edges) exceeds workspace (%d, %d, %d)",
                     num_graphs, num_nodes, num_edges, ws->max_graphs, ws->max_nodes, ws->max_edges);
+    // lazy detection: a batch prepared EARLIER on this workspace was flagged on the device (edge leaving its graph,
+    // broken ptr arrays, broken max_graph_nodes promise) and nobody called gnnb_workspace_check since.  Read from a
+    // host-mapped word without synchronising: it reports what has already run, never the batch being enqueued now.
+    if (ws->err_host && *(volatile int32_t *)ws->err_host != 0) {
+        *(volatile int32_t *)ws->err_host = 0;
+        return fail(GNNB_ERR_GRAPH, "an earlier batch on this workspace was flagged as malformed (its results were "
+                                    "unspecified); gnnb_workspace_check reports and clears the flags");
+    }
     BatchTables &t = ws->t;
     t.node_ptr = node_ptr_dev;
     t.num_graphs = num_graphs;
@@ -513,6 +535,8 @@ int gnnb_workspace_check(gnnb_workspace *ws, void *stream)
         (void)hipMemsetAsync(ws->t.err, 0, sizeof(int32_t), (hipStream_t)stream); // reset on read
         (void)hipStreamSynchronize((hipStream_t)stream);
     }
+    if (ws->err_host)
+        *(volatile int32_t *)ws->err_host = 0;
     if (err != 0)
         return fail(GNNB_ERR_GRAPH, "malformed batch (flags 0x%x): ptr arrays not monotone/complete, "
                                     "or an edge leaves its graph", err);

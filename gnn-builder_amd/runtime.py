@@ -281,7 +281,9 @@ class CompiledModel:
         """All arguments are torch CUDA tensors (fp32 / int32, contiguous; ``coo`` is [E, 2] (src, dst) rows, NOT a PyG
         ``edge_index`` [2, E] -- transpose it); returns ``out`` [B, mlp_out].  Asynchronous on the current torch stream.
         With a ``max_graph_nodes`` promise set, call ``check()`` on the batch: a broken promise is flagged there, and
-        the results of a flagged batch are unspecified."""
+        the results of a flagged batch are unspecified.  Without a ``check()`` the flag still surfaces: the next call
+        on this workspace after a flagged batch has run raises ``GnnbError`` ("an earlier batch ...", no synchronisation,
+        best effort)."""
         import torch
         self._check_batch(x, coo, node_ptr, edge_ptr)
         B = int(node_ptr.numel()) - 1

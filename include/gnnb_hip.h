@@ -127,7 +127,9 @@ size_t gnnb_workspace_bytes(const gnnb_workspace *ws);
  * promise, the default).  Small molecules (n <= 61; 45 in the opt-in bf16x6 math mode) let whole graphs be staged in LDS, which enables
  * the fused conv-stack kernels.  The promise is VALIDATED on the device by every graph prep: a
  * larger graph makes gnnb_workspace_check() return GNNB_ERR_GRAPH (the reference's MAX_NODES, by
- * contrast, is never checked: model.cpp.jinja:5-22). */
+ * contrast, is never checked: model.cpp.jinja:5-22).  Callers that never call the check still find out: the NEXT
+ * gnnb_graph_prep / gnnb_forward_batched on the workspace after a flagged batch has run returns GNNB_ERR_GRAPH
+ * (read from a host-mapped word, no synchronisation; best effort -- the check is the authoritative answer). */
 int gnnb_workspace_set_max_graph_nodes(gnnb_workspace *ws, int n);
 
 /* ------------------------------------------------------------------ batched forward

@@ -233,6 +233,28 @@ def test_malformed_batch_is_reported(dev):
         cm.check()
 
 
+def test_flagged_batch_is_reported_lazily_without_a_check(dev):
+    """A caller that never calls check(): the forward after a flagged batch has RUN raises (host-mapped flag read without
+    synchronisation); check() then reports and clears the device-side flags, and the workspace works again.  Covers a
+    broken max_graph_nodes promise on the fused GCN stack, the case the advisor singled out."""
+    model = make_model("gcn", in_dim=11, hidden=32, layers=2, task_out=1)
+    good = synthetic.make_batch("qm9", 64, seed=0)
+    cm = runtime.CompiledModel.from_model(model, good.num_graphs, good.num_nodes, good.num_edges,
+                                          max_graph_nodes=int(np.diff(good.node_ptr).max()) - 3)   # promise too small
+    args = to_dev(good, dev)
+    cm.forward(*args)                    # runs (contained), flags the batch on the device
+    torch.cuda.synchronize()
+    with pytest.raises(runtime.GnnbError, match="earlier batch"):
+        cm.forward(*args)
+    with pytest.raises(runtime.GnnbError, match="malformed batch"):
+        cm.check()
+    cm.set_max_graph_nodes(int(np.diff(good.node_ptr).max()))
+    out = cm.forward(*args).cpu().numpy()
+    cm.check()
+    ref = O.forward_batched(model.spec(), canon(model), good.x, good.coo, good.node_ptr, good.edge_ptr)
+    assert np.abs(out - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
+
+
 def test_capacity_is_checked(dev):
     batch = synthetic.make_batch("qm9", 8, 0)
     cm = runtime.CompiledModel.from_model(plain_model("gcn", 11, 8), 4, batch.num_nodes, batch.num_edges)
