@@ -1518,11 +1518,12 @@ __device__ __forceinline__ void split3x8(const float4 &f0, const float4 &f1, u32
 // are XOR-swizzled through the DMA *source* address (slot = piece ^ (row & 7)), which keeps the ds_read_b128
 // fragment reads conflict-free.
 //
-// Shape: two 4-wave workgroups per CU (they fill each other's barrier gaps: ONE 8-wave workgroup with a 256 x 128
-// tile and a three-deep chunk ring was built and measured -- 696 vs 600 us at the C4 shape, every barrier idles
-// the whole CU), 128 x 128 output tile, two chunk buffers.  Measured: without its chunk DMA the kernel runs at 84 %
-// of the fp32 MFMA peak, with it at 65 %: a chunk requested one chunk ahead lands late (A comes from HBM, one
-// 128-B line per row and chunk) -- see the note on compiler-tracked loads in the item body.
+// Shape: two 4-wave workgroups per CU (they fill each other's barrier gaps), 128 x 128 output tile, two chunk buffers;
+// the constants below also express the other shape that was built and measured -- ONE 8-wave workgroup per CU, 256 x
+// 128 tile, three-deep chunk ring (DM 256, DWG 512, DNBUF 3, DWGPC 1): 579 / 544 us against 592 / 535 us at the C4 /
+// C5 shapes, a wash, every barrier idles the whole CU.  What mattered was in the generated code: without its chunk DMA
+// the kernel ran at 84 % of the fp32 MFMA peak, with it at 65 % -- see the note on compiler-tracked loads in the item
+// body.
 static constexpr int DM = 128, DN = 128, DWG = 256, DNBUF = 2, DNW = DWG / 64, DWGPC = 2;
 static constexpr int DBUF_B = (DM + DN) * BK * 4; // 32 KB: A chunk | W chunk
 // MATH 1 (opt-in, gnnb_set_option("math", 1)): the same chunks, but each 16-wide k block is multiplied as six
