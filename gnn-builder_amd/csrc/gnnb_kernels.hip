@@ -250,6 +250,11 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     int32_t *__restrict__ err, int32_t *__restrict__ err_host)
 {
     __shared__ int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node
+    // Highest wave priority: with batches in flight on several streams this kernel runs BESIDE the conv-stack kernel of
+    // another batch (one wave slot per SIMD is left over there) and sits on its own stream's critical path -- 37-53 us
+    // instead of 7 when it queues behind sixteen MFMA-issuing waves per CU.  It is a few hundred instructions per wave;
+    // letting them issue first costs the big kernel nothing measurable (C2 step 55.5 -> 54.0 us).
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = blockIdx.x * (WG / 64) + wave;
@@ -3090,6 +3095,7 @@ __global__ __launch_bounds__(HS_THREADS, 5) void k_head_small(const float *__res
                                                              float *__restrict__ out, int ldact)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __builtin_amdgcn_s_setprio(3); // (co-runs with the next batch's conv-stack kernel: see k_graph_prep)
     float *sact = reinterpret_cast<float *>(smem); // [2][16][ldact]: ldact = widest hidden layer + 4 (padded rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
