@@ -107,9 +107,17 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
 // Whole 2-layer GCN conv stack + pooling in one persistent launch (graphs staged once in LDS):
 // x -> agg -> W0 -> act -> agg -> W1 -> act -> pooled [B, np*h1].  hipErrorNotSupported when the
 // model / batch does not qualify (caller runs the layer-by-layer path).
+// layers between the first and the last of a fused GCN stack (width h0 -> h0): layer l's weight at wmid + (l - 1) *
+// mid_stride floats, its bias at bmid + (l - 1) * bmid_stride; nl = number of conv layers (2: no middle layers)
+struct G2Deep {
+    int nl = 2;
+    const float *wmid = nullptr, *bmid = nullptr;
+    long mid_stride = 0, bmid_stride = 0;
+    int skip = 0;
+};
 hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                              int h0, const float *w1, const float *b1, int h1, int act,
-                             const int32_t *pools, int num_pools, float *pooled, hipStream_t s);
+                             const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const G2Deep &deep = G2Deep{});
 
 // dst = src put on the ap_fixed<W, I> grid (truncate, wrap); dst may alias src
 hipError_t launch_quantize(const float *src, float *dst, size_t n, int W, int I, hipStream_t s);

@@ -3406,14 +3406,21 @@ __device__ __forceinline__ void g2_mma_bf6(const char *__restrict__ planes, int 
             v[k][r] = act_t<ACT>(acc[k][r] + bias);
 }
 
-template <int ACT, int KQ0, int KQ1, int MATH>
+// DEEP: stacks of MORE than two GCN layers (reference compute_gnn_head loops any number of layers,
+// model.cpp.jinja:151-359).  The middle layers l = 1 .. nl-2 (width h0 -> h0, skip connection on exactly these,
+// models.py:562-564) repeat the P1 / M pair inside the stage with H updated in place; the wave's 16-column weight slice
+// is re-read from L2 for every layer and stage (requested in front of P1, consumed behind its barrier) into the
+// registers the two-layer form loads once.  The middle layers' weights sit `mid_stride` floats apart (the model blob is
+// laid out layer by layer; the launcher checks it).
+template <int ACT, int KQ0, int KQ1, int MATH, bool DEEP = false>
 __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_graph,
     const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, int N, const float *__restrict__ W0,
     const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ b1,
-    int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled)
+    int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled, int nl,
+    const float *__restrict__ Wmid, const float *__restrict__ bmid, long mid_stride, long bmid_stride, int skip)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G2_UNITS = g2_units(MATH), G2_CAP = 16 * G2_UNITS;
@@ -3543,7 +3550,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     for (int q = 0; q < KQ1; q++) {
         const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!MATH && n1c < h1)
+        if (!MATH && !DEEP && n1c < h1)
             v = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + k);
         w1r[q * 4 + 0] = v.x;
         w1r[q * 4 + 1] = v.y;
@@ -3746,7 +3753,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         // destination rows padded for M1's fragment reads.  Offsets and coefficients come ready-made from
         // REC; the next pass's record is fetched while this pass's rows are in flight.  (VALU instructions
         // are what bounds this kernel: row-level scalars must not be recomputed by all lanes of a group.)
-        {
+        auto phase_p1 = [&]() {
             typedef Vf<4> V;
             const char *Hl = reinterpret_cast<const char *>(H) + gl * 16; // this lane's chunk of row 0
             int4 ra = make_int4(0, 0, 0, 0), rc = ra, rd = ra;
@@ -3798,7 +3805,60 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                     accA.store(A1 + rA * lda1 + gl * 4);
                 }
             }
+        };
+        // (DEEP) this wave's weight slice + bias for a 128-wide layer -> the w1r registers: ordinary loads, requested
+        // here, first used behind the next barrier
+        auto load_slice = [&](const float *Wl, const float *bl, int ncol, int nlim) {
+#pragma unroll
+            for (int q = 0; q < KQ1; q++) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ncol < nlim)
+                    v = *reinterpret_cast<const float4 *>(Wl + (size_t)ncol * h0 + 16 * q + 4 * lg);
+                w1r[q * 4 + 0] = v.x;
+                w1r[q * 4 + 1] = v.y;
+                w1r[q * 4 + 2] = v.z;
+                w1r[q * 4 + 3] = v.w;
+            }
+            bias1 = (ncol < nlim && bl) ? bl[ncol] : 0.0f;
+        };
+        if (DEEP) {
+            for (int l = 1; l + 1 < nl; l++) {
+                load_slice(Wmid + (size_t)(l - 1) * mid_stride, bmid ? bmid + (size_t)(l - 1) * bmid_stride : nullptr, n0c, h0);
+                __builtin_amdgcn_sched_barrier(0); // (keep the requests in FRONT of P1: their latency hides behind it)
+                phase_p1();
+                g2_barrier();
+                // ---- M (middle layer): H = act(A1 . Wl^T + bl (+ H)), in place -- a lane reads exactly the elements it writes
+                {
+                    const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
+                    auto mm = [&](auto nutag) {
+                        constexpr int NU = decltype(nutag)::value;
+                        float v[NU][4];
+                        g2_mma<GNNB_ACT_NONE, KQ1, NU, false>(A1, lda1, 1, w1r, bias1, rg0, nrg0, li, lg, v);
+                        if (n0c < h0) {
+#pragma unroll
+                            for (int k = 0; k < NU; k++)
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    float *hp = H + ((rg0 + k * nrg0) * 16 + lg * 4 + r) * ldh + n0c;
+                                    *hp = act_t<ACT>(v[k][r] + (skip ? *hp : 0.0f));
+                                }
+                        }
+                    };
+                    if (G2_UNITS > 3 && nu == 4)
+                        mm(IntTag<G2_UNITS>{});
+                    else if (nu == 3)
+                        mm(IntTag<3>{});
+                    else if (nu == 2)
+                        mm(IntTag<2>{});
+                    else if (nu == 1)
+                        mm(IntTag<1>{});
+                }
+                g2_barrier();
+            }
+            load_slice(W1, b1, n1c, h1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        phase_p1();
         G2_PT(6);
         g2_barrier(); // (4)
         G2_PT(7);
@@ -3897,10 +3957,13 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 
 hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                              int h0, const float *w1, const float *b1, int h1, int act,
-                             const int32_t *pools, int num_pools, float *pooled, hipStream_t s)
+                             const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const G2Deep &deep)
 {
     const Options &o = options();
     if (!o.fuse_gcn2 || t.num_nodes <= 0)
+        return hipErrorNotSupported;
+    // more than two layers: fp32 mode only, middle weights 16-B aligned (float4 slice loads)
+    if (deep.nl < 2 || (deep.nl > 2 && (o.math || !deep.wmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3))))
         return hipErrorNotSupported;
     const int math = o.math ? 1 : 0;
     const int cap = 16 * g2_units(math);
@@ -3921,10 +3984,11 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     const int kq0 = f0 <= 16 ? 1 : 2, kq1 = h0 / 16;
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
     hipError_t rc = hipErrorNotSupported;
-    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto mtag) {
+    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto mtag, auto dtag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
         constexpr int MATH = decltype(mtag)::value;
-        auto kern = k_gcn2_fused<ACT, KQ0, KQ1, MATH>;
+        constexpr bool DEEP = decltype(dtag)::value != 0;
+        auto kern = k_gcn2_fused<ACT, KQ0, KQ1, MATH, DEEP>;
         if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess) {
             rc = hipErrorNotSupported;
             return;
@@ -3951,14 +4015,16 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_WG), lds, s, x, f0, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_graph, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, w0, b0, h0, w1, b1, h1, p0, p1, p2,
-                           num_pools, pooled);
+                           num_pools, pooled, deep.nl, deep.wmid, deep.bmid, deep.mid_stride, deep.bmid_stride, deep.skip);
         rc = hipGetLastError();
     };
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
         if (math)
-            go2(atag, q0tag, q1tag, IntTag<1>{});
+            go2(atag, q0tag, q1tag, IntTag<1>{}, IntTag<0>{});
+        else if (deep.nl > 2)
+            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{});
         else
-            go2(atag, q0tag, q1tag, IntTag<0>{});
+            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<0>{});
     };
     auto go_q = [&](auto atag) {
         if (kq0 == 1 && kq1 == 8) go(atag, IntTag<1>{}, IntTag<8>{});

@@ -504,7 +504,7 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     t.tile_rows = std::max(options().tile_rows, 4);
     // A 2-layer GCN with a promise takes the fused stack only if a whole tile (tile_rows - 1 + largest graph) fits
     // one 64-row stage (48 in the bf16x6 mode): for graphs of 50..61 nodes finer tiles (8, 4) keep that path open
-    if (options().fuse_gcn2 && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && ws->max_graph_nodes > 0) {
+    if (options().fuse_gcn2 && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers >= 2 && ws->max_graph_nodes > 0) {
         const int stage_rows = options().math ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
         while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > stage_rows)
             t.tile_rows >>= 1;
@@ -673,6 +673,33 @@ static int linear1(const float *a, int lda, int k, const float *w, int ldw, cons
     return gnnb_linear(&seg, 1, w, ldw, bias, skip, y, M, N, act, stream);
 }
 
+
+// Middle layers of a GCN stack for the fused kernel: every one hidden -> hidden, weights / biases at one constant
+// stride in the model blob (it is laid out layer by layer, so they are -- checked, not assumed).  nl = 0: not eligible.
+static G2Deep gcn_stack_middle_layers(const gnnb_model *model)
+{
+    const gnnb_model_desc &d = model->desc;
+    G2Deep g;
+    g.nl = 0;
+    const int L = d.num_layers;
+    if (d.conv_type != GNNB_CONV_GCN || L < 2 || L > GNNB_MAX_LAYERS)
+        return g;
+    if (L > 2) {
+        g.wmid = model->conv[1][0];
+        g.bmid = model->conv[1][1];
+        if (L > 3) {
+            g.mid_stride = (long)(model->conv[2][0] - model->conv[1][0]);
+            g.bmid_stride = (long)(model->conv[2][1] - model->conv[1][1]);
+        }
+        for (int l = 1; l + 1 < L; l++)
+            if (model->conv[l][0] != g.wmid + (long)(l - 1) * g.mid_stride || model->conv[l][1] != g.bmid + (long)(l - 1) * g.bmid_stride)
+                return g;
+    }
+    g.skip = d.skip ? 1 : 0;
+    g.nl = L;
+    return g;
+}
+
 static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, float *out_dev,
                                  void *stream);
 
@@ -713,11 +740,13 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
         x_dev = ws->act[1]; // (the layer loop never writes the buffer it reads)
     }
 
-    // ---- fused path: 2-layer GCN stack + pooling in one persistent kernel, then the MLP head
-    if (!fpx && d.conv_type == GNNB_CONV_GCN && d.num_layers == 2 && d.mlp_num_linear <= 8) {
+    // ---- fused path: the whole GCN stack (two or more layers) + pooling in one persistent kernel, then the MLP head
+    const G2Deep deep = gcn_stack_middle_layers(model);
+    if (!fpx && deep.nl >= 2 && d.mlp_num_linear <= 8) {
+        const int L = d.num_layers;
         hipError_t he = launch_gcn2_fused(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
-                                          model->conv[1][0], model->conv[1][1], d.out_dim, d.activation, d.pools,
-                                          d.num_pools, ws->pooled, (hipStream_t)stream);
+                                          model->conv[L - 1][0], model->conv[L - 1][1], d.out_dim, d.activation, d.pools,
+                                          d.num_pools, ws->pooled, (hipStream_t)stream, deep);
         if (he == hipSuccess) {
             HeadArgs head;
             memset(&head, 0, sizeof(head));
@@ -1014,13 +1043,15 @@ int gnnb_gcn_stack_timed(const gnnb_model *model, gnnb_workspace *ws, const floa
     if (!ws->prepared)
         return fail(GNNB_ERR_INVALID, "workspace has no prepared batch");
     const gnnb_model_desc &d = model->desc;
-    if (d.conv_type != GNNB_CONV_GCN || d.num_layers != 2)
-        return fail(GNNB_ERR_INVALID, "the fused stack exists for 2-layer GCN models");
+    const G2Deep deep = gcn_stack_middle_layers(model);
+    if (deep.nl < 2)
+        return fail(GNNB_ERR_INVALID, "the fused stack exists for GCN models of two or more layers");
     hipStream_t s = (hipStream_t)stream;
     auto launch = [&]() {
+        const int L = d.num_layers;
         return launch_gcn2_fused(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
-                                 model->conv[1][0], model->conv[1][1], d.out_dim, d.activation, d.pools,
-                                 d.num_pools, ws->pooled, s);
+                                 model->conv[L - 1][0], model->conv[L - 1][1], d.out_dim, d.activation, d.pools,
+                                 d.num_pools, ws->pooled, s, deep);
     };
     hipEvent_t e0, e1;
     GNNB_HIP_TRY(hipEventCreate(&e0));

@@ -397,7 +397,7 @@ class CompiledModel:
         return float(us.value)
 
     def gcn_stack_timed(self, x, iters: int, stream=None) -> float:
-        """Mean microseconds per launch of the fused 2-layer GCN stack + pooling kernel on the prepared
+        """Mean microseconds per launch of the fused GCN stack + pooling kernel on the prepared
         batch (``graph_prep`` first); HIP events on the launch stream.  Raises if that path is not eligible."""
         us = C.c_float()
         _check(self.lib.gnnb_gcn_stack_timed(self._model, self._ws, _dptr(x), int(iters), _stream_ptr(stream),

@@ -234,8 +234,8 @@ int gnnb_linear_timed(const float *a_dev, int lda, int k, const float *w_dev, in
                       const float *bias_dev, float *y_dev, int M, int N, int act, int iters,
                       void *stream, float *out_us_per_launch);
 
-/* Same for the fused 2-layer GCN stack + pooling kernel on the workspace's prepared batch (the kernel
- * gnnb_forward_prepared runs when the model is a 2-layer GCN and a max_graph_nodes promise is set;
+/* Same for the fused GCN stack + pooling kernel on the workspace's prepared batch (the kernel
+ * gnnb_forward_prepared runs when the model is a GCN of two or more layers and a max_graph_nodes promise is set;
  * replaces compute_gnn_head + compute_global_graph_pooling, templates/model.cpp.jinja:151-359,
  * :413-449).  GNNB_ERR_INVALID when that path is not eligible. */
 int gnnb_gcn_stack_timed(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, int iters,

@@ -952,6 +952,35 @@ def test_forward_is_graph_capturable(dev, conv, shape, promise):
     cm.check()
 
 
+@pytest.mark.parametrize("layers,hidden,out_dim,act,skip,shape", [
+    (3, 128, 128, "relu", True, "qm9"), (3, 128, 128, "relu", False, "qm9"), (4, 64, 32, "tanh", True, "esol"),
+    (5, 32, 64, "gelu", True, "qm9"), (6, 128, 20, "sigmoid", True, "esol"), (3, 64, 128, "relu", True, "qm9")])
+def test_fused_gcn_stack_of_more_than_two_layers(dev, layers, hidden, out_dim, act, skip, shape):
+    """GCN stacks of 3..6 layers in ONE kernel (reference compute_gnn_head, model.cpp.jinja:151-359, any depth): the
+    middle layers repeat the aggregate / update pair inside the stage, skip connection on exactly these, their weight
+    slices re-read per layer.  Against the oracle, against the layer-by-layer path, on molecule batches and on random
+    multigraphs (hubs, duplicate edges, empty graphs); the timed entry proves the fused stack is what ran."""
+    fin = synthetic.SHAPES[shape]["f_in"]
+    model = make_model("gcn", in_dim=fin, hidden=hidden, layers=layers, out_dim=out_dim, act=act, skip=skip, task_out=3)
+    rng = np.random.default_rng(layers * 100 + hidden)
+    for batch in (synthetic.make_batch(shape, 400, seed=layers), pack_graphs(_random_graphs(rng, 120, 40, fin, dense=4))):
+        promise = int(np.diff(batch.node_ptr).max())
+        ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+        scale = max(1.0, float(np.abs(ref).max()))
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
+        args = to_dev(batch, dev)
+        got = cm.forward(*args).cpu().numpy()
+        cm.check()
+        assert cm.gcn_stack_timed(args[0], 2) > 0.0
+        assert np.abs(got - ref).max() < TOL * scale, (np.abs(got - ref).max(), scale)
+        try:
+            runtime.set_option("fuse_gcn2", 0)
+            lw = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1))
+            assert np.abs(lw.forward(*args).cpu().numpy() - got).max() < 5e-5 * scale
+        finally:
+            runtime.set_option("fuse_gcn2", 1)
+
+
 def test_config1_esol_takes_the_fused_stack(dev):
     """BASELINE config 1 (2-layer GCN d=64, ESOL: graphs of up to 55 nodes) with the reference's MAX_NODES as the promise:
     the 64-row stages take it on the fused stack (one graph of exactly 55 nodes included), same numbers as the oracle and as
