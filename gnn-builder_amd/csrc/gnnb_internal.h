@@ -109,11 +109,15 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
 // model / batch does not qualify (caller runs the layer-by-layer path).
 // layers between the first and the last of a fused GCN stack (width h0 -> h0): layer l's weight at wmid + (l - 1) *
 // mid_stride floats, its bias at bmid + (l - 1) * bmid_stride; nl = number of conv layers (2: no middle layers)
+// gin: a GIN stack instead -- wmid / bmid then address ALL hidden x hidden matrices in execution order (index 0 = layer 0's
+// second linear, 2l - 1 / 2l = layer l's first / second linear), eps = GINConv's (1 + eps) self weight
 struct G2Deep {
     int nl = 2;
     const float *wmid = nullptr, *bmid = nullptr;
     long mid_stride = 0, bmid_stride = 0;
     int skip = 0;
+    int gin = 0;
+    float eps = 0.0f;
 };
 hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                              int h0, const float *w1, const float *b1, int h1, int act,

@@ -3412,7 +3412,12 @@ __device__ __forceinline__ void g2_mma_bf6(const char *__restrict__ planes, int 
 // is re-read from L2 for every layer and stage (requested in front of P1, consumed behind its barrier) into the
 // registers the two-layer form loads once.  The middle layers' weights sit `mid_stride` floats apart (the model blob is
 // laid out layer by layer; the launcher checks it).
-template <int ACT, int KQ0, int KQ1, int MATH, bool DEEP = false>
+// GIN (with DEEP): the same stage loop for GIN stacks (reference gin_conv, gnn_builder_lib.h:1389-1544): the aggregate
+// is (1 + eps) x_i + sum_j x_j, every layer has TWO linears (ReLU between them, the model's activation and the skip
+// connection behind the second), all wide matrices hidden x hidden at one stride in the blob: index 0 = layer 0's
+// second linear, 2l - 1 / 2l = layer l's first / second.  A linear whose input and output share a buffer multiplies,
+// waits for everybody at a barrier, then writes.
+template <int ACT, int KQ0, int KQ1, int MATH, bool DEEP = false, bool GIN = false>
 __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
@@ -3420,7 +3425,8 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, int N, const float *__restrict__ W0,
     const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ b1,
     int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled, int nl,
-    const float *__restrict__ Wmid, const float *__restrict__ bmid, long mid_stride, long bmid_stride, int skip)
+    const float *__restrict__ Wmid, const float *__restrict__ bmid, long mid_stride, long bmid_stride, int skip,
+    float gin_eps)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G2_UNITS = g2_units(MATH), G2_CAP = 16 * G2_UNITS;
@@ -3664,11 +3670,11 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
             const int4 r0 = srec[2 * ic], r1 = srec[2 * ic + 1];
             const int deg = r0.y;
             const int jl[4] = {r0.z - nb, r0.w - nb, r1.x - nb, r1.y - nb};
-            const float di = sdinv[ic];
+            const float di = GIN ? 1.0f : sdinv[ic];
             float xv[T0][4], xself[T0], sv[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                sv[q] = sdinv[jl[q]];
+                sv[q] = GIN ? 1.0f : sdinv[jl[q]];
 #pragma unroll
                 for (int t = 0; t < T0; t++) {
                     const int f = l8 + 8 * t;
@@ -3697,7 +3703,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 // without this loop altogether is 55.2 vs 57.0 us)
                 for (int k = r0.x + 4; k < r0.x + deg; k++) {
                     const int j = col[k] - nb;
-                    const float cj = di * sdinv[j];
+                    const float cj = GIN ? 1.0f : di * sdinv[j];
 #pragma unroll
                     for (int t = 0; t < T0; t++) {
                         const int f = l8 + 8 * t;
@@ -3707,12 +3713,12 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 #pragma unroll
                 for (int t = 0; t < T0; t++) {
                     const int f = l8 + 8 * t;
-                    A0[i * LD0 + f] = f < f0 ? acc[t] + xself[t] * (di * di) : 0.0f;
+                    A0[i * LD0 + f] = f < f0 ? acc[t] + xself[t] * (GIN ? 1.0f + gin_eps : di * di) : 0.0f;
                 }
                 if (l8 == 0) { // the row's scalars, computed once here instead of by every lane of P1's lane group
                     REC[3 * i] = make_int4(jl[0] * ldh * 4, jl[1] * ldh * 4, jl[2] * ldh * 4, jl[3] * ldh * 4);
                     REC[3 * i + 1] = make_int4(__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]), __float_as_int(c[3]));
-                    REC[3 * i + 2] = make_int4(__float_as_int(di * di), r0.x, deg, __float_as_int(di));
+                    REC[3 * i + 2] = make_int4(__float_as_int(GIN ? 1.0f + gin_eps : di * di), r0.x, deg, __float_as_int(di));
                 }
             }
         }
@@ -3727,7 +3733,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
             auto m0 = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
                 float v[NU][4];
-                g2_mma<ACT, KQ0, NU, false>(A0, LD0, 1, w0r, bias0, rg0, nrg0, li, lg, v);
+                g2_mma<GIN ? (int)GNNB_ACT_RELU : ACT, KQ0, NU, false>(A0, LD0, 1, w0r, bias0, rg0, nrg0, li, lg, v);
                 if (n0c < h0) {
 #pragma unroll
                     for (int k = 0; k < NU; k++)
@@ -3787,7 +3793,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 for (int k = da.y + 4; k < da.y + da.z; k++) { // degree > 4
                     const int j = col[k] - nb;
                     accA = vadd(accA, vmul(V::load(reinterpret_cast<const float *>(Hl + j * ldh * 4)),
-                                           V::splat(__int_as_float(da.w) * sdinv[j])));
+                                           V::splat(GIN ? 1.0f : __int_as_float(da.w) * sdinv[j])));
                 }
                 accA = vadd(accA, vmul(selfA, V::splat(__int_as_float(da.x))));
                 if (MATH) {
@@ -3821,44 +3827,100 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
             }
             bias1 = (ncol < nlim && bl) ? bl[ncol] : 0.0f;
         };
-        if (DEEP) {
-            for (int l = 1; l + 1 < nl; l++) {
-                load_slice(Wmid + (size_t)(l - 1) * mid_stride, bmid ? bmid + (size_t)(l - 1) * bmid_stride : nullptr, n0c, h0);
-                __builtin_amdgcn_sched_barrier(0); // (keep the requests in FRONT of P1: their latency hides behind it)
+        // ---- M (a 128-wide layer whose output replaces H): H = act(A1 . Wl^T + bl (+ H)) -- a lane reads exactly the
+        // elements it writes, so the skip term needs no second buffer
+        auto m_mid = [&]() {
+            const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
+            auto mm = [&](auto nutag) {
+                constexpr int NU = decltype(nutag)::value;
+                float v[NU][4];
+                g2_mma<GNNB_ACT_NONE, KQ1, NU, false>(A1, lda1, 1, w1r, bias1, rg0, nrg0, li, lg, v);
+                if (n0c < h0) {
+#pragma unroll
+                    for (int k = 0; k < NU; k++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float *hp = H + ((rg0 + k * nrg0) * 16 + lg * 4 + r) * ldh + n0c;
+                            *hp = act_t<ACT>(v[k][r] + (skip ? *hp : 0.0f));
+                        }
+                }
+            };
+            if (G2_UNITS > 3 && nu == 4)
+                mm(IntTag<G2_UNITS>{});
+            else if (nu == 3)
+                mm(IntTag<3>{});
+            else if (nu == 2)
+                mm(IntTag<2>{});
+            else if (nu == 1)
+                mm(IntTag<1>{});
+        };
+        // ---- M in place (GIN: input and output share `buf`): multiply, barrier (everybody has read), write, barrier
+        auto m_inplace = [&](float *buf, int ld, auto acttag) {
+            constexpr int A = decltype(acttag)::value;
+            const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
+            float v[G2_UNITS][4];
+            auto comp = [&](auto nutag) {
+                constexpr int NU = decltype(nutag)::value;
+                float t[NU][4];
+                g2_mma<A, KQ1, NU, false>(buf, ld, 1, w1r, bias1, rg0, nrg0, li, lg, t);
+#pragma unroll
+                for (int k = 0; k < NU; k++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        v[k][r] = t[k][r];
+            };
+            if (G2_UNITS > 3 && nu == 4)
+                comp(IntTag<G2_UNITS>{});
+            else if (nu == 3)
+                comp(IntTag<3>{});
+            else if (nu == 2)
+                comp(IntTag<2>{});
+            else if (nu == 1)
+                comp(IntTag<1>{});
+            g2_barrier();
+            if (n0c < h0) {
+#pragma unroll
+                for (int k = 0; k < G2_UNITS; k++)
+                    if (k < nu) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            buf[((rg0 + k * nrg0) * 16 + lg * 4 + r) * ld + n0c] = v[k][r];
+                    }
+            }
+            g2_barrier();
+        };
+        if (GIN) {
+            // layer 0's second linear, then per further layer: aggregate, first linear (ReLU, in place on A1), second
+            // linear (-> H with skip + activation; the LAST one stays in the accumulators for the pooling below)
+            load_slice(Wmid, bmid, n0c, h0);
+            m_inplace(H, ldh, IntTag<ACT>{});
+            for (int l = 1; l < nl; l++) {
+                load_slice(Wmid + (size_t)(2 * l - 1) * mid_stride, bmid + (size_t)(2 * l - 1) * bmid_stride, n0c, h0);
+                __builtin_amdgcn_sched_barrier(0);
                 phase_p1();
                 g2_barrier();
-                // ---- M (middle layer): H = act(A1 . Wl^T + bl (+ H)), in place -- a lane reads exactly the elements it writes
-                {
-                    const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
-                    auto mm = [&](auto nutag) {
-                        constexpr int NU = decltype(nutag)::value;
-                        float v[NU][4];
-                        g2_mma<GNNB_ACT_NONE, KQ1, NU, false>(A1, lda1, 1, w1r, bias1, rg0, nrg0, li, lg, v);
-                        if (n0c < h0) {
-#pragma unroll
-                            for (int k = 0; k < NU; k++)
-#pragma unroll
-                                for (int r = 0; r < 4; r++) {
-                                    float *hp = H + ((rg0 + k * nrg0) * 16 + lg * 4 + r) * ldh + n0c;
-                                    *hp = act_t<ACT>(v[k][r] + (skip ? *hp : 0.0f));
-                                }
-                        }
-                    };
-                    if (G2_UNITS > 3 && nu == 4)
-                        mm(IntTag<G2_UNITS>{});
-                    else if (nu == 3)
-                        mm(IntTag<3>{});
-                    else if (nu == 2)
-                        mm(IntTag<2>{});
-                    else if (nu == 1)
-                        mm(IntTag<1>{});
+                m_inplace(A1, lda1, IntTag<GNNB_ACT_RELU>{});
+                load_slice(Wmid + (size_t)(2 * l) * mid_stride, bmid + (size_t)(2 * l) * bmid_stride, n0c, h0);
+                if (l + 1 < nl) {
+                    m_mid();
+                    g2_barrier();
                 }
-                g2_barrier();
             }
-            load_slice(W1, b1, n1c, h1);
-            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            if (DEEP) {
+                for (int l = 1; l + 1 < nl; l++) {
+                    load_slice(Wmid + (size_t)(l - 1) * mid_stride, bmid ? bmid + (size_t)(l - 1) * bmid_stride : nullptr, n0c, h0);
+                    __builtin_amdgcn_sched_barrier(0); // (keep the requests in FRONT of P1: their latency hides behind it)
+                    phase_p1();
+                    g2_barrier();
+                    m_mid();
+                    g2_barrier();
+                }
+                load_slice(W1, b1, n1c, h1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            phase_p1();
         }
-        phase_p1();
         G2_PT(6);
         g2_barrier(); // (4)
         G2_PT(7);
@@ -3965,6 +4027,9 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     // more than two layers: fp32 mode only, middle weights 16-B aligned (float4 slice loads)
     if (deep.nl < 2 || (deep.nl > 2 && (o.math || !deep.wmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3))))
         return hipErrorNotSupported;
+    // GIN stacks: fp32 mode, hidden == out (every wide matrix h0 x h0), biases present
+    if (deep.gin && (o.math || h1 != h0 || !deep.wmid || !deep.bmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3)))
+        return hipErrorNotSupported;
     const int math = o.math ? 1 : 0;
     const int cap = 16 * g2_units(math);
     if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > cap)
@@ -3987,8 +4052,8 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto mtag, auto dtag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
         constexpr int MATH = decltype(mtag)::value;
-        constexpr bool DEEP = decltype(dtag)::value != 0;
-        auto kern = k_gcn2_fused<ACT, KQ0, KQ1, MATH, DEEP>;
+        constexpr bool DEEP = decltype(dtag)::value != 0, GIN = decltype(dtag)::value == 2;
+        auto kern = k_gcn2_fused<ACT, KQ0, KQ1, MATH, DEEP, GIN>;
         if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess) {
             rc = hipErrorNotSupported;
             return;
@@ -4015,11 +4080,13 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_WG), lds, s, x, f0, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_graph, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, w0, b0, h0, w1, b1, h1, p0, p1, p2,
-                           num_pools, pooled, deep.nl, deep.wmid, deep.bmid, deep.mid_stride, deep.bmid_stride, deep.skip);
+                           num_pools, pooled, deep.nl, deep.wmid, deep.bmid, deep.mid_stride, deep.bmid_stride, deep.skip, deep.eps);
         rc = hipGetLastError();
     };
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
-        if (math)
+        if (deep.gin)
+            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<2>{});
+        else if (math)
             go2(atag, q0tag, q1tag, IntTag<1>{}, IntTag<0>{});
         else if (deep.nl > 2)
             go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{});

@@ -504,7 +504,8 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     t.tile_rows = std::max(options().tile_rows, 4);
     // A 2-layer GCN with a promise takes the fused stack only if a whole tile (tile_rows - 1 + largest graph) fits
     // one 64-row stage (48 in the bf16x6 mode): for graphs of 50..61 nodes finer tiles (8, 4) keep that path open
-    if (options().fuse_gcn2 && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers >= 2 && ws->max_graph_nodes > 0) {
+    if (options().fuse_gcn2 && (ws->desc.conv_type == GNNB_CONV_GCN || ws->desc.conv_type == GNNB_CONV_GIN) && ws->desc.num_layers >= 2 &&
+        ws->max_graph_nodes > 0) {
         const int stage_rows = options().math ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
         while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > stage_rows)
             t.tile_rows >>= 1;
@@ -682,6 +683,30 @@ static G2Deep gcn_stack_middle_layers(const gnnb_model *model)
     G2Deep g;
     g.nl = 0;
     const int L = d.num_layers;
+    if (d.conv_type == GNNB_CONV_GIN && L >= 2 && L <= GNNB_MAX_LAYERS && d.hidden_dim == d.out_dim) {
+        // wide matrices in execution order: Wb0 | Wa1 Wb1 | Wa2 Wb2 ...  (conv[l] = {Wa, ba, Wb, bb})
+        std::vector<const float *> w, b;
+        w.push_back(model->conv[0][2]);
+        b.push_back(model->conv[0][3]);
+        for (int l = 1; l < L; l++) {
+            w.push_back(model->conv[l][0]);
+            b.push_back(model->conv[l][1]);
+            w.push_back(model->conv[l][2]);
+            b.push_back(model->conv[l][3]);
+        }
+        g.wmid = w[0];
+        g.bmid = b[0];
+        g.mid_stride = (long)(w[1] - w[0]);
+        g.bmid_stride = (long)(b[1] - b[0]);
+        for (size_t j = 0; j < w.size(); j++)
+            if (w[j] != g.wmid + (long)j * g.mid_stride || b[j] != g.bmid + (long)j * g.bmid_stride)
+                return g;
+        g.gin = 1;
+        g.eps = d.gin_eps;
+        g.skip = d.skip ? 1 : 0;
+        g.nl = L;
+        return g;
+    }
     if (d.conv_type != GNNB_CONV_GCN || L < 2 || L > GNNB_MAX_LAYERS)
         return g;
     if (L > 2) {
@@ -1045,7 +1070,7 @@ int gnnb_gcn_stack_timed(const gnnb_model *model, gnnb_workspace *ws, const floa
     const gnnb_model_desc &d = model->desc;
     const G2Deep deep = gcn_stack_middle_layers(model);
     if (deep.nl < 2)
-        return fail(GNNB_ERR_INVALID, "the fused stack exists for GCN models of two or more layers");
+        return fail(GNNB_ERR_INVALID, "the fused stack exists for GCN / GIN models of two or more layers");
     hipStream_t s = (hipStream_t)stream;
     auto launch = [&]() {
         const int L = d.num_layers;

@@ -235,7 +235,8 @@ int gnnb_linear_timed(const float *a_dev, int lda, int k, const float *w_dev, in
                       void *stream, float *out_us_per_launch);
 
 /* Same for the fused GCN stack + pooling kernel on the workspace's prepared batch (the kernel
- * gnnb_forward_prepared runs when the model is a GCN of two or more layers and a max_graph_nodes promise is set;
+ * gnnb_forward_prepared runs when the model is a GCN (or a GIN with hidden = out) of two or more layers and a
+ * max_graph_nodes promise is set;
  * replaces compute_gnn_head + compute_global_graph_pooling, templates/model.cpp.jinja:151-359,
  * :413-449).  GNNB_ERR_INVALID when that path is not eligible. */
 int gnnb_gcn_stack_timed(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, int iters,

@@ -981,6 +981,37 @@ def test_fused_gcn_stack_of_more_than_two_layers(dev, layers, hidden, out_dim, a
             runtime.set_option("fuse_gcn2", 1)
 
 
+@pytest.mark.parametrize("layers,hidden,act,skip,shape,eps", [
+    (2, 128, "relu", True, "qm9", 0.0), (3, 128, "relu", True, "qm9", 0.2), (3, 64, "tanh", False, "esol", 0.0),
+    (4, 32, "gelu", True, "qm9", -0.3), (5, 128, "sigmoid", True, "esol", 0.1)])
+def test_fused_gin_stack(dev, layers, hidden, act, skip, shape, eps):
+    """GIN stacks (hidden = out, graphs within the promise) in ONE kernel: (1 + eps) x_i + sum_j x_j, two linears per
+    layer with ReLU between them (reference gin_conv, gnn_builder_lib.h:1389-1544), skip connection and the model's
+    activation behind the second.  Against the oracle and the layer-by-layer path; the timed entry proves which ran."""
+    fin = synthetic.SHAPES[shape]["f_in"]
+    model = make_model("gin", in_dim=fin, hidden=hidden, layers=layers, out_dim=hidden, act=act, skip=skip, task_out=3)
+    for c in model.gnn_convs:
+        c.eps = eps
+        c.conv.eps.fill_(eps)
+    rng = np.random.default_rng(layers * 10 + hidden)
+    for batch in (synthetic.make_batch(shape, 300, seed=layers), pack_graphs(_random_graphs(rng, 100, 40, fin, dense=4))):
+        promise = int(np.diff(batch.node_ptr).max())
+        ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+        scale = max(1.0, float(np.abs(ref).max()))
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
+        args = to_dev(batch, dev)
+        got = cm.forward(*args).cpu().numpy()
+        cm.check()
+        assert cm.gcn_stack_timed(args[0], 2) > 0.0
+        assert np.abs(got - ref).max() < TOL * scale, (np.abs(got - ref).max(), scale)
+        try:
+            runtime.set_option("fuse_gcn2", 0)
+            lw = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1))
+            assert np.abs(lw.forward(*args).cpu().numpy() - got).max() < 5e-5 * scale
+        finally:
+            runtime.set_option("fuse_gcn2", 1)
+
+
 def test_config1_esol_takes_the_fused_stack(dev):
     """BASELINE config 1 (2-layer GCN d=64, ESOL: graphs of up to 55 nodes) with the reference's MAX_NODES as the promise:
     the 64-row stages take it on the fused stack (one graph of exactly 55 nodes included), same numbers as the oracle and as
