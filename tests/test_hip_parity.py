@@ -1012,6 +1012,24 @@ def test_fused_gin_stack(dev, layers, hidden, act, skip, shape, eps):
             runtime.set_option("fuse_gcn2", 1)
 
 
+@pytest.mark.parametrize("conv,layers,hidden", [("gcn", 3, 64), ("gin", 3, 128), ("gin", 2, 32), ("gcn", 4, 32)])
+def test_fused_stacks_with_wide_input_features(dev, conv, layers, hidden):
+    """F_in = 20 (two 16-wide k blocks in the first layer's product) and 30 on the deep GCN / GIN fused stacks, random
+    multigraphs with graphs of up to 57 nodes (the largest the default 8-row node tiles admit)."""
+    for fin in (20, 30):
+        model = make_model(conv, in_dim=fin, hidden=hidden, layers=layers, out_dim=hidden, act="relu", task_out=2)
+        rng = np.random.default_rng(fin + layers)
+        batch = pack_graphs(_random_graphs(rng, 150, 57, fin, dense=3))
+        promise = int(np.diff(batch.node_ptr).max())
+        ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
+        args = to_dev(batch, dev)
+        got = cm.forward(*args).cpu().numpy()
+        cm.check()
+        assert cm.gcn_stack_timed(args[0], 2) > 0.0
+        assert np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
+
+
 def test_config1_esol_takes_the_fused_stack(dev):
     """BASELINE config 1 (2-layer GCN d=64, ESOL: graphs of up to 55 nodes) with the reference's MAX_NODES as the promise:
     the 64-row stages take it on the fused stack (one graph of exactly 55 nodes included), same numbers as the oracle and as
