@@ -16,9 +16,9 @@ The timed region (K steps between barrier + synchronize on both sides, MAX over 
 `--repeats` times; `value` is computed from the MEDIAN repeat, min / max are reported beside it.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt) with these extra objects:
-  roofline      -- the kernel that dominates the timed step.  c2 (2-layer GCN with a max_graph_nodes
-                   promise) runs the fused stack kernel k_gcn2_fused: bound = fp32 MFMA.  c3: the
-                   K=N=128 update GEMM (k_linear_wlds); c4 / c5: the large-K segmented GEMM (k_linear_dma);
+  roofline      -- the kernel that dominates the timed step.  c2 and c3 (GCN / GIN stacks, graphs within the
+                   max_graph_nodes promise) run the fused stack kernel k_gcn2_fused: bound = fp32 MFMA (c3 without
+                   the promise: the K=N=128 update GEMM, k_linear_wlds); c4 / c5: the large-K segmented GEMM (k_linear_dma);
                    all bound = fp32 MFMA, flops / launch duration from HIP events on the launch stream.
   roofline_gather_aggregate -- the GCN gather-aggregate kernel at the full feature width (the
                    north-star kernel; every layer-by-layer model runs it): algorithmic bytes (SURVEY.md
@@ -178,9 +178,9 @@ def pmc_traffic(kind="aggregate"):
         return None
 
 
-def measure_fused_stack(cm, batch_dev, model_dims, iters=200):
-    """The fused 2-layer GCN stack + pooling kernel on one prepared batch: launches issued back to back
-    from C, HIP events on the launch stream.  Returns None when the path is not eligible."""
+def measure_fused_stack(cm, batch_dev, model_dims, iters=200, conv="gcn", layers=2):
+    """The fused conv stack + pooling kernel (GCN / GIN, two or more layers, graphs within the promise) on one prepared
+    batch: launches issued back to back from C, HIP events on the launch stream.  None when the path is not eligible."""
     x, coo, nptr, eptr = batch_dev
     N, E, B = int(x.shape[0]), int(coo.shape[0]), int(nptr.numel()) - 1
     f0, h0, h1, npool = model_dims
@@ -189,7 +189,11 @@ def measure_fused_stack(cm, batch_dev, model_dims, iters=200):
         us = cm.gcn_stack_timed(x, iters)
     except RuntimeError:
         return None
-    flops = 2.0 * N * (f0 * h0 + h0 * h1)          # the two dense updates (MFMA); aggregation flops not counted
+    # the dense updates (MFMA); aggregation flops not counted.  GCN: one linear per layer; GIN: two (hidden = out)
+    if conv == "gin":
+        flops = 2.0 * N * (f0 * h0 + (2 * layers - 1) * h0 * h0)
+    else:
+        flops = 2.0 * N * (f0 * h0 + (layers - 2) * h0 * h0 + h0 * h1)
     # HBM bytes the kernel has to move: x + node records + dinv + tile/graph tables in, pooled out
     alg_bytes = 4 * N * f0 + 32 * N + 4 * N + 4 * (B + 1) + 4 * B * npool * h1
     return dict(us=us, tflops=flops / (us * 1e-6) / 1e12, flops=flops, alg_bytes=alg_bytes)
@@ -446,8 +450,8 @@ def main():
         cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=mg)
         bd = tuple(torch.from_numpy(a).to(dev) for a in (batch.x, batch.coo, batch.node_ptr, batch.edge_ptr))
         alg_bytes, agg = measure_aggregate_roofline(cm, bd, w["hidden"], dev, regimes=("hbm",))
-        fused = measure_fused_stack(cm, bd, (int(batch.x.shape[1]), w["hidden"], w["hidden"], len(w["pools"]))) \
-            if w["conv"] == "gcn" and w["layers"] == 2 else None
+        fused = measure_fused_stack(cm, bd, (int(batch.x.shape[1]), w["hidden"], w["hidden"], len(w["pools"])),
+                                    conv=w["conv"], layers=w["layers"]) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
         print(json.dumps({"roofline_only": True, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"],
                           "copy_same_launch_shape": agg.get("copy_same_launch_shape"), "fused_stack": fused}))
         return
@@ -629,20 +633,20 @@ def main():
             "in_pipeline_l3_resident": agg["l3_resident"],
             "copy_ceiling_same_bytes": ceiling,
         }
-        fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w["hidden"],
-                                                        len(w["pools"]))) if w["conv"] == "gcn" and w["layers"] == 2 else None
+        fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w["hidden"], len(w["pools"])),
+                                    conv=w["conv"], layers=w["layers"]) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
         upd = dict(kernel="k_linear_wlds (fp32 MFMA, weights in LDS), full-width layer update", bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS,
                    unit="TFLOP/s", traffic=None, **measure_update_mfma(w, batches[0].num_nodes, dev))
         if fused is not None:
             # the step runs the fused stack: that kernel dominates it and is bound by the fp32 matrix rate
             result["roofline"] = {
-                "kernel": "k_gcn2_fused (2 GCN layers + pooling in one persistent kernel, graphs staged in LDS)",
+                "kernel": "k_gcn2_fused (%d %s layers + pooling in one persistent kernel, graphs staged in LDS)" % (w["layers"], w["conv"].upper()),
                 "bound": "mfma", "achieved": fused["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("gcn2"),
+                "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("gcn2") if w["conv"] == "gcn" and w["layers"] == 2 else None,
                 "algorithmic_flops_per_launch": fused["flops"], "algorithmic_hbm_bytes_per_launch": fused["alg_bytes"],
                 "us_per_launch": fused["us"], "share_of_step": fused["us"] / (ms_noprep * 1e3),
-                "note": "flops = 2 N (F0 h0 + h0 h1), the two dense updates on v_mfma_f32_16x16x4_f32; HIP events on "
-                        "the launch stream, launches issued back to back from C on one prepared batch",
+                "note": "flops = the dense updates on v_mfma_f32_16x16x4_f32 (GCN: 2 N (F0 h0 + h0 h1); GIN: 2 N (F0 h + (2L - 1) h^2)); "
+                        "HIP events on the launch stream, launches issued back to back from C on one prepared batch",
             }
         elif w["conv"] in ("sage", "pna"):
             # layer-wise workloads with a wide concatenated update: the large-K segmented GEMM dominates the step
