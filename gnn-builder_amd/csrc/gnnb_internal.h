@@ -119,6 +119,7 @@ struct G2Deep {
     int gin = 0;
     float eps = 0.0f;
 };
+long gcn2_fused_tile_capacity();
 hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                              int h0, const float *w1, const float *b1, int h1, int act,
                              const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const G2Deep &deep = G2Deep{});

@@ -4017,6 +4017,17 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 #endif
 }
 
+// node tiles the fused stack can walk in one launch: every resident workgroup keeps its run of the tile table in LDS
+// (graph prep coarsens the tiles of very large batches against this, so that they stay on the fused path)
+long gcn2_fused_tile_capacity()
+{
+    int devid = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    return (long)(G2_TCAP - 2) * 2 * cus;
+}
+
 hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                              int h0, const float *w1, const float *b1, int h1, int act,
                              const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const G2Deep &deep)

@@ -509,6 +509,10 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
         const int stage_rows = options().math ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
         while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > stage_rows)
             t.tile_rows >>= 1;
+        // very large batches: coarser tiles (while a tile still fits a stage) keep the per-workgroup tile table in LDS
+        static const long tile_cap = gcn2_fused_tile_capacity();
+        while ((num_nodes + t.tile_rows - 1) / t.tile_rows > tile_cap && ws->max_graph_nodes + 2 * t.tile_rows - 1 <= stage_rows)
+            t.tile_rows <<= 1;
     }
     t.num_tiles = (num_nodes + t.tile_rows - 1) / t.tile_rows;
     if (!(pna_delta > 0.0f))
