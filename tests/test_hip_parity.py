@@ -881,7 +881,7 @@ def test_linear_dma_path_segments_rowscale_and_ragged_edges(dev, M, N, F):
 
 
 @pytest.mark.parametrize("M,N,K", [(256 * 300 - 5, 256, 64), (256 * 561 + 70, 128, 96), (256 * 265, 200, 32),
-                                   (256 * 40 + 3, 128, 160), (256 * 100 - 130, 256, 64)])
+                                   (256 * 40 + 3, 128, 160), (256 * 100 - 130, 256, 64), (5000, 130, 64), (77, 255, 96)])
 def test_linear_dma_tail_split_is_bit_identical(dev, M, N, K):
     """Tiles of the last, partial round go out as two 128-row or four 64-row slices (600 = 2 x 256 + 88 tiles -> halves,
     562 = 2 x 256 + 50 -> quarters, 530 = 2 x 256 + 18 -> quarters, 41 and 200 tiles < 256 CUs -> all tiles sliced):
