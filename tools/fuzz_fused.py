@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the fused conv-stack kernel (GCN / GIN, any depth) against the oracle on one GPU.
+    python tools/fuzz_fused.py [cases] [seed]
+Random model shapes (depth 2..6, width 32 / 64 / 128, F_in 1..32, activation, skip, pool order), random multigraph
+batches (1..300 graphs of 0..promise nodes, promise 4..61: empty graphs, isolated nodes, self loops, duplicate edges, hubs)
+with the promise exactly met by at least one graph.  Prints the worst error; exits non-zero on a mismatch or when the
+fused path did not take a model it should have taken."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+from helpers import canon, make_model, to_dev  # noqa: E402
+from gnnbuilder_amd import runtime  # noqa: E402
+from gnnbuilder_amd.batching import pack_graphs  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+worst = 0.0
+for it in range(cases):
+    conv = rng.choice(["gcn", "gin"])
+    L = int(rng.integers(2, 7))
+    h = int(rng.choice([32, 64, 128]))
+    out = h if conv == "gin" else int(rng.choice([h, 4 * int(rng.integers(1, 33))]))
+    fin = int(rng.integers(1, 33))
+    act = str(rng.choice(["relu", "gelu", "sigmoid", "tanh"]))
+    skip = bool(rng.integers(0, 2))
+    pools = tuple(rng.permutation(["add", "mean", "max"])[: int(rng.integers(1, 4))])
+    model = make_model(conv, in_dim=fin, hidden=h, layers=L, out_dim=out, act=act, skip=skip, pools=pools, task_out=int(rng.integers(1, 5)),
+                       seed=it)
+    if conv == "gin":
+        eps = float(rng.uniform(-0.5, 0.5))
+        for c in model.gnn_convs:
+            c.eps = eps
+            c.conv.eps.fill_(eps)
+    promise = int(rng.integers(4, 62))
+    B = int(rng.integers(1, 301))
+    graphs = []
+    for g in range(B):
+        n = promise if g == B // 2 else int(rng.integers(0, promise + 1))
+        e = int(rng.integers(0, 4 * n + 1)) if n else 0
+        coo = np.stack([rng.integers(0, max(n, 1), e), rng.integers(0, max(n, 1), e)], 1).astype(np.int32) if e else np.zeros((0, 2), np.int32)
+        if n and rng.integers(0, 4) == 0:            # a hub: many edges into one node
+            hub = int(rng.integers(0, n))
+            extra = np.stack([rng.integers(0, n, 12), np.full(12, hub)], 1).astype(np.int32)
+            coo = np.concatenate([coo, extra])
+        graphs.append((rng.uniform(-1, 1, (n, fin)).astype(np.float32), coo))
+    batch = pack_graphs(graphs)
+    if batch.num_nodes == 0:
+        continue
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
+    args = to_dev(batch, dev)
+    got = cm.forward(*args).cpu().numpy()
+    cm.check()
+    took = True
+    try:
+        cm.gcn_stack_timed(args[0], 1)
+    except runtime.GnnbError:
+        took = False
+    err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    worst = max(worst, err)
+    tag = f"{conv} L={L} h={h} out={out} F={fin} {act} skip={int(skip)} pools={'/'.join(pools)} promise={promise} B={B} N={batch.num_nodes}"
+    if not took or not err < 1e-4:
+        print(f"FAIL case {it}: {tag}: fused={took} err={err:.3e}")
+        sys.exit(1)
+    if it % 10 == 0:
+        print(f"case {it}: {tag}: err {err:.2e}", flush=True)
+    cm.close()
+print(f"{cases} cases, worst relative error {worst:.3e}")
