@@ -3727,6 +3727,24 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         issue_rows(nxt, tv & 63, wv); // (P0 was the last reader of the rows buffer)
         G2_PT(3);
 
+        // (DEEP) this wave's weight slice + bias for a 128-wide layer -> the w1r registers: ordinary loads, requested
+        // here, first used behind the next barrier
+        auto load_slice = [&](const float *Wl, const float *bl, int ncol, int nlim) {
+#pragma unroll
+            for (int q = 0; q < KQ1; q++) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ncol < nlim)
+                    v = *reinterpret_cast<const float4 *>(Wl + (size_t)ncol * h0 + 16 * q + 4 * lg);
+                w1r[q * 4 + 0] = v.x;
+                w1r[q * 4 + 1] = v.y;
+                w1r[q * 4 + 2] = v.z;
+                w1r[q * 4 + 3] = v.w;
+            }
+            bias1 = (ncol < nlim && bl) ? bl[ncol] : 0.0f;
+        };
+        if (GIN)
+            load_slice(Wmid, bmid, n0c, h0); // layer 0's second linear: in flight behind M0
+
         // ---- M0: H = act(A0 . W0^T + b0)   (wave: column slice x row group)
         {
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
@@ -3812,21 +3830,6 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 }
             }
         };
-        // (DEEP) this wave's weight slice + bias for a 128-wide layer -> the w1r registers: ordinary loads, requested
-        // here, first used behind the next barrier
-        auto load_slice = [&](const float *Wl, const float *bl, int ncol, int nlim) {
-#pragma unroll
-            for (int q = 0; q < KQ1; q++) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ncol < nlim)
-                    v = *reinterpret_cast<const float4 *>(Wl + (size_t)ncol * h0 + 16 * q + 4 * lg);
-                w1r[q * 4 + 0] = v.x;
-                w1r[q * 4 + 1] = v.y;
-                w1r[q * 4 + 2] = v.z;
-                w1r[q * 4 + 3] = v.w;
-            }
-            bias1 = (ncol < nlim && bl) ? bl[ncol] : 0.0f;
-        };
         // ---- M (a 128-wide layer whose output replaces H): H = act(A1 . Wl^T + bl (+ H)) -- a lane reads exactly the
         // elements it writes, so the skip term needs no second buffer
         auto m_mid = [&]() {
@@ -3855,7 +3858,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 mm(IntTag<1>{});
         };
         // ---- M in place (GIN: input and output share `buf`): multiply, barrier (everybody has read), write, barrier
-        auto m_inplace = [&](float *buf, int ld, auto acttag) {
+        auto m_inplace = [&](float *buf, int ld, auto acttag, int next_wide) {
             constexpr int A = decltype(acttag)::value;
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
             float v[G2_UNITS][4];
@@ -3877,6 +3880,10 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 comp(IntTag<2>{});
             else if (nu == 1)
                 comp(IntTag<1>{});
+            // the weight registers are free again: request the next linear's slice now, its latency hides behind the
+            // two barriers and the write-back
+            if (next_wide >= 0)
+                load_slice(Wmid + (size_t)next_wide * mid_stride, bmid + (size_t)next_wide * bmid_stride, n0c, h0);
             g2_barrier();
             if (n0c < h0) {
 #pragma unroll
@@ -3892,17 +3899,15 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         if (GIN) {
             // layer 0's second linear, then per further layer: aggregate, first linear (ReLU, in place on A1), second
             // linear (-> H with skip + activation; the LAST one stays in the accumulators for the pooling below)
-            load_slice(Wmid, bmid, n0c, h0);
-            m_inplace(H, ldh, IntTag<ACT>{});
+            m_inplace(H, ldh, IntTag<ACT>{}, 1); // (its own slice, index 0, was requested in front of M0)
             for (int l = 1; l < nl; l++) {
-                load_slice(Wmid + (size_t)(2 * l - 1) * mid_stride, bmid + (size_t)(2 * l - 1) * bmid_stride, n0c, h0);
-                __builtin_amdgcn_sched_barrier(0);
+                // (layer l's first slice, index 2l - 1, is in flight since the previous in-place product)
                 phase_p1();
                 g2_barrier();
-                m_inplace(A1, lda1, IntTag<GNNB_ACT_RELU>{});
-                load_slice(Wmid + (size_t)(2 * l) * mid_stride, bmid + (size_t)(2 * l) * bmid_stride, n0c, h0);
+                m_inplace(A1, lda1, IntTag<GNNB_ACT_RELU>{}, 2 * l);
                 if (l + 1 < nl) {
                     m_mid();
+                    load_slice(Wmid + (size_t)(2 * l + 1) * mid_stride, bmid + (size_t)(2 * l + 1) * bmid_stride, n0c, h0);
                     g2_barrier();
                 }
             }
