@@ -1569,8 +1569,11 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         n0 = (t % tiles_n) * DN;
     };
 
-    // issue cursor: runs two chunks ahead of the multiply cursor, across item boundaries
+    // issue cursor: runs ahead of the multiply cursor, across item boundaries (its item's origin is decoded once per item:
+    // the integer divisions are scalar instructions in front of every wave's next MFMA)
     int iss_item = blockIdx.x, iss_c = 0, iss_buf = 0;
+    int iss_m0 = 0, iss_n0 = 0, iss_mrows = 0;
+    decode(iss_item, iss_m0, iss_n0, iss_mrows);
     int vm = 0; // vector-memory instructions this wave has issued (DMA + epilogue stores): for the counted waits
     // The next chunk's DMA goes out in FOUR parts, one per k step of the chunk being multiplied (a burst of eight
     // instructions behind the barrier kept every wave of the workgroup off the matrix pipe at the same moment):
@@ -1586,8 +1589,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         ic.valid = iss_item < num_items;
         if (!ic.valid)
             return ic;
-        int m0, n0;
-        decode(iss_item, m0, n0, ic.mrows);
+        const int m0 = iss_m0, n0 = iss_n0;
+        ic.mrows = iss_mrows;
         const int c = iss_c;
         // segment lookup with static indexing only (keeps the kernarg struct out of scratch)
         const float *ap = g.a[0];
@@ -1637,6 +1640,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         if (++iss_c == total) {
             iss_c = 0;
             iss_item += gridDim.x;
+            if (iss_item < num_items)
+                decode(iss_item, iss_m0, iss_n0, iss_mrows);
         }
         return vm;
     };
