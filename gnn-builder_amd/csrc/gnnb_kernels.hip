@@ -2,8 +2,10 @@
 //
 //   k_graph_prep   COO -> CSR-by-destination + degree scalers + node tiles   (HBM / latency bound)
 //   k_aggregate    gather -> segmented reduce per destination row            (HBM bound: THE roofline kernel)
-//   k_linear       multi-segment X.W^T + bias + skip + activation on fp32 MFMA (matrix-core bound)
-//   k_global_pool  per-graph add / mean / max readout                        (HBM bound)
+//   k_linear*      multi-segment X.W^T + bias + skip + activation on fp32 MFMA (matrix-core bound):
+//                  k_linear_wlds / k_linear_reg (K <= 128), k_linear_dma (large K), k_linear (irregular shapes)
+//   k_global_pool, k_pool_mlp, k_head_small   per-graph add / mean / max readout + MLP head   (HBM bound)
+//   k_gcn2_fused   whole GCN / GIN conv stack + pooling in one persistent kernel, graphs staged in LDS (matrix-core bound)
 //
 // Wavefront = 64 lanes everywhere.  Reference semantics are cited per kernel
 // (paths relative to the reference repository root).
@@ -3259,21 +3261,23 @@ hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_grap
 // =====================================================================================
 // fused 2-layer GCN stack + pooling (the BASELINE config 1 / 2 model family)
 // =====================================================================================
-// Reference dataflow being fused: compute_gnn_head (two gcn_conv layers with activation,
-// templates/model.cpp.jinja:151-359; gcn_conv gnn_builder_lib.h:1213-1387) and
+// Reference dataflow being fused: compute_gnn_head (the conv layers with skip / activation,
+// templates/model.cpp.jinja:151-359; gcn_conv gnn_builder_lib.h:1213-1387, gin_conv :1389-1544) and
 // compute_global_graph_pooling (:413-449).  Layer by layer, every intermediate [N, d] matrix makes a
 // round trip through HBM (aggregate out -> GEMM in -> GEMM out -> next aggregate in -> ... -> pooling
 // in).  A molecule is a few dozen rows, so a handful of WHOLE graphs fit in LDS: here a persistent
-// workgroup walks its run of node tiles in stages of <= 48 rows (3 MFMA units) and, per stage,
-//   DMA   raw x rows + node records + dinv of the NEXT stage -> LDS (global_load_lds, double-buffered)
-//   P0    A0 = gcn-aggregate(x)            LDS -> LDS   (width F0, all 256 threads)
+// workgroup walks its run of node tiles in stages of <= 64 rows (4 MFMA units) and, per stage,
+//   DMA   raw x rows + node records (one buffer, refilled behind P0), dinv + graph boundaries (two buffers) of the
+//         NEXT stage -> LDS (global_load_lds)
+//   P0    A0 = aggregate(x)                LDS -> LDS   (width F0, eight lanes per row)
 //   M0    H  = act(A0 . W0^T + b0)         MFMA 16x16x4, W0 slice in registers -> LDS
-//   P1    A1 = gcn-aggregate(H)            LDS -> LDS   (lane group per row, padded destination rows)
-//   M1    H  = act(A1 . W1^T + b1)         MFMA, W1 slice (32 cols x K) in registers -> LDS
+//   P1    A1 = aggregate(H)                LDS -> LDS   (lane group per row, padded destination rows)
+//   M1    out = act(A1 . W1^T + b1)        MFMA, W1 slice (16 cols x K) in registers; stays in the accumulators
 //   PL    pooled[g] = add|mean|max over the rows of each graph of the stage -> HBM
-// HBM traffic = x + tables in, [B, np*d] out: ~5 MB instead of ~270 MB at C2; the kernel is bound by
-// the fp32 matrix cores.  Needs: num_layers == 2, F0 <= 32, h0 in {32,64,128}, h1 <= 128 (h1 % 4 == 0)
-// and the caller's promise max_graph_nodes <= 48 - (tile_rows - 1) (validated by graph prep).
+// (stacks of more than two layers and GIN stacks repeat P1 / M inside the stage: the DEEP / GIN variants below).
+// HBM traffic = x + tables in, [B, np*d] out: ~14 MB instead of ~270 MB at C2; the kernel is bound by
+// the fp32 matrix cores.  Needs: F0 <= 32, h0 in {32,64,128}, h1 <= 128 (h1 % 4 == 0) and the caller's promise
+// max_graph_nodes <= 64 - (tile_rows - 1) (validated by graph prep).
 // rows per stage: FOUR 16-row MFMA units (64 rows) -- a stage costs ~13 k cycles of barriers and latency chains whatever
 // it holds, and three molecules fill 54 of 64 rows where two filled 36 of 48.  The bf16x6 mode keeps three units (its A1
 // is three bf16 planes: 1.5x the bytes, and two workgroups must stay resident per CU).
