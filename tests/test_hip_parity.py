@@ -1112,6 +1112,33 @@ def test_full_size_configs_3_4_5(dev, case):
     assert np.abs(out_rev[::-1] - out_d).max() < 2e-5 * max(1.0, float(np.abs(out_d).max()))
 
 
+def test_full_size_config3_on_the_fused_gin_stack(dev):
+    """BASELINE config 3 (GIN L3 d=128, 4096 molhiv-shaped graphs) the way bench.py runs it: with the largest graph of
+    the batch as the promise the whole stack runs in the fused kernel.  256 sampled graphs (both ends, the largest
+    graph) against the oracle; reversed order permutes the rows; same numbers as the layer-by-layer route."""
+    model = make_model("gin", in_dim=9, hidden=128, layers=3, pools=("add",), task_out=1, seed=7)
+    B = 4096
+    batch = synthetic.make_batch("molhiv", B, seed=31)
+    promise = int(np.diff(batch.node_ptr).max())
+    assert promise <= 61
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise)
+    args = to_dev(batch, dev)
+    out_d = cm.forward(*args).cpu().numpy()
+    cm.check()
+    assert cm.gcn_stack_timed(args[0], 2) > 0.0
+    idx = np.sort(np.random.default_rng(3).choice(B, 256, replace=False))
+    idx[0], idx[-1], idx[1] = 0, B - 1, int(np.argmax(np.diff(batch.node_ptr)))
+    sub = pack_graphs([batch.graph(int(g)) for g in idx])
+    ref = O.forward_batched(model.spec(), canon(model), sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(out_d[idx] - ref).max() < TOL * scale
+    rev = pack_graphs([batch.graph(int(g)) for g in range(B - 1, -1, -1)])
+    out_rev = cm.forward(*to_dev(rev, dev)).cpu().numpy()
+    assert np.abs(out_rev[::-1] - out_d).max() < 2e-5 * max(1.0, float(np.abs(out_d).max()))
+    lw = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    assert np.abs(lw.forward(*args).cpu().numpy() - out_d).max() < 5e-5 * max(1.0, float(np.abs(out_d).max()))
+
+
 # --------------------------------------------------------------------------- malformed batches stay inside the buffers
 @pytest.mark.parametrize("conv", ["gcn", "gin", "sage", "pna"])
 def test_malformed_batches_are_contained(dev, conv):
