@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the fused conv-stack kernel (GCN / GIN, any depth) against the oracle on one GPU.
-    python tools/fuzz_fused.py [cases] [seed]
+    python tests/fuzz_fused.py [cases] [seed]      (lives under tests/: it uses the oracle, which is test infrastructure)
 Random model shapes (depth 2..6, width 32 / 64 / 128, F_in 1..32, activation, skip, pool order), random multigraph
 batches (1..300 graphs of 0..promise nodes, promise 4..61: empty graphs, isolated nodes, self loops, duplicate edges, hubs)
 with the promise exactly met by at least one graph.  Prints the worst error; exits non-zero on a mismatch or when the
