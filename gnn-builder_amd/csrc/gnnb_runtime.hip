@@ -1,5 +1,5 @@
 // gnnb_runtime.hip -- host side of libgnnb_hip.so: model / workspace handles, the batched
-// forward that sequences the kernels of gnnb_kernels.hip on one HIP stream, and the C ABI
+// forward that sequences the kernels of k_*.hip on one HIP stream, and the C ABI
 // declared in include/gnnb_hip.h.
 //
 // Sequencing follows the reference's generated top (gnnbuilder/templates/model.cpp.jinja):
