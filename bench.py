@@ -163,17 +163,24 @@ def measure_segmented_gemm(w, N, dev, iters=50):
                 frac=flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, shape=f"M={N} K={K} N={d}", what=what)
 
 
-def pmc_traffic(kind="aggregate"):
-    """HBM bytes per launch of a kernel from the latest committed rocprofv3 PMC passes (FETCH_SIZE x2 on
-    gfx950 + WRITE_SIZE, tools/profile_r.sh -> profiles/*_<kind>_pmc.json).  Counters cannot be read from
-    inside this process; None when no profile is committed."""
+def pmc_traffic(kind, workload, alg_bytes):
+    """HBM bytes per launch of kernel `kind` AT THIS WORKLOAD from the latest committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/profile_r.sh -> profiles/<round>_<workload>_<kind>_pmc.json).
+    Counters cannot be read from inside this process, so this is a replay of a committed profile
+    (`measured_in_this_run`: false), and only of one taken on the same launch: the profile's algorithmic
+    byte count must agree with this run's within 2 %.  None when there is no such profile."""
     try:
-        files = sorted((ROOT / "profiles").glob(f"*_{kind}_pmc.json"))
+        files = sorted((ROOT / "profiles").glob(f"*_{workload}_{kind}_pmc.json"))
+        if not files and workload == "c2":  # rounds 1-2 named the config-2 profiles without the workload
+            files = sorted(f for f in (ROOT / "profiles").glob(f"r0[12]*_{kind}_pmc.json"))
         d = json.loads(files[-1].read_text())
+        ref = d.get("algorithmic_bytes_per_launch", d.get("algorithmic_hbm_bytes_per_launch"))
+        if not ref or abs(ref - alg_bytes) > 0.02 * alg_bytes:
+            return None
         t = d["hbm_traffic_bytes_per_launch"]
         return {"bytes_per_launch": t["total"], "read_bytes_fetch_size_x2": t["read_corrected_x2"],
-                "write_bytes": t["write"], "over_algorithmic": t["over_algorithmic"],
-                "source": f"profiles/{files[-1].name} (rocprofv3 --pmc, separate passes)"}
+                "write_bytes": t["write"], "over_algorithmic": t["total"] / alg_bytes, "measured_in_this_run": False,
+                "source": f"committed profile profiles/{files[-1].name} (rocprofv3 --pmc, separate passes, same workload)"}
     except Exception:
         return None
 
@@ -350,33 +357,72 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def self_launch(n, argv):
+def self_launch(n, argv, poll_s=0.2, overall_timeout_s=None):
     """Parent of `python bench.py --gpus N` (no launcher around it): start N rank processes of this same
     script and relay rank 0's JSON line.  The parent makes NO GPU call (no torch.cuda, no HIP library
-    load) and never exec()s; a failing rank makes it exit non-zero."""
+    load) and never exec()s.  It polls EVERY child: the first rank that exits non-zero (bad device, import
+    error, a crash in a kernel) makes the parent terminate the others -- they would otherwise sit in
+    init_process_group / barrier until the collective timeout -- and exit 1 within seconds.  An overall
+    timeout (BENCH_LAUNCH_TIMEOUT_S, default 1800 s) bounds a hang of all ranks."""
+    import tempfile
+    import threading
+
+    if overall_timeout_s is None:
+        overall_timeout_s = float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "1800"))
+    # The rendezvous port: bind to port 0, read the number, close.  Another process could take it before rank 0
+    # binds (a benign race: the ranks then fail fast with "address in use" and so does the parent).
     port = _free_port()
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")  # rank 0's stdout: a file, so that no pipe can fill up while we poll
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for l in (out0 or "").splitlines():
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+
+    def stop_all():
+        for p in procs:  # the children we started, by handle: never by pattern
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t0 = time.monotonic()
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = f"ranks failed (rank, exit code): {bad}; the other ranks were terminated"
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() - t0 > overall_timeout_s:
+            failed = f"no result after {overall_timeout_s:.0f} s: ranks terminated"
+            break
+        time.sleep(poll_s)
+    if failed:
+        stop_all()
+    out0.seek(0)
+    for l in out0.read().splitlines():
         # rank 0's JSON line goes to stdout; anything else a library printed there (gloo / RCCL banners) to stderr
         try:
             json.loads(l)
-            print(l)
+            if not failed:
+                print(l)
         except ValueError:
             if l.strip():
                 print(l, file=sys.stderr)
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+    if failed:
+        print(f"bench.py: {failed}", file=sys.stderr)
         sys.exit(1)
     sys.exit(0)
 
@@ -424,10 +470,18 @@ def main():
     from gnnbuilder_amd.batching import shard_bounds
 
     dry = args.dry_launch
+    if os.environ.get("BENCH_TEST_FAIL_RANK") == str(rank):  # launcher test hook: this rank dies at start-up
+        print(f"bench.py: rank {rank} exiting 3 (BENCH_TEST_FAIL_RANK)", file=sys.stderr)
+        sys.exit(3)
     if dry:
         dev = torch.device("cpu")
         torch.set_num_threads(1)
     else:
+        # (device_count() does not initialise the GPU on this image: safe before anything else)
+        ndev = torch.cuda.device_count()
+        if ndev <= local_rank:
+            print(f"bench.py: rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible", file=sys.stderr)
+            sys.exit(4)
         runtime.load_library(require_gpu=True)  # no fallback: fail loudly without the HIP path
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
@@ -627,7 +681,7 @@ def main():
         gather = {
             "kernel": "k_aggregate_ring<GCN> (gather-aggregate, width %d)" % w["hidden"],
             "bound": "hbm", "achieved": agg["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic("aggregate"),
+            "frac": agg["hbm"]["gbps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic("aggregate", args.workload, alg_bytes),
             "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": agg["hbm"]["us"],
             "regime": "inputs/outputs rotate over >256 MiB of distinct buffers (HBM-served); launches issued "
                       "back to back from C, HIP events on the launch stream",
@@ -640,12 +694,23 @@ def main():
                    unit="TFLOP/s", traffic=None, **measure_update_mfma(w, batches[0].num_nodes, dev))
         if fused is not None:
             # the step runs the fused stack: that kernel dominates it and is bound by the fp32 matrix rate
+            step_us = elapsed / args.steps * 1e3 * 1e3 / 1.0
             result["roofline"] = {
-                "kernel": "k_gcn2_fused (%d %s layers + pooling in one persistent kernel, graphs staged in LDS)" % (w["layers"], w["conv"].upper()),
+                "kernel": "%s (%d %s layers + pooling in one persistent kernel, graphs staged in LDS)" % (cm.stack_kernel_name(), w["layers"], w["conv"].upper()),
                 "bound": "mfma", "achieved": fused["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("gcn2") if w["conv"] == "gcn" and w["layers"] == 2 else None,
+                "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": pmc_traffic("gcn2", args.workload, fused["alg_bytes"]),
                 "algorithmic_flops_per_launch": fused["flops"], "algorithmic_hbm_bytes_per_launch": fused["alg_bytes"],
-                "us_per_launch": fused["us"], "share_of_step": fused["us"] / (ms_noprep * 1e3),
+                "us_per_launch": fused["us"],
+                # the solo launch time against the one-stream prepared forward (NOT against the timed step: with
+                # several batches in flight the stack kernels of consecutive batches overlap their edges)
+                "share_of_single_stream_forward": fused["us"] / (ms_noprep * 1e3),
+                # the same flops against the timed step itself: what the kernel delivers inside the pipeline
+                "in_pipeline": {"us_per_step": step_us, "achieved": fused["flops"] / (step_us * 1e-6) / 1e12,
+                                "frac": fused["flops"] / (step_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                "note": "algorithmic flops of one launch / time per timed step (graph prep and readout of "
+                                        "other batches run beside the kernel; a solo launch can be LONGER than a step "
+                                        "when consecutive launches overlap on the chip)"},
                 "note": "flops = the dense updates on v_mfma_f32_16x16x4_f32 (GCN: 2 N (F0 h0 + h0 h1); GIN: 2 N (F0 h + (2L - 1) h^2)); "
                         "HIP events on the launch stream, launches issued back to back from C on one prepared batch",
             }

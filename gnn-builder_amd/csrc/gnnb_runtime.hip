@@ -57,7 +57,7 @@ Options &options()
                         env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_GEMM_DMA", 1),
                         env_int("GNNB_GEMM_WLDS", 1),             env_int("GNNB_GEMM_WLDS_SLOTS", 2),
-                        env_int("GNNB_FUSE_NARROW", 1),
+                        env_int("GNNB_FUSE_NARROW", 1),     env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_ZF_SHAPE", 1),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
                         env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 1)};
@@ -163,6 +163,7 @@ struct gnnb_workspace {
     float *mlp[2] = {nullptr, nullptr}; // [max_graphs, max(mlp_hidden, mlp_out)]
     bool prepared = false;
     int max_graph_nodes = 0; // caller's promise (0 = none)
+    int last_path = GNNB_PATH_NONE; // which kernels the last forward on this workspace ran (gnnb_workspace_last_path)
     int device = 0;
     int32_t *err_host = nullptr; // host-mapped word the prep kernel drops "flagged" into (lazy detection, see gnnb_graph_prep)
     char *stage = nullptr;   // device staging of the host-buffer entry (x | coo | node_ptr | edge_ptr | out), sized for
@@ -211,6 +212,10 @@ int gnnb_set_option(const char *name, int value)
         o.fuse_narrow = value;
     else if (!strcmp(name, "fuse_gcn2") && value >= 0 && value <= 1)
         o.fuse_gcn2 = value;
+    else if (!strcmp(name, "fuse_zf") && value >= 0 && value <= 1)
+        o.fuse_zf = value;
+    else if (!strcmp(name, "zf_shape") && value >= 0 && value <= 1)
+        o.zf_shape = value;
     else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
         o.fuse_head = value;
     else if (!strcmp(name, "head_split") && value >= 0 && value <= 1)
@@ -466,6 +471,8 @@ void gnnb_workspace_destroy(gnnb_workspace *ws)
 
 size_t gnnb_workspace_bytes(const gnnb_workspace *ws) { return ws ? ws->bytes : 0; }
 
+int gnnb_workspace_last_path(const gnnb_workspace *ws) { return ws ? ws->last_path : GNNB_PATH_NONE; }
+
 int gnnb_workspace_set_max_graph_nodes(gnnb_workspace *ws, int n)
 {
     if (!ws || n < 0)
@@ -506,11 +513,13 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     // one 64-row stage (48 in the bf16x6 mode): for graphs of 50..61 nodes finer tiles (8, 4) keep that path open
     if (options().fuse_gcn2 && (ws->desc.conv_type == GNNB_CONV_GCN || ws->desc.conv_type == GNNB_CONV_GIN) && ws->desc.num_layers >= 2 &&
         ws->max_graph_nodes > 0) {
-        const int stage_rows = options().math ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
+        // (a 2-layer fp32 GCN stack runs k_gcn2_zf with its 96-row stages; everything else k_gcn2_fused)
+        const bool zf = ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && options().fuse_zf && !options().math;
+        const int stage_rows = zf ? zf_stage_rows() : options().math ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
         while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > stage_rows)
             t.tile_rows >>= 1;
         // very large batches: coarser tiles (while a tile still fits a stage) keep the per-workgroup tile table in LDS
-        static const long tile_cap = gcn2_fused_tile_capacity();
+        const long tile_cap = zf ? gcn2_zf_tile_capacity() : gcn2_fused_tile_capacity();
         while ((num_nodes + t.tile_rows - 1) / t.tile_rows > tile_cap && ws->max_graph_nodes + 2 * t.tile_rows - 1 <= stage_rows)
             t.tile_rows <<= 1;
     }
@@ -729,6 +738,27 @@ static G2Deep gcn_stack_middle_layers(const gnnb_model *model)
     return g;
 }
 
+// The LDS-resident conv stack + pooling for this model on the prepared batch -> ws->pooled.  hipErrorNotSupported when
+// no stack kernel takes the model / batch (the caller runs layer by layer); *path says which kernel ran.
+static hipError_t launch_conv_stack(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, const G2Deep &deep,
+                                    hipStream_t s, int *path)
+{
+    const gnnb_model_desc &d = model->desc;
+    const int L = d.num_layers;
+    hipError_t he = hipErrorNotSupported;
+    if (!deep.gin && L == 2) // two GCN layers, fp32: the transform-first form with 96-row stages (k_stack_zf.hip)
+        he = launch_gcn2_zf(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim, model->conv[1][0],
+                            model->conv[1][1], d.out_dim, d.activation, d.pools, d.num_pools, ws->pooled, s);
+    *path = GNNB_PATH_STACK_ZF;
+    if (he == hipErrorNotSupported) {
+        *path = GNNB_PATH_STACK;
+        he = launch_gcn2_fused(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
+                               model->conv[L - 1][0], model->conv[L - 1][1], d.out_dim, d.activation, d.pools,
+                               d.num_pools, ws->pooled, s, deep);
+    }
+    return he;
+}
+
 static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, float *out_dev,
                                  void *stream);
 
@@ -772,10 +802,7 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
     // ---- fused path: the whole GCN stack (two or more layers) + pooling in one persistent kernel, then the MLP head
     const G2Deep deep = gcn_stack_middle_layers(model);
     if (!fpx && deep.nl >= 2 && d.mlp_num_linear <= 8) {
-        const int L = d.num_layers;
-        hipError_t he = launch_gcn2_fused(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
-                                          model->conv[L - 1][0], model->conv[L - 1][1], d.out_dim, d.activation, d.pools,
-                                          d.num_pools, ws->pooled, (hipStream_t)stream, deep);
+        hipError_t he = launch_conv_stack(model, ws, x_dev, deep, (hipStream_t)stream, &ws->last_path);
         if (he == hipSuccess) {
             HeadArgs head;
             memset(&head, 0, sizeof(head));
@@ -812,6 +839,7 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
             return fail(GNNB_ERR_HIP, "fused GCN stack launch failed: %s", hipGetErrorString(he));
     }
 
+    ws->last_path = GNNB_PATH_LAYERWISE;
     const float *cur = x_dev;
     int which = 0;
     for (int l = 0; l < d.num_layers; l++) {
@@ -1071,17 +1099,11 @@ int gnnb_gcn_stack_timed(const gnnb_model *model, gnnb_workspace *ws, const floa
         return fail(GNNB_ERR_INVALID, "bad argument to gnnb_gcn_stack_timed");
     if (!ws->prepared)
         return fail(GNNB_ERR_INVALID, "workspace has no prepared batch");
-    const gnnb_model_desc &d = model->desc;
     const G2Deep deep = gcn_stack_middle_layers(model);
     if (deep.nl < 2)
         return fail(GNNB_ERR_INVALID, "the fused stack exists for GCN / GIN models of two or more layers");
     hipStream_t s = (hipStream_t)stream;
-    auto launch = [&]() {
-        const int L = d.num_layers;
-        return launch_gcn2_fused(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
-                                 model->conv[L - 1][0], model->conv[L - 1][1], d.out_dim, d.activation, d.pools,
-                                 d.num_pools, ws->pooled, s, deep);
-    };
+    auto launch = [&]() { return launch_conv_stack(model, ws, x_dev, deep, s, &ws->last_path); };
     hipEvent_t e0, e1;
     GNNB_HIP_TRY(hipEventCreate(&e0));
     GNNB_HIP_TRY(hipEventCreate(&e1));

@@ -4,5 +4,6 @@
 #include "k_gemm.hip"
 #include "k_readout.hip"
 #include "k_stack.hip"
+#include "k_stack_zf.hip"
 #include "k_misc.hip"
 #include "gnnb_runtime.hip"

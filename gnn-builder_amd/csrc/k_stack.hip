@@ -1,6 +1,6 @@
 // k_stack.hip -- whole GCN / GIN conv stack + pooling in one persistent kernel (k_gcn2_fused)
 // Part of libgnnb_hip.so (hand-written gfx950 / CDNA4 kernels of the GNNBuilder hot path); wavefront = 64 lanes.
-#include "gnnb_device.h"
+#include "gnnb_stack.h"
 
 namespace gnnb {
 
@@ -27,37 +27,6 @@ namespace gnnb {
 // rows per stage: FOUR 16-row MFMA units (64 rows) -- a stage costs ~13 k cycles of barriers and latency chains whatever
 // it holds, and three molecules fill 54 of 64 rows where two filled 36 of 48.  The bf16x6 mode keeps three units (its A1
 // is three bf16 planes: 1.5x the bytes, and two workgroups must stay resident per CU).
-__host__ __device__ constexpr int g2_units(int math) { return math ? 3 : 4; }
-static_assert(16 * g2_units(0) == GNNB_G2_STAGE_ROWS && 16 * g2_units(1) == GNNB_G2_STAGE_ROWS_BF6, "graph prep picks the tile size against these");
-static constexpr int G2_TCAP = 64;           // tile-table entries a workgroup keeps in LDS
-static constexpr int G2_WG = 512;            // 8 waves; two workgroups per CU = 4 waves per SIMD
-static constexpr int G2_NW = G2_WG / 64;
-
-struct G2Stage {
-    int ta, tb, nb, rows, ga, gb;
-};
-
-// Sum / max of a value over the four 16-lane rows of a wave (same lane index in each row) with the
-// gfx950 row-swap instructions -- two VALU operations per step instead of an LDS crossbar round trip.
-__device__ __forceinline__ float rows4_sum(float x)
-{
-    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-__device__ __forceinline__ float rows4_max(float x)
-{
-    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-// Workgroup barrier of the fused kernel: LDS traffic drained, NO vector-memory drain.  __syncthreads()
-// carries a fence, for which the compiler emits s_waitcnt vmcnt(0) whenever it has stores of its own in
-// flight (the pooled outputs) -- and that would also wait for the untracked DMA of the next stage.
-__device__ __forceinline__ void g2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // One MFMA phase of the fused stack: v[k][r] = act(A . Wslice^T + bias) for the wave's 16 columns and
 // the rows (rg + k nrg) * 16 + lg * 4 + r of its units k < NU (NU wave-uniform).  The units'
 // accumulators are interleaved so that dependent MFMAs are >= 2 issues apart (NU == 1: the k range
@@ -872,7 +841,12 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
         else if (kq0 == 2 && kq1 == 4) go(atag, IntTag<2>{}, IntTag<4>{});
         else go(atag, IntTag<2>{}, IntTag<2>{});
     };
+#ifdef GNNB_DEV_FAST // development builds: only the BASELINE config 2 instantiation (seconds instead of minutes to compile)
+    if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && !deep.gin && !math && deep.nl == 2)
+        go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<0>{});
+#else
     GNNB_DISPATCH_ACT(act, go_q)
+#endif
     return rc;
 }
 

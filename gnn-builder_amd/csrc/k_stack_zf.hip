@@ -1,0 +1,808 @@
+// k_stack_zf.hip -- 2-layer GCN stack + pooling in one persistent kernel, last layer TRANSFORMED BEFORE it is aggregated
+// Part of libgnnb_hip.so (hand-written gfx950 / CDNA4 kernels of the GNNBuilder hot path); wavefront = 64 lanes.
+#include "gnnb_stack.h"
+
+namespace gnnb {
+
+// =====================================================================================
+// k_gcn2_zf: the BASELINE config 1 / 2 model family (two GCN layers, fp32), round 3
+// =====================================================================================
+// Reference dataflow being fused: compute_gnn_head with two gcn_conv layers (templates/model.cpp.jinja:151-359,
+// gnn_builder_lib.h:1213-1387: aggregate, then `linear`, then the activation) + compute_global_graph_pooling
+// (:413-449, global_*_pool lib:2709-2803).
+//
+// Difference to k_gcn2_fused (k_stack.hip), which keeps the reference's aggregate-then-transform order in both layers
+// and needs a second [rows, h0] LDS matrix A1 for the aggregated hidden rows:
+//   layer 1 here is   out = act( A^ . (H . W1^T) + b1 )   instead of   act( (A^ . H) . W1^T + b1 )
+// -- the same mathematics up to fp32 summation order (both are a double sum over neighbours j and hidden units k).
+// The product Z = H . W1^T is formed on the matrix cores straight from H, kept in the accumulators across one barrier
+// and written back OVER H; the aggregation then runs on Z, one wave per GRAPH, each lane group walking its rows in
+// order with bias / activation applied on the way and the add / mean / max pooling accumulated in registers.  What
+// this buys on this chip (fp32 MFMA and VALU instructions share one issue port, so every VALU instruction is paid in
+// matrix slots -- DESIGN 3.5):
+//   * no A1 buffer: 34 KB less LDS per 64 rows, spent on BIGGER stages -- up to 96 rows (6 MFMA units) with two
+//     workgroups per CU, so a workgroup's share of the BASELINE config 2 batch (~144 rows) is two stages instead of
+//     three or four, and the fixed per-stage chain (DMA wait, four barriers, the two narrow phases) is paid less often;
+//   * pooling without masks: the old form pooled the accumulator tiles of M1 (rows spread over registers and lane
+//     groups, ~7 VALU per element and graph for the in / out-of-graph selects); here a graph's rows arrive one after
+//     the other in one lane group: 2 VALU per element;
+//   * stages are planned BALANCED (equal shares of the workgroup's rows, cut at graph boundaries) instead of greedily
+//     filled: with a 96-row stage capacity against ~72 rows needed, every workgroup of the config 2 batch runs exactly
+//     two stages and the kernel no longer ends with the one workgroup in ten that needed an extra stage;
+//   * P0 of stage s+1 (the narrow aggregate of the raw features) runs in the same barrier interval as the wide
+//     aggregate of stage s, on the waves that have no graph to reduce: four barriers per stage, not five.
+//
+// Per stage s (rows of whole graphs, <= 96):
+//   top   issue DMA: raw x rows + node records of stage s+1 -> ROWS (single buffer: P0(s) is done), dinv + graph
+//         boundaries of s+1 -> SMALL[(s+1)&1]                                                   (global_load_lds)
+//   M0    H = act(A0 . W0^T + b0)                 MFMA 16x16x4, W0 slice in registers           A0 -> H
+//   ---- barrier
+//   M1    Z = H . W1^T                            MFMA, W1 slice (16 cols x K) in registers     H -> accumulators
+//   wait  own DMA of stage s+1 landed (vmcnt(0): nothing younger is in flight)
+//   ---- barrier   (everybody has read H; everybody's DMA is in)
+//   ZW    Z -> H (in place)
+//   ---- barrier
+//   P1    per graph (one wave each): out_i = act(sum_j c_ij Z_j + c_ii Z_i + b1), pooled add / mean / max -> HBM
+//   P0'   A0 = aggregate(x) of stage s+1 (eight lanes per row) + its per-row records REC[(s+1)&1]
+//   ---- barrier
+// HBM traffic = x + tables in, [B, np*h1] out (as k_gcn2_fused).  Bound: fp32 MFMA.
+// Needs: GCN, exactly two layers, fp32 math mode, F0 <= 32, h0 in {32,64,128}, h1 <= 128 (h1 % 4 == 0), and the caller's
+// promise max_graph_nodes <= 96 - (tile_rows - 1) (validated by graph prep).
+// Two shapes (runtime option zf_shape): 1 = ONE workgroup of 16 waves per CU, stages of up to 160 rows (10 MFMA units)
+// -- all waves of a CU move through the phases together, so the narrow VALU phases never compete with another
+// workgroup's MFMA stream (a VALU instruction that does costs a whole 32-cycle MFMA slot: they share the issue port and a
+// single wave cannot issue fast enough to keep the MFMA waves out); 0 = two workgroups of 8 waves, stages of up to 96 rows.
+static constexpr int ZF_TCAP = 128;          // tile-table entries a workgroup keeps in LDS
+#ifndef ZF_PRIO
+#define ZF_PRIO 2
+#endif
+
+// accumulate NU 16-row units (rows row0[k] + li) x the wave's 16-column slice over K = 16 KQ:
+// acc[k] += A[rows of unit k][:] . Wslice^T.  Fragments of k block q+1 are requested before the MFMAs of block q.
+template <int KQ, int NU>
+__device__ __forceinline__ void zf_mma(const float *__restrict__ A, int lda, const float (&wr)[KQ * 4], const int (&row0)[NU],
+                                       int li, int lg, f32x4 (&acc)[NU])
+{
+    const float *ap[NU];
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+        ap[k] = A + (row0[k] + li) * lda + lg * 4;
+    float4 a4[NU], an[NU];
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+        a4[k] = *reinterpret_cast<const float4 *>(ap[k]);
+#pragma unroll
+    for (int q = 0; q < KQ; q++) {
+        if (q + 1 < KQ) {
+#pragma unroll
+            for (int k = 0; k < NU; k++)
+                an[k] = *reinterpret_cast<const float4 *>(ap[k] + 16 * (q + 1));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int k = 0; k < NU; k++) {
+                const float av = t == 0 ? a4[k].x : (t == 1 ? a4[k].y : (t == 2 ? a4[k].z : a4[k].w));
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[q * 4 + t], acc[k], 0, 0, 0);
+            }
+        if (q + 1 < KQ) {
+#pragma unroll
+            for (int k = 0; k < NU; k++)
+                a4[k] = an[k];
+        }
+    }
+}
+
+struct ZfStage {
+    int ta, tb, nb, rows, ga, gb, e0, ne;
+};
+
+template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS, int CH>
+__global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
+    const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
+    const int32_t *__restrict__ col, const float *__restrict__ dinv,
+    const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_graph, const int32_t *__restrict__ tile_edge,
+    const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, int N, int E, const float *__restrict__ W0,
+    const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ b1,
+    int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ZF_CAP = 16 * ZF_UNITS, G2_NW = NW, G2_WG = NW * 64, G2_TCAP = ZF_TCAP;
+    constexpr int GMAX = ZF_CAP <= 96 ? 64 : 128; // graph boundaries of a stage kept in LDS (more: empty graphs piling up)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- LDS carve (bytes, every region 16-B aligned; LDS pointers are always derived arithmetically from `smem`:
+    // runtime-indexed arrays of LDS pointers turn into FLAT accesses, see k_stack.hip)
+    //   ROWS   xs | srec                     ONE buffer (P0 is its only reader; refilled one stage ahead)
+    //   SMALL  sdinv | node_ptr of <= 64 graphs (+ end)      TWO buffers
+    //   A0     [CAP][LD0]                    P0 -> M0
+    //   H      [CAP][ldh]                    M0 -> M1, then Z in place -> P1
+    //   REC    [CAP] x 48 B                  TWO buffers (P0 of the next stage writes while P1 of this one reads)
+    //   SCOL   [ECAP] int32                  TWO buffers: the stage's slice of the CSR `col` array, for rows of degree > 4
+    //                                        (a tracked global read there costs a full memory round trip per neighbour)
+    //   stile, sgraph, sedge                 the workgroup's run of the tile tables
+    constexpr int LD0 = 16 * KQ0; // A0 row: F0 values zero-padded to whole 16-wide MFMA k blocks
+    const int xs_b = ((ZF_CAP * f0 * 4) + 15) & ~15;
+    const int rows_b = xs_b + ZF_CAP * 32;
+    constexpr int small_b = ZF_CAP * 4 + ((GMAX + 1) * 4 + 15) / 16 * 16;
+    constexpr int a0_b = ZF_CAP * LD0 * 4;
+    const int ldh = (h0 > h1 ? h0 : h1) + 4; // padded H / Z row (floats): conflict-free fragment reads, base + immediate
+    const int ldhb = ldh * 4;
+    constexpr int rec_b = ZF_CAP * 48;
+    float *A0 = reinterpret_cast<float *>(smem + rows_b + 2 * small_b);
+    float *H = reinterpret_cast<float *>(smem + rows_b + 2 * small_b + a0_b);
+    char *RECb = reinterpret_cast<char *>(H) + ZF_CAP * ldhb;
+    constexpr int ECAP = ZF_CAP <= 96 ? 512 : 1024;
+    char *SCOLb = RECb + 2 * rec_b;
+    int32_t *stile = reinterpret_cast<int32_t *>(SCOLb + 2 * ECAP * 4);
+    int32_t *sgraph = stile + (G2_TCAP + 1);
+    int32_t *sedge = sgraph + (G2_TCAP + 1);
+
+    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
+    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    if (t1 <= t0)
+        return;
+    // (the weight loads go out FIRST: they depend on nothing and their latency then overlaps the tile-table round trip)
+    // ---- wave roles: layer L has ncs_L = pow2ceil(h_L / 16) column slices of 16 and nrg_L = 8 / ncs_L row groups;
+    // wave w owns slice (w mod ncs) for the units rg, rg + nrg, ... with rg = w / ncs
+    int cs0l = 0, cs1l = 0;
+    while ((16 << cs0l) < h0)
+        cs0l++;
+    while ((16 << cs1l) < h1)
+        cs1l++; // h <= 128 -> <= 3
+    const int nrg0 = G2_NW >> cs0l, nrg1 = G2_NW >> cs1l;
+    // lanes per row in P1: the next power of two >= h1 / (4 CH) (CH float4 chunks per lane: gl, gl + Gl)
+    int glog2 = 2;
+    while ((4 * CH << glog2) < h1 && glog2 < 5)
+        glog2++;
+    const int Gl = 1 << glog2;
+
+    // ---- weight slices -> registers (16 output columns x K per layer and wave), biases
+    float w0r[KQ0 * 4];
+    float bias0;
+    float4 bias1[CH];
+    {
+        const int li = lane & 15, lg = lane >> 4;
+        const int n0c = (wave & ((1 << cs0l) - 1)) * 16 + li, n1c = (wave & ((1 << cs1l) - 1)) * 16 + li;
+#pragma unroll
+        for (int q = 0; q < KQ0; q++) {
+            const int k = 16 * q + 4 * lg;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0c < h0)
+                v = load4_guard(W0 + (size_t)n0c * f0 + k, f0 - k, false);
+            w0r[q * 4 + 0] = v.x;
+            w0r[q * 4 + 1] = v.y;
+            w0r[q * 4 + 2] = v.z;
+            w0r[q * 4 + 3] = v.w;
+        }
+        bias0 = (n0c < h0 && b0) ? b0[n0c] : 0.0f;
+        const int gl = lane & (Gl - 1);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            bias1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b1 && (gl + c * Gl) * 4 < h1)
+                bias1[c] = *reinterpret_cast<const float4 *>(b1 + (gl + c * Gl) * 4); // (h1 % 4 == 0, b1 16-B aligned: checked by the launcher)
+        }
+    }
+    // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
+    for (int i = tid; i <= t1 - t0; i += G2_WG) {
+        stile[i] = min(max(tile_first[t0 + i], 0), N);
+        sgraph[i] = min(max(tile_graph[t0 + i], 0), num_graphs);
+        sedge[i] = min(max(tile_edge[t0 + i], 0), E);
+    }
+    __syncthreads();
+
+    // ---- balanced stage plan: the rows that are left are cut into the fewest stages that can hold them, of EQUAL
+    // size, at tile (= graph) boundaries.  A stage takes the boundary closest to its share; boundaries that would
+    // leave more than the remaining stages can hold are only taken when there is no other (then the largest).
+    auto plan = [&](int ta) {
+        ZfStage st;
+        st.ta = ta;
+        st.tb = ta;
+        st.nb = 0;
+        st.rows = 0;
+        st.ga = 0;
+        st.gb = 0;
+        st.e0 = 0;
+        st.ne = 0;
+        if (ta >= t1)
+            return st;
+        st.nb = stile[ta - t0];
+        const int rrem = stile[t1 - t0] - st.nb; // (re-read per call: kept in a register across the stage loop it is spilled)
+        const int krem = max((rrem + ZF_CAP - 1) / ZF_CAP, 1);
+        const int target = (rrem + krem - 1) / krem;
+        const int rmin = rrem - (krem - 1) * ZF_CAP;
+        int tb = ta + 1, bestd = 1 << 30;
+        for (int c = ta + 1; c <= t1; c++) {
+            const int r = stile[c - t0] - st.nb;
+            if (r > ZF_CAP)
+                break;
+            const int d = r < rmin ? 4096 + (rmin - r) : (r > target ? r - target : target - r);
+            if (d <= bestd) { // (ties: the later boundary, so that empty tiles are swallowed)
+                bestd = d;
+                tb = c;
+            }
+        }
+        st.tb = tb;
+        st.rows = max(min(stile[tb - t0] - st.nb, ZF_CAP), 0); // (> CAP only if the max_graph_nodes promise is broken)
+        st.ga = sgraph[ta - t0];
+        // (empty graphs after the last node belong to the last stage: when N is a multiple of the tile
+        // size the first of them already owns tile_graph[num_tiles])
+        st.gb = max(tb == num_tiles ? num_graphs : sgraph[tb - t0], st.ga);
+        st.e0 = sedge[ta - t0];
+        st.ne = max(sedge[tb - t0] - st.e0, 0);
+        return st;
+    };
+    // the stage's rows (x, node records) -> ROWS
+    auto issue_rows = [&](const ZfStage &st, int bb, int lane, int wave) {
+        if (st.ta >= t1)
+            return;
+        dma_dwords_u(x + (size_t)st.nb * f0, smem, st.rows * f0, wave, lane, G2_NW);
+        if (st.ne <= ECAP) // (a stage with more edges -- hubs, multigraphs -- reads `col` from global memory)
+            dma_dwords_u(col + st.e0, SCOLb + (size_t)bb * ECAP * 4, st.ne, (wave + G2_NW / 2) & (G2_NW - 1), lane, G2_NW);
+        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
+        const int rbytes = st.rows * 32; // 1 KiB per wave: waves 0 .. CAP / 32 - 1
+        if (wave * 1024 + lane * 16 < rbytes)
+            dma16_to_lds_u(grec + wave * 1024 + lane * 16, smem + xs_b + wave * 1024);
+    };
+    // its normalisers and graph boundaries -> SMALL[bb]
+    auto issue_small = [&](const ZfStage &st, int bb, int lane, int wave) {
+        if (st.ta >= t1)
+            return;
+        // (a stage may have NO rows and still own graphs: empty graphs behind a graph that ends on the
+        // tile edge -- their boundaries are still needed by the pooling)
+        char *base = smem + rows_b + (size_t)bb * small_b;
+        // 64-dword pieces, one per wave from wave 3 on: ND pieces of dinv, then NG pieces of the graph boundaries of
+        // the stage (first GMAX graphs; more only if empty graphs pile up, those are read from global memory)
+        constexpr int ND = (ZF_CAP + 63) / 64, NG = (GMAX + 1 + 63) / 64;
+        static_assert(3 + ND + NG <= NW, "one small-DMA piece per wave");
+        const int pc = wave - 3;
+        const int ng = min(st.gb - st.ga, GMAX) + 1;
+        if (pc >= 0 && pc < ND) {
+            if (pc * 64 + lane < st.rows)
+                dma4_to_lds_u(dinv + st.nb + pc * 64 + lane, base + pc * 256);
+        } else if (pc >= ND && pc < ND + NG) {
+            const int o = (pc - ND) * 64;
+            if (o + lane < ng)
+                dma4_to_lds_u(node_ptr + st.ga + o + lane, base + ZF_CAP * 4 + o * 4);
+        }
+    };
+
+    // the first stage's inputs start their way to LDS before the weights are fetched (both are waited for below)
+    ZfStage cur = plan(t0);
+    issue_small(cur, 0, lane, wave);
+    issue_rows(cur, 0, lane, wave);
+
+    // Pin every weight register through an (empty) asm: the compiler must finish the loads HERE (k_stack.hip: left
+    // alone it guards their first use inside the stage loop with s_waitcnt vmcnt(0), which also waits for the DMA)
+#pragma unroll
+    for (int q = 0; q < KQ0 * 4; q++)
+        asm volatile("" : "+v"(w0r[q]));
+    asm volatile("" : "+v"(bias0));
+#pragma unroll
+    for (int c = 0; c < CH; c++)
+        asm volatile("" : "+v"(bias1[c].x), "+v"(bias1[c].y), "+v"(bias1[c].z), "+v"(bias1[c].w));
+    dma_wait_all();
+    __syncthreads();
+
+    const int pools[3] = {p0, p1, p2};
+
+    // ---- P0: A0[i][f] = sum_j x_j[f] dinv_i dinv_j + x_i[f] dinv_i^2   (CSR order, self last) and the per-row record
+    // for P1: {byte offsets of the 4 inline neighbour rows in H}{coefficients dinv_i dinv_j, 0 past the degree}
+    // {dinv_i^2, rp0, deg, dinv_i}.  Eight lanes per row, lane l8 takes features l8, l8 + 8, ...; a wave pass = 8 rows;
+    // wave-pass p of the stage is done by wave (pstart + p) mod 8.  Every LDS load is unconditional (unused neighbour
+    // slots alias the row itself, inactive lanes read row 0) and the degree only selects.
+    auto phase_p0 = [&](const ZfStage &st, int bb, int tv, int pstart) {
+        constexpr int T0 = LD0 / 8;
+        const float *xs = reinterpret_cast<const float *>(smem);
+        const int4 *srec = reinterpret_cast<const int4 *>(smem + xs_b);
+        const float *sdinv = reinterpret_cast<const float *>(smem + rows_b + (size_t)bb * small_b);
+        int4 *REC = reinterpret_cast<int4 *>(RECb + (size_t)bb * rec_b);
+        const int32_t *scol = reinterpret_cast<const int32_t *>(SCOLb + (size_t)bb * ECAP * 4);
+        const bool col_lds = st.ne <= ECAP;
+        const int e0 = st.e0;
+        const int wv = tv >> 6, l8 = tv & 7, r8 = (tv >> 3) & 7;
+        const int rows = st.rows, nb = st.nb;
+        const int npass = (rows + 7) >> 3;
+        for (int p = (wv - pstart) & (G2_NW - 1); p < npass; p += G2_NW) {
+            const int i = p * 8 + r8;
+            const bool active = i < rows;
+            const int ic = active ? i : 0;
+            const int4 r0 = srec[2 * ic], r1 = srec[2 * ic + 1];
+            const int deg = r0.y;
+            const int jl[4] = {r0.z - nb, r0.w - nb, r1.x - nb, r1.y - nb};
+            const float di = sdinv[ic];
+            float xv[T0][4], xself[T0], sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                sv[q] = sdinv[jl[q]];
+#pragma unroll
+                for (int t = 0; t < T0; t++) {
+                    const int f = l8 + 8 * t;
+                    xv[t][q] = xs[jl[q] * f0 + (f < f0 ? f : 0)];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T0; t++) {
+                const int f = l8 + 8 * t;
+                xself[t] = xs[ic * f0 + (f < f0 ? f : 0)];
+            }
+            float c[4], acc[T0];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                c[q] = deg > q ? di * sv[q] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < T0; t++) {
+                acc[t] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    acc[t] += xv[t][q] * c[q];
+            }
+            if (active) {
+                // degree > 4: the rest of the CSR row, from the stage's slice in LDS (two loops, not a select between an
+                // LDS and a global pointer: that becomes a flat load with a full drain)
+                auto more = [&](int j) {
+                    const float cj = di * sdinv[j];
+#pragma unroll
+                    for (int t = 0; t < T0; t++) {
+                        const int f = l8 + 8 * t;
+                        acc[t] += xs[j * f0 + (f < f0 ? f : 0)] * cj;
+                    }
+                };
+                if (col_lds) {
+                    for (int k = r0.x + 4; k < r0.x + deg; k++)
+                        more(scol[min(max(k - e0, 0), ECAP - 1)] - nb);
+                } else {
+                    for (int k = r0.x + 4; k < r0.x + deg; k++)
+                        more(col[k] - nb);
+                }
+#pragma unroll
+                for (int t = 0; t < T0; t++) {
+                    const int f = l8 + 8 * t;
+                    A0[i * LD0 + f] = f < f0 ? acc[t] + xself[t] * (di * di) : 0.0f;
+                }
+                if (l8 == 0) {
+                    REC[3 * i] = make_int4(jl[0] * ldhb, jl[1] * ldhb, jl[2] * ldhb, jl[3] * ldhb);
+                    REC[3 * i + 1] = make_int4(__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]), __float_as_int(c[3]));
+                    REC[3 * i + 2] = make_int4(__float_as_int(di * di), r0.x, deg, __float_as_int(di));
+                }
+            }
+        }
+    };
+
+#ifdef GNNB_PROBE
+    unsigned long long pt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = clock64(), pw0 = wall_clock64(), pt_last = pt0;
+    int nst = 0;
+#define ZF_PT(i) do { const unsigned long long _n = clock64(); pt[i] += _n - pt_last; pt_last = _n; } while (0)
+#else
+#define ZF_PT(i) do { } while (0)
+#endif
+
+    phase_p0(cur, 0, tid, 0);
+    ZfStage nxt = plan(cur.tb);
+    g2_barrier();
+    ZF_PT(0);
+
+    // Wave priority.  Two workgroups share a CU and fp32 MFMA and VALU instructions share one issue port: a wave in a
+    // narrow phase (DMA issue, P0, P1: a few hundred VALU / LDS instructions on the workgroup's critical path) that
+    // competes at equal priority with the other workgroup's two MFMA-streaming waves on its SIMD gets one instruction
+    // in per 32-cycle MFMA or two (measured: P1 12.8 k cycles per stage for ~400 instructions per wave).  The narrow
+    // phases therefore run at raised priority and only the long M1 stream at priority 0: the matrix pipe stays fed by
+    // whichever workgroup is in M1, and the other one's narrow phases cost what their instructions cost.
+    __builtin_amdgcn_s_setprio(ZF_PRIO);
+    int b = 0;
+    while (cur.ta < t1) {
+        // The thread index is re-made OPAQUE every stage and every per-lane quantity is derived from it again
+        // (otherwise the compiler hoists dozens of loop-invariant LDS offsets out of the stage loop and spills them)
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int li = tv & 15, lg = (tv >> 4) & 3, wv = tv >> 6;
+        const int rows = cur.rows, nb = cur.nb;
+        const int units = (rows + 15) >> 4;
+        // ---- top: the next stage's inputs start their way to LDS (ROWS: P0 of `cur` was its last reader)
+        issue_small(nxt, b ^ 1, tv & 63, wv);
+        issue_rows(nxt, b ^ 1, tv & 63, wv);
+        // the wave's W1 slice (16 columns x K) -> registers, requested here and first used behind M0 and a barrier.  It
+        // is re-read (from L2: every CU reads the same 64 KB) in every stage so that its 32 registers are free during
+        // P1 / P0, which need them for two rows of eight values in flight per lane
+        float w1r[KQ1 * 4];
+        {
+            const int n1c_ = (wv & ((1 << cs1l) - 1)) * 16 + li;
+#pragma unroll
+            for (int q = 0; q < KQ1; q++) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n1c_ < h1)
+                    v = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c_ * h0 + 16 * q + 4 * lg); // h0 == 16 * KQ1
+                w1r[q * 4 + 0] = v.x;
+                w1r[q * 4 + 1] = v.y;
+                w1r[q * 4 + 2] = v.z;
+                w1r[q * 4 + 3] = v.w;
+            }
+        }
+        ZF_PT(1);
+
+        // ---- M0: H = act(A0 . W0^T + b0)   (wave: column slice x row group)
+        {
+            const int n0c = (wv & ((1 << cs0l) - 1)) * 16 + li;
+            const int rg0 = wv >> cs0l;
+            auto m0 = [&](auto nutag, int ubase) {
+                constexpr int NU = decltype(nutag)::value;
+                int row0[NU];
+                f32x4 acc[NU];
+#pragma unroll
+                for (int k = 0; k < NU; k++) {
+                    row0[k] = (rg0 + (ubase + k) * nrg0) * 16;
+                    acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                zf_mma<KQ0, NU>(A0, LD0, w0r, row0, li, lg, acc);
+                if (n0c < h0) {
+#pragma unroll
+                    for (int k = 0; k < NU; k++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            H[(row0[k] + lg * 4 + r) * ldh + n0c] = act_t<ACT>(acc[k][r] + bias0);
+                }
+            };
+            const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
+            // (units in groups of three: register budget)
+            if (nu >= 3)
+                m0(IntTag<3>{}, 0);
+            else if (nu == 2)
+                m0(IntTag<2>{}, 0);
+            else if (nu == 1)
+                m0(IntTag<1>{}, 0);
+            if (nu == 6)
+                m0(IntTag<3>{}, 3);
+            else if (nu == 5)
+                m0(IntTag<2>{}, 3);
+            else if (nu == 4)
+                m0(IntTag<1>{}, 3);
+        }
+        ZF_PT(2);
+        g2_barrier(); // H complete
+        ZF_PT(3);
+
+        // ---- M1: Z = H . W1^T for the wave's column slice and its units: stays in the accumulators across the barrier
+        // (the ONLY phase at low priority: see the note on s_setprio at the top of the stage loop)
+        __builtin_amdgcn_s_setprio(0);
+        const int n1c = (wv & ((1 << cs1l) - 1)) * 16 + li;
+        const int rg1 = wv >> cs1l;
+        const int nu1 = rg1 < units ? (units - rg1 + nrg1 - 1) / nrg1 : 0;
+        constexpr int ZMAX = (ZF_UNITS * 8 + NW - 1) / NW; // units one wave can own (all eight column slices in use)
+        static_assert(ZMAX <= 6, "M0 / M1 handle up to two groups of three units per wave");
+        f32x4 z[ZMAX];
+#pragma unroll
+        for (int k = 0; k < ZMAX; k++)
+            z[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            auto m1 = [&](auto nutag, auto basetag) {
+                constexpr int NU = decltype(nutag)::value, UB = decltype(basetag)::value;
+                int row0[NU];
+                f32x4 acc[NU];
+#pragma unroll
+                for (int k = 0; k < NU; k++) {
+                    row0[k] = (rg1 + (UB + k) * nrg1) * 16;
+                    acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                zf_mma<KQ1, NU>(H, ldh, w1r, row0, li, lg, acc);
+#pragma unroll
+                for (int k = 0; k < NU; k++)
+                    if (UB + k < ZMAX)
+                        z[UB + k < ZMAX ? UB + k : 0] = acc[k];
+            };
+            if (nu1 >= 3)
+                m1(IntTag<3>{}, IntTag<0>{});
+            else if (nu1 == 2)
+                m1(IntTag<2>{}, IntTag<0>{});
+            else if (nu1 == 1)
+                m1(IntTag<1>{}, IntTag<0>{});
+            if (ZMAX >= 6 && nu1 == 6)
+                m1(IntTag<3>{}, IntTag<3>{});
+            else if (nu1 == 5)
+                m1(IntTag<2>{}, IntTag<3>{});
+            else if (nu1 == 4)
+                m1(IntTag<1>{}, IntTag<3>{});
+        }
+        __builtin_amdgcn_s_setprio(ZF_PRIO);
+        ZF_PT(4);
+        // own DMA of the next stage has landed (issued a whole M0 + M1 ago; nothing younger is outstanding except
+        // nothing: the pooled stores of the previous stage are older and retire first)
+        dma_wait_all();
+        g2_barrier(); // everybody has read H; everybody's DMA is in
+        ZF_PT(5);
+
+        // ---- ZW: Z -> H in place
+        if (n1c < h1) {
+#pragma unroll
+            for (int k = 0; k < ZMAX; k++)
+                if (k < nu1) {
+                    const int row0 = (rg1 + k * nrg1) * 16 + lg * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        H[(row0 + r) * ldh + n1c] = z[k][r];
+                }
+        }
+        g2_barrier(); // Z complete
+        ZF_PT(6);
+
+        // ---- P1 + pooling: graph gi of the stage is reduced by wave gi mod NW.  A lane holds CH float4 chunks of the row
+        // (chunks gl, gl + Gl, ...: Gl lanes per row), the wave's 64 / Gl lane groups take the graph's rows round robin and
+        // IN ORDER: out_i = act(sum_j c_ij Z_j + c_ii Z_i + b1)  (CSR order, self last, as the reference's gcn_conv), summed
+        // / maxed per lane, then combined across the lane groups (fixed order) and stored: 16-B stores, one per lane,
+        // chunk, graph and pool (reference global_add/mean/max_pool, gnn_builder_lib.h:2709-2803).  With two chunks per
+        // lane (h1 > 64) the per-row overhead (record, offsets, loop) is paid once per 8 values and a graph of 18 rows
+        // is five passes of the wave instead of nine.
+        const int ngr = cur.gb - cur.ga;
+        {
+            typedef Vf<4> V;
+            const int gl = tv & (Gl - 1), sr = (tv & 63) >> glog2, S = 64 >> glog2;
+            const char *Hl = reinterpret_cast<const char *>(H) + gl * 16; // this lane's first chunk of row 0
+            const int choff = Gl * 16;                                    // byte distance of its next chunk
+            const int4 *REC = reinterpret_cast<const int4 *>(RECb + (size_t)b * rec_b);
+            const char *sbase = smem + rows_b + (size_t)b * small_b;
+            const float *sdinv = reinterpret_cast<const float *>(sbase);
+            const int32_t *sgp = reinterpret_cast<const int32_t *>(sbase + ZF_CAP * 4);
+            const int32_t *scol = reinterpret_cast<const int32_t *>(SCOLb + (size_t)b * ECAP * 4);
+            const bool col_lds = cur.ne <= ECAP;
+            const int e0 = cur.e0;
+            auto reduce_graph = [&](int gi, int r0g, int r1g) { // wave-uniform row range of graph ga + gi
+                r0g = max(__builtin_amdgcn_readfirstlane(r0g) - nb, 0);
+                r1g = min(__builtin_amdgcn_readfirstlane(r1g) - nb, rows);
+                V sum[CH], mx[CH];
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    sum[c] = V::splat(0.0f);
+                    mx[c] = V::splat(-INFINITY);
+                }
+                const int n = max(r1g - r0g, 0);
+                const int niter = (n + S - 1) >> (6 - glog2);
+                int row = r0g + sr;
+                int rc_ = row < r1g ? row : r0g; // (clamped: inactive lanes re-read the first row)
+                int4 ra = make_int4(0, 0, 0, 0), rcf = ra, rd = ra;
+                if (n > 0) {
+                    ra = REC[3 * rc_];
+                    rcf = REC[3 * rc_ + 1];
+                    rd = REC[3 * rc_ + 2];
+                }
+#ifdef GNNB_PROBE
+                const unsigned long long pl0 = clock64();
+#endif
+#pragma unroll 1
+                for (int it = 0; it < niter; it++) {
+                    const bool active = row < r1g;
+                    const int4 ja = ra, ca = rcf, da = rd;
+                    const int rowc = rc_;
+                    row += S;
+                    rc_ = row < r1g ? row : r0g;
+                    if (it + 1 < niter) {
+                        ra = REC[3 * rc_];
+                        rcf = REC[3 * rc_ + 1];
+                        rd = REC[3 * rc_ + 2];
+                    }
+                    const char *p0_ = Hl + ja.x, *p1_ = Hl + ja.y, *p2_ = Hl + ja.z, *p3_ = Hl + ja.w, *ps_ = Hl + rowc * ldhb;
+                    V nv[CH][5];
+#pragma unroll
+                    for (int c = 0; c < CH; c++) { // unused slots alias the row itself (coefficient 0)
+                        nv[c][0] = V::load(reinterpret_cast<const float *>(p0_ + c * choff));
+                        nv[c][1] = V::load(reinterpret_cast<const float *>(p1_ + c * choff));
+                        nv[c][2] = V::load(reinterpret_cast<const float *>(p2_ + c * choff));
+                        nv[c][3] = V::load(reinterpret_cast<const float *>(p3_ + c * choff));
+                        nv[c][4] = V::load(reinterpret_cast<const float *>(ps_ + c * choff));
+                    }
+                    V acc[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; c++) {
+                        acc[c] = vmul(nv[c][0], V::splat(__int_as_float(ca.x)));
+                        acc[c] = vadd(acc[c], vmul(nv[c][1], V::splat(__int_as_float(ca.y))));
+                        acc[c] = vadd(acc[c], vmul(nv[c][2], V::splat(__int_as_float(ca.z))));
+                        acc[c] = vadd(acc[c], vmul(nv[c][3], V::splat(__int_as_float(ca.w))));
+                    }
+                    if (da.z > 4) { // degree > 4: the rest of the CSR row (slice of `col` in LDS; two loops, see P0)
+                        auto more = [&](int j) {
+                            const float cj = __int_as_float(da.w) * sdinv[j];
+#pragma unroll
+                            for (int c = 0; c < CH; c++)
+                                acc[c] = vadd(acc[c], vmul(V::load(reinterpret_cast<const float *>(Hl + j * ldhb + c * choff)), V::splat(cj)));
+                        };
+                        if (col_lds) {
+                            for (int k = da.y + 4; k < da.y + da.z; k++)
+                                more(scol[min(max(k - e0, 0), ECAP - 1)] - nb);
+                        } else {
+                            for (int k = da.y + 4; k < da.y + da.z; k++)
+                                more(col[k] - nb);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CH; c++) {
+                        acc[c] = vadd(acc[c], vmul(nv[c][4], V::splat(__int_as_float(da.x))));
+                        V o;
+                        o.v = make_float4(act_t<ACT>(acc[c].v.x + bias1[c].x), act_t<ACT>(acc[c].v.y + bias1[c].y),
+                                          act_t<ACT>(acc[c].v.z + bias1[c].z), act_t<ACT>(acc[c].v.w + bias1[c].w));
+                        if (active) {
+                            sum[c] = vadd(sum[c], o);
+                            mx[c] = vmax(mx[c], o);
+                        }
+                    }
+                }
+#ifdef GNNB_PROBE
+                pt[10] += clock64() - pl0; // (the row loop alone)
+#endif
+                // combine the lane groups (same chunks, different rows): xor butterflies over the row-group bits
+                for (int m = Gl; m < 64; m <<= 1) {
+#pragma unroll
+                    for (int c = 0; c < CH; c++) {
+                        sum[c].v.x += __shfl_xor(sum[c].v.x, m);
+                        sum[c].v.y += __shfl_xor(sum[c].v.y, m);
+                        sum[c].v.z += __shfl_xor(sum[c].v.z, m);
+                        sum[c].v.w += __shfl_xor(sum[c].v.w, m);
+                        mx[c].v.x = fmaxf(mx[c].v.x, __shfl_xor(mx[c].v.x, m));
+                        mx[c].v.y = fmaxf(mx[c].v.y, __shfl_xor(mx[c].v.y, m));
+                        mx[c].v.z = fmaxf(mx[c].v.z, __shfl_xor(mx[c].v.z, m));
+                        mx[c].v.w = fmaxf(mx[c].v.w, __shfl_xor(mx[c].v.w, m));
+                    }
+                }
+                if (sr == 0) {
+#pragma unroll
+                    for (int c = 0; c < CH; c++) {
+                        const int col0 = (gl + c * Gl) * 4;
+                        if (col0 < h1) {
+#pragma unroll
+                            for (int kk = 0; kk < 3; kk++) {
+                                if (kk >= np)
+                                    break;
+                                V rr = sum[c];
+                                if (pools[kk] == GNNB_POOL_MEAN)
+                                    rr = n > 0 ? vmul(sum[c], V::splat(1.0f / (float)n)) : V::splat(0.0f);
+                                else if (pools[kk] == GNNB_POOL_MAX)
+                                    rr = n > 0 ? mx[c] : V::splat(0.0f);
+                                rr.store(pooled + ((size_t)(cur.ga + gi) * np + kk) * h1 + col0);
+                            }
+                        }
+                    }
+                }
+            };
+            // two loops, not one with a choice inside: a select between the LDS table and global memory is
+            // if-converted into flat loads (+ a full vmcnt/lgkmcnt drain per graph)
+            const int nlds = min(ngr, GMAX);
+            for (int gi = wv; gi < nlds; gi += G2_NW)
+                reduce_graph(gi, sgp[gi], sgp[gi + 1]);
+            for (int gi = nlds + ((wv - nlds) & (G2_NW - 1)); gi < ngr; gi += G2_NW) // a pile of empty graphs
+                reduce_graph(gi, node_ptr[cur.ga + gi], node_ptr[cur.ga + gi + 1]);
+        }
+        ZF_PT(7);
+
+        // ---- P0 of the NEXT stage (its rows landed before the last barrier but one), starting on the first wave that
+        // had no graph to reduce
+        if (nxt.ta < t1)
+            phase_p0(nxt, b ^ 1, tv, ngr & (G2_NW - 1));
+        ZF_PT(8);
+        cur = nxt;
+        nxt = plan(cur.tb);
+        b ^= 1;
+        g2_barrier(); // A0 / REC of the next stage complete; everybody is done with Z
+        ZF_PT(9);
+#ifdef GNNB_PROBE
+        nst++;
+#endif
+    }
+#ifdef GNNB_PROBE
+    if (lane == 0 && blockIdx.x < 512 && wave < 8) {
+        unsigned long long *o = g_probe + 8 * 8192 + (blockIdx.x * 8 + wave) * 16; // second half: other kernels stamp the first
+        o[0] = pw0;
+        o[1] = wall_clock64();
+        for (int i = 0; i < 11; i++)
+            o[2 + i] = pt[i];
+        o[13] = clock64() - pt0;
+        o[14] = (unsigned long long)nst;
+    }
+#endif
+}
+
+int zf_stage_rows() { return options().zf_shape ? 160 : 96; }
+long gcn2_zf_tile_capacity()
+{
+    int devid = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    return (long)(ZF_TCAP - 2) * (options().zf_shape ? 1 : 2) * cus;
+}
+
+hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
+                          int h0, const float *w1, const float *b1, int h1, int act,
+                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s)
+{
+    const Options &o = options();
+    if (!o.fuse_gcn2 || !o.fuse_zf || o.math || t.num_nodes <= 0)
+        return hipErrorNotSupported;
+    const int cap = zf_stage_rows();
+    if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > cap)
+        return hipErrorNotSupported; // no promise that whole graphs fit a stage
+    if (f0 < 1 || f0 > 32 || !(h0 == 32 || h0 == 64 || h0 == 128) || h1 < 4 || h1 > 128 || (h1 & 3))
+        return hipErrorNotSupported;
+    if ((((uintptr_t)w1) & 15) || (((uintptr_t)pooled) & 15) || (((uintptr_t)x) & 3) || (b1 && (((uintptr_t)b1) & 15)))
+        return hipErrorNotSupported;
+    const int kq0 = f0 <= 16 ? 1 : 2, kq1 = h0 / 16;
+    const int gmax = cap <= 96 ? 64 : 128;
+    const int xs_b = ((cap * f0 * 4) + 15) & ~15;
+    const int rows_b = xs_b + cap * 32, small_b = cap * 4 + ((gmax + 1) * 4 + 15) / 16 * 16;
+    const int ldh = (h0 > h1 ? h0 : h1) + 4;
+    const int ecap = cap <= 96 ? 512 : 1024;
+    const size_t lds = (size_t)rows_b + 2 * (size_t)small_b + (size_t)cap * 16 * kq0 * 4 + (size_t)cap * ldh * 4 +
+                       2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 3 * (size_t)(ZF_TCAP + 1) * 4;
+    const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
+    hipError_t rc = hipErrorNotSupported;
+    auto go3 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag, auto chtag) {
+        constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
+        constexpr int NW = decltype(nwtag)::value, NU = decltype(utag)::value, CH = decltype(chtag)::value;
+        auto kern = k_gcn2_zf<ACT, KQ0, KQ1, NW, NU, CH>;
+        if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess) {
+            rc = hipErrorNotSupported;
+            return;
+        }
+        // occupancy of this instantiation at this LDS size, per device
+        static std::mutex mu;
+        static std::map<std::pair<int, size_t>, std::pair<int, int>> occ; // (device, lds) -> (blocks per CU, CUs)
+        int devid = 0;
+        (void)hipGetDevice(&devid);
+        int blocks = 0, cus = 256;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            auto it = occ.find(std::make_pair(devid, lds));
+            if (it == occ.end()) {
+                int nb = 0;
+                hipDeviceProp_t prop;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, lds) != hipSuccess || nb < 1)
+                    nb = 1;
+                if (hipGetDeviceProperties(&prop, devid) == hipSuccess)
+                    cus = prop.multiProcessorCount;
+                const int want = NW == 16 ? 1 : 2;
+                it = occ.emplace(std::make_pair(devid, lds), std::make_pair(nb > want ? want : nb, cus)).first;
+            }
+            blocks = it->second.first;
+            cus = it->second.second;
+        }
+        long long grid = (long long)cus * blocks;
+        if (grid > t.num_tiles)
+            grid = t.num_tiles;
+        const long long min_grid = ((long long)t.num_tiles + ZF_TCAP - 2) / (ZF_TCAP - 1);
+        if (grid < min_grid) {
+            rc = hipErrorNotSupported;
+            return;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, f0, t.node_rec, t.col, t.dinv,
+                           t.tile_first, t.tile_graph, t.tile_edge, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, t.num_edges, w0, b0, h0, w1, b1, h1,
+                           p0, p1, p2, num_pools, pooled);
+        rc = hipGetLastError();
+    };
+    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag) {
+        if (h1 > 64)
+            go3(atag, q0tag, q1tag, nwtag, utag, IntTag<2>{});
+#ifndef GNNB_DEV_FAST
+        else
+            go3(atag, q0tag, q1tag, nwtag, utag, IntTag<1>{});
+#endif
+    };
+    auto go = [&](auto atag, auto q0tag, auto q1tag) {
+        if (o.zf_shape)
+            go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<10>{});
+        else
+            go2(atag, q0tag, q1tag, IntTag<8>{}, IntTag<6>{});
+    };
+    auto go_q = [&](auto atag) {
+        if (kq0 == 1 && kq1 == 8) go(atag, IntTag<1>{}, IntTag<8>{});
+        else if (kq0 == 1 && kq1 == 4) go(atag, IntTag<1>{}, IntTag<4>{});
+        else if (kq0 == 1 && kq1 == 2) go(atag, IntTag<1>{}, IntTag<2>{});
+        else if (kq0 == 2 && kq1 == 8) go(atag, IntTag<2>{}, IntTag<8>{});
+        else if (kq0 == 2 && kq1 == 4) go(atag, IntTag<2>{}, IntTag<4>{});
+        else go(atag, IntTag<2>{}, IntTag<2>{});
+    };
+#ifdef GNNB_DEV_FAST // development builds: only the BASELINE config 2 instantiation
+    if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8)
+        go(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{});
+#else
+    GNNB_DISPATCH_ACT(act, go_q)
+#endif
+    return rc;
+}
+
+} // namespace gnnb

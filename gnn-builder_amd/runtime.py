@@ -67,10 +67,13 @@ class GemmSeg(C.Structure):
 
 
 # every symbol include/gnnb_hip.h declares (tests check the .so exports each one)
+PATH_NAMES = {0: "none", 1: "layerwise", 2: "stack", 3: "stack_zf"}  # gnnb_hip.h GNNB_PATH_*
+
 EXPORTED_SYMBOLS = [
     "gnnb_version", "gnnb_last_error", "gnnb_device_count", "gnnb_stream_sync",
     "gnnb_model_num_params", "gnnb_model_create", "gnnb_model_destroy", "gnnb_model_get_desc",
     "gnnb_workspace_create", "gnnb_workspace_destroy", "gnnb_workspace_bytes", "gnnb_workspace_set_max_graph_nodes",
+    "gnnb_workspace_last_path",
     "gnnb_forward_batched", "gnnb_forward_prepared", "gnnb_forward_batched_host", "gnnb_workspace_check",
     "gnnb_graph_prep", "gnnb_graph_tables_to_host", "gnnb_aggregate", "gnnb_linear", "gnnb_global_pool",
     "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
@@ -134,6 +137,7 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
         lib.gnnb_stream_sync.argtypes = [C.c_void_p]
         lib.gnnb_set_option.argtypes = [C.c_char_p, C.c_int]
         lib.gnnb_workspace_set_max_graph_nodes.argtypes = [C.c_void_p, C.c_int]
+        lib.gnnb_workspace_last_path.argtypes = [C.c_void_p]
         lib.gnnb_aggregate_timed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_int, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         lib.gnnb_linear_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
@@ -253,6 +257,11 @@ class CompiledModel:
 
     def set_max_graph_nodes(self, n: int) -> None:
         _check(self.lib.gnnb_workspace_set_max_graph_nodes(self._ws, int(n)))
+
+    def last_path(self) -> str:
+        """Which kernels the last forward on this workspace ran: "layerwise", "stack" (k_gcn2_fused) or "stack_zf"
+        (k_gcn2_zf); "none" before the first forward.  Diagnostics only."""
+        return PATH_NAMES.get(int(self.lib.gnnb_workspace_last_path(self._ws)), "?")
 
     @property
     def out_dim(self) -> int:

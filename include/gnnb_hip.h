@@ -124,13 +124,25 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
 void gnnb_workspace_destroy(gnnb_workspace *ws);
 size_t gnnb_workspace_bytes(const gnnb_workspace *ws);
 /* Promise that no graph of the batches run on this workspace has more than `n` nodes (0 = no
- * promise, the default).  Small molecules (n <= 61; 45 in the opt-in bf16x6 math mode) let whole graphs be staged in LDS, which enables
+ * promise, the default).  Small molecules (n <= 61; 45 in the opt-in bf16x6 math mode; 89 for a 2-layer fp32 GCN) let whole graphs be staged in LDS, which enables
  * the fused conv-stack kernels.  The promise is VALIDATED on the device by every graph prep: a
  * larger graph makes gnnb_workspace_check() return GNNB_ERR_GRAPH (the reference's MAX_NODES, by
  * contrast, is never checked: model.cpp.jinja:5-22).  Callers that never call the check still find out: the NEXT
  * gnnb_graph_prep / gnnb_forward_batched on the workspace after a flagged batch has run returns GNNB_ERR_GRAPH
  * (read from a host-mapped word, no synchronisation; best effort -- the check is the authoritative answer). */
 int gnnb_workspace_set_max_graph_nodes(gnnb_workspace *ws, int n);
+
+/* Which kernels the LAST forward on this workspace ran (diagnostics / benchmarks: the answer does not change any
+ * result).  The reference has one dataflow per generated model (compute_gnn_head, model.cpp.jinja:151-359); here the
+ * same model can take the LDS-resident stack kernels or the layer-by-layer kernels depending on the batch (the
+ * max_graph_nodes promise) and the options. */
+enum {
+    GNNB_PATH_NONE = 0,      /* no forward yet */
+    GNNB_PATH_LAYERWISE = 1, /* per layer: gather-aggregate + GEMM kernels */
+    GNNB_PATH_STACK = 2,     /* whole conv stack + pooling in k_gcn2_fused (GCN / GIN, graphs <= 61 nodes) */
+    GNNB_PATH_STACK_ZF = 3   /* 2-layer fp32 GCN in k_gcn2_zf (last layer transformed before aggregation, graphs <= 89 nodes) */
+};
+int gnnb_workspace_last_path(const gnnb_workspace *ws);
 
 /* ------------------------------------------------------------------ batched forward
  * x_dev        [num_nodes, in_dim] fp32 row-major, graphs concatenated

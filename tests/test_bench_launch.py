@@ -55,3 +55,18 @@ def test_parent_makes_no_gpu_call_before_spawning():
     launch = src[src.index("def self_launch("):src.index("def main():")]
     code = launch[launch.index('"""', launch.index('"""') + 3) + 3:]  # body without the docstring
     assert "os.exec" not in code and "torch" not in code and "load_library" not in code
+
+
+def test_a_rank_that_dies_at_startup_fails_the_launch_within_seconds():
+    """Rank 1 exits 3 before the rendezvous: rank 0 would wait in init_process_group for the collective
+    timeout (minutes).  The parent polls every child, terminates the survivors and exits 1."""
+    import time
+
+    t0 = time.monotonic()
+    p = _run(["--gpus", "2", "--dry-launch", "--workload", "tiny", "--steps", "2", "--warmup", "0", "--repeats", "1",
+              "--batches", "2"], {"BENCH_TEST_FAIL_RANK": "1"})
+    dt = time.monotonic() - t0
+    assert p.returncode == 1, (p.returncode, p.stderr)
+    assert dt < 30.0, dt
+    assert "ranks failed" in p.stderr and "(1, 3)" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.strip()]  # no JSON line from a failed launch

@@ -621,9 +621,11 @@ def test_fused_narrow_layer_equals_separate_kernels(dev, conv, fin):
                                                  (11, 32, 128, "gelu", ("mean",)), (20, 128, 64, "sigmoid", ("add", "mean", "max")),
                                                  (11, 64, 20, "relu", ("add",))])
 @pytest.mark.parametrize("pad_to_tile", [False, True])
-def test_fused_gcn_stack_equals_layerwise_and_oracle(dev, fin, h0, h1, act, pools, pad_to_tile):
-    """The persistent 2-layer GCN kernel (graphs staged once in LDS) vs the layer-by-layer path vs the
-    oracle, on molecule batches plus degenerate graphs (empty, isolated node, in-degree 8, self loop)."""
+@pytest.mark.parametrize("zf", [1, 0])
+def test_fused_gcn_stack_equals_layerwise_and_oracle(dev, fin, h0, h1, act, pools, pad_to_tile, zf):
+    """The persistent 2-layer GCN kernels (graphs staged once in LDS: k_gcn2_zf, the default, which transforms the last
+    layer before aggregating it, and k_gcn2_fused) vs the layer-by-layer path vs the oracle, on molecule batches plus
+    degenerate graphs (empty, isolated node, in-degree 8, self loop)."""
     model = make_model("gcn", in_dim=fin, hidden=h0, layers=2, out_dim=h1, act=act, pools=pools, task_out=5)
     rng = np.random.default_rng(h0 + h1)
     star = np.array([[i, 0] for i in range(1, 9)] + [[0, i] for i in range(1, 9)] + [[3, 3]])
@@ -639,10 +641,16 @@ def test_fused_gcn_stack_equals_layerwise_and_oracle(dev, fin, h0, h1, act, pool
     batch = pack_graphs([(np.asarray(x, np.float32), np.asarray(c, np.int32)) for x, c in graphs])
     ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
     cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)
-    fused = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    try:
+        runtime.set_option("fuse_zf", zf)
+        fused = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+        assert cm.last_path() == ("stack_zf" if zf else "stack")
+    finally:
+        runtime.set_option("fuse_zf", 1)
     cm.check()
     cm.set_max_graph_nodes(0)  # no promise -> layer-by-layer path
     layerwise = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    assert cm.last_path() == "layerwise"
     assert np.isfinite(fused).all()
     assert np.abs(fused - ref).max() < TOL and np.abs(layerwise - ref).max() < TOL
     assert np.abs(fused - layerwise).max() < 2e-5
@@ -905,11 +913,14 @@ def test_linear_dma_tail_split_is_bit_identical(dev, M, N, K):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("promise,math", [(34, 0), (50, 0), (55, 0), (57, 0), (58, 0), (61, 0), (62, 0), (41, 1), (45, 1), (46, 1)])
-def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math):
-    """Graphs of up to 57 nodes fit one 64-row stage with the default 8-row node tiles, up to 61 with 4-row tiles (graph
-    prep picks the tile size from the promise): ESOL-sized molecules (n_max 55) take the fused stack.  62 is past the
-    limit: the layer-by-layer path answers, same numbers.  The opt-in bf16x6 mode keeps 48-row stages (limit 45)."""
+@pytest.mark.parametrize("promise,math,zf", [(34, 0, 0), (50, 0, 0), (55, 0, 0), (57, 0, 0), (58, 0, 0), (61, 0, 0), (62, 0, 0),
+                                             (41, 1, 1), (45, 1, 1), (46, 1, 1),
+                                             (34, 0, 1), (62, 0, 1), (85, 0, 1), (89, 0, 1), (92, 0, 1), (93, 0, 1), (94, 0, 1)])
+def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math, zf):
+    """k_gcn2_fused: graphs of up to 57 nodes fit one 64-row stage with the default 8-row node tiles, up to 61 with 4-row
+    tiles (graph prep picks the tile size from the promise): ESOL-sized molecules (n_max 55) take the fused stack.  62 is
+    past the limit: the layer-by-layer path answers, same numbers.  The opt-in bf16x6 mode keeps 48-row stages (limit 45).
+    k_gcn2_zf (the default for two fp32 GCN layers) has 96-row stages: 89 nodes with 8-row tiles, 93 with 4-row tiles."""
     model = make_model("gcn", in_dim=9, hidden=128, layers=2, out_dim=128, act="relu", pools=("add", "mean", "max"), task_out=4)
     rng = np.random.default_rng(promise)
     graphs = []
@@ -923,19 +934,24 @@ def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math):
     ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
     try:
         runtime.set_option("math", math)
+        runtime.set_option("fuse_zf", zf)
         cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
         got = cm.forward(*to_dev(batch, dev)).cpu().numpy()
         cm.check()
         assert np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
-        # which path ran: the fused stack's timed entry refuses when it is not eligible
+        # which path ran: reported by the workspace; the stack's timed entry refuses when it is not eligible
         xd = torch.from_numpy(batch.x).to(dev)
-        if promise <= (45 if math else 61):
+        limit = 45 if math else (93 if zf else 61)
+        if promise <= limit:
+            assert cm.last_path() == ("stack_zf" if zf and not math else "stack")
             assert cm.gcn_stack_timed(xd, 2) > 0.0
         else:
+            assert cm.last_path() == "layerwise"
             with pytest.raises(runtime.GnnbError):
                 cm.gcn_stack_timed(xd, 2)
     finally:
         runtime.set_option("math", 0)
+        runtime.set_option("fuse_zf", 1)
 
 
 @pytest.mark.parametrize("conv,shape,promise", [("gcn", "qm9", True), ("gin", "molhiv", False), ("pna", "qm9", False)])

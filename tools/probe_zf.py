@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic: phase cycles of the transform-first 2-layer GCN stack kernel k_gcn2_zf (probe build, `make probe`)."""
+import ctypes as C, os, sys, json
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("GNNB_HIP_LIB", str(ROOT / "gnn-builder_amd" / "libgnnb_hip_probe.so"))
+import bench
+from gnnbuilder_amd import runtime, synthetic
+w = bench.WORKLOADS["c2"]; dev = torch.device("cuda:0")
+model = bench.build_model(w)
+b = synthetic.make_batch(w["shape"], w["batch"], seed=0)
+cm = runtime.CompiledModel.from_model(model, b.num_graphs, b.num_nodes, b.num_edges, max_graph_nodes=int(np.diff(b.node_ptr).max()))
+bd = tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr))
+for _ in range(10):
+    cm.forward(*bd)
+torch.cuda.synchronize()
+assert cm.last_path() == "stack_zf", cm.last_path()
+lib = runtime.load_library(); n = 16 * 8192
+buf = (C.c_ulonglong * n)(); lib.gnnb_probe_read(buf, n)
+pall = np.frombuffer(buf, dtype=np.uint64)[8 * 8192:8 * 8192 + 16 * 4096].reshape(512, 8, 16).astype(np.float64)
+p = pall[:, 0, :]
+p = p[p[:, 14] > 0]
+life = (p[:, 1] - p[:, 0]) / 100
+out = {"workgroups": len(p), "stages_per_wg_mean": p[:, 14].mean(), "stages_per_wg_max": p[:, 14].max(),
+       "span_us": (p[:, 1].max() - p[:, 0].min()) / 100, "lifetime_us_mean": life.mean(), "lifetime_us_max": life.max(),
+       "last_start_us": (p[:, 0].max() - p[:, 0].min()) / 100, "clock_mhz": float(np.median(p[:, 13] / life))}
+print(json.dumps(out))
+names = ["prologue (tables, weights, first DMA, P0 of stage 0)", "issue next DMA", "M0", "barrier (H complete)", "M1 (Z in accumulators)",
+         "DMA wait + barrier (H read)", "Z write + barrier", "P1 + pooling", "P0 of the next stage", "barrier (end of stage)", "(inside P1: the row loop alone)"]
+for i, nm in enumerate(names):
+    per = p[:, 2 + i] / (1 if i == 0 else p[:, 14])
+    print(f"  {nm:52s} {100 * (p[:, 2 + i] / p[:, 13]).mean():5.1f}%  {per.mean():8.0f} cycles" + ("" if i == 0 else "/stage"))
+print("per-wave cycles/stage (mean over workgroups):")
+pa = pall[pall[:, 0, 14] > 0]
+for wv in range(8):
+    print(f"  wave {wv}: " + " ".join(f"{(pa[:, wv, 2 + i] / (1 if i == 0 else pa[:, wv, 14])).mean():7.0f}" for i in range(11)))
