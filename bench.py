@@ -693,10 +693,11 @@ def main():
         upd = dict(kernel="k_linear_wlds (fp32 MFMA, weights in LDS), full-width layer update", bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS,
                    unit="TFLOP/s", traffic=None, **measure_update_mfma(w, batches[0].num_nodes, dev))
         if fused is not None:
+            stack_path = cm.last_path()  # which stack kernel the timed launches ran
             # the step runs the fused stack: that kernel dominates it and is bound by the fp32 matrix rate
             step_us = elapsed / args.steps * 1e3 * 1e3 / 1.0
             result["roofline"] = {
-                "kernel": "%s (%d %s layers + pooling in one persistent kernel, graphs staged in LDS)" % (cm.stack_kernel_name(), w["layers"], w["conv"].upper()),
+                "kernel": "%s (%d %s layers + pooling in one persistent kernel, graphs staged in LDS)" % ({"stack_zf": "k_gcn2_zf", "stack": "k_gcn2_fused"}.get(stack_path, stack_path), w["layers"], w["conv"].upper()),
                 "bound": "mfma", "achieved": fused["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                 "traffic": pmc_traffic("gcn2", args.workload, fused["alg_bytes"]),

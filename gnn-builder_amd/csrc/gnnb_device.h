@@ -33,6 +33,23 @@ static hipError_t ensure_dynamic_lds(const void *kern, size_t lds)
     return e;
 }
 
+// CUs of the CURRENT device (cached per device under a lock: a process may drive several GPUs)
+static int device_cu_count()
+{
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end())
+        return it->second;
+    hipDeviceProp_t prop;
+    const int n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    cus[dev] = n;
+    return n;
+}
+
 static constexpr int WG = 256; // 4 wavefronts
 
 // compile-time integer tag (generic lambdas dispatch on it)

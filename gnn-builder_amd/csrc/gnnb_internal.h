@@ -24,6 +24,8 @@ struct BatchTables {
     int32_t *tile_edge;  // [T+1] first CSR slot of the tile (= edge_ptr of its first graph, clamped)
     int32_t *tile_graph; // [T+1] index of the graph that starts at tile_first[t] (B past the end)
     int32_t max_graph_nodes_hint; // caller's promise (0 = unknown); validated on device by prep
+    int32_t promise_graphs;       // ... for graphs [0, promise_graphs) (the rest: the caller's "large segment")
+    int32_t tile_lo;              // first node tile the gather-aggregate kernels walk (0; the large segment's first tile)
     int32_t *err;        // [1]   != 0 when the batch was malformed
     int32_t *err_host_dev; // device-visible address of the host-mapped copy of "flagged" (nullptr: none)
     const int32_t *node_ptr; // [B+1] caller's graph_node_ptr (device): read by graph prep ONLY
@@ -36,8 +38,8 @@ struct BatchTables {
 
 constexpr int GNNB_G2_STAGE_ROWS = 64;     // rows per stage of the fused 2-layer GCN kernel (4 MFMA units)
 constexpr int GNNB_G2_STAGE_ROWS_BF6 = 48; // ... in the opt-in bf16x6 math mode (3 units)
-int zf_stage_rows();        // rows per stage of the transform-first 2-layer GCN kernel k_gcn2_zf (option zf_shape: 160 or 96)
-long gcn2_zf_tile_capacity(); // node tiles it can walk in one launch
+int zf_stage_rows(int f0);  // rows per stage of the transform-first 2-layer GCN kernel k_gcn2_zf for input width f0 (176 or 96)
+long gcn2_zf_tile_capacity(int f0); // node tiles it can walk in one launch
 
 struct Options {
     int tile_rows;    // node-tile granularity (rows; tiles are cut at graph boundaries)
@@ -54,7 +56,7 @@ struct Options {
     int fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
     int fuse_zf;       // 1 = a 2-layer fp32 GCN stack takes k_gcn2_zf (last layer transformed before it is aggregated, 96-row
                        //     stages) instead of k_gcn2_fused (default); needs fuse_gcn2
-    int zf_shape;      // k_gcn2_zf: 1 = one 16-wave workgroup per CU, 160-row stages (default); 0 = two 8-wave workgroups, 96-row stages
+    int zf_shape;      // k_gcn2_zf: 1 = one 16-wave workgroup per CU, 176-row stages (default); 0 = two 8-wave workgroups, 96-row stages
     int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it (k_gcn2_fused), 0 = layer by layer
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
     int head_small;    // 1 = readout on a pooled matrix with the small-footprint kernel that co-resides with the
@@ -132,7 +134,7 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
 // The same stack for exactly two GCN layers in fp32 math, last layer transformed before it is aggregated (k_stack_zf.hip)
 hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                           int h0, const float *w1, const float *b1, int h1, int act,
-                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s);
+                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1_frag_order = nullptr);
 
 // dst = src put on the ap_fixed<W, I> grid (truncate, wrap); dst may alias src
 hipError_t launch_quantize(const float *src, float *dst, size_t n, int W, int I, hipStream_t s);

@@ -147,6 +147,7 @@ struct gnnb_model {
     // per conv layer device pointers (canonical slots; SAGE slot 0 is the fused [Wl|Wr])
     std::vector<std::vector<const float *>> conv;
     std::vector<const float *> head_w, head_b;
+    const float *zf_w1f = nullptr; // 2-layer GCN: layer 1's weight once more, in MFMA-fragment order (see k_gcn2_zf)
     int device = 0;
 };
 
@@ -164,6 +165,9 @@ struct gnnb_workspace {
     bool prepared = false;
     int max_graph_nodes = 0; // caller's promise (0 = none)
     int last_path = GNNB_PATH_NONE; // which kernels the last forward on this workspace ran (gnnb_workspace_last_path)
+    // "large segment" of the NEXT batches (gnnb_workspace_set_large_segment): graphs [large_g, B) -- nodes from large_n,
+    // edges from large_e -- are exempt from the max_graph_nodes promise and run layer by layer; -1 = no such segment
+    int large_g = -1, large_n = -1, large_e = -1;
     int device = 0;
     int32_t *err_host = nullptr; // host-mapped word the prep kernel drops "flagged" into (lazy detection, see gnnb_graph_prep)
     char *stage = nullptr;   // device staging of the host-buffer entry (x | coo | node_ptr | edge_ptr | out), sized for
@@ -316,6 +320,33 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
         }
         pi += slots;
     }
+    // k_gcn2_zf reads its 16-column slice of the last GCN layer's weight as MFMA B fragments: lane (li, lg) of the wave that
+    // owns slice s takes W[16 s + li][16 q + 4 lg .. + 3] for q = 0 .. K/16 - 1.  Straight from the [out][in] matrix that is
+    // 16 rows x 64 B per load instruction (half of every 128-B line unused, 32 MB of L2 traffic per launch over the chip);
+    // a second copy in fragment order -- float4 index ((s K/16 + q) 4 + lg) 16 + li -- makes every load instruction one
+    // contiguous KiB.  Rows past `out` are zero.
+    size_t w1f_off = 0;
+    bool have_w1f = false;
+    if (d.conv_type == GNNB_CONV_GCN && d.num_layers == 2 && d.hidden_dim % 16 == 0 && d.hidden_dim <= 128 && d.out_dim <= 128) {
+        const int K = d.hidden_dim, KQ = K / 16, NS = (d.out_dim + 15) / 16;
+        std::vector<float> frag((size_t)NS * 16 * K, 0.0f);
+        const float *w1 = &img[conv_off[1][0]]; // (the image copy: already on the fixed-point grid when fpx is set)
+        for (int s = 0; s < NS; s++)
+            for (int q = 0; q < KQ; q++)
+                for (int lg = 0; lg < 4; lg++)
+                    for (int li = 0; li < 16; li++) {
+                        const int n = 16 * s + li;
+                        if (n >= d.out_dim)
+                            continue;
+                        for (int e = 0; e < 4; e++)
+                            frag[((((size_t)s * KQ + q) * 4 + lg) * 16 + li) * 4 + e] = w1[(size_t)n * K + 16 * q + 4 * lg + e];
+                    }
+        const bool fpx_save = fpx;
+        (void)fpx_save;
+        // (push() would quantise again: harmless -- the grid is idempotent)
+        w1f_off = push(frag.data(), frag.size());
+        have_w1f = true;
+    }
     for (int i = 0; i < d.mlp_num_linear; i++) {
         int din, dout;
         mlp_dims(d, i, &din, &dout);
@@ -341,6 +372,8 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
     for (int l = 0; l < d.num_layers; l++)
         for (size_t off : conv_off[l])
             m->conv[l].push_back(m->blob + off);
+    if (have_w1f)
+        m->zf_w1f = m->blob + w1f_off;
     for (int i = 0; i < d.mlp_num_linear; i++) {
         m->head_w.push_back(m->blob + hw[i]);
         m->head_b.push_back(m->blob + hb[i]);
@@ -473,6 +506,22 @@ size_t gnnb_workspace_bytes(const gnnb_workspace *ws) { return ws ? ws->bytes : 
 
 int gnnb_workspace_last_path(const gnnb_workspace *ws) { return ws ? ws->last_path : GNNB_PATH_NONE; }
 
+int gnnb_workspace_set_large_segment(gnnb_workspace *ws, int first_graph, int first_node, int first_edge)
+{
+    if (!ws)
+        return fail(GNNB_ERR_INVALID, "null workspace");
+    if (first_graph < 0) { // no large segment
+        ws->large_g = ws->large_n = ws->large_e = -1;
+        return GNNB_OK;
+    }
+    if (first_node < 0 || first_edge < 0)
+        return fail(GNNB_ERR_INVALID, "the large segment needs the node and edge offsets of its first graph");
+    ws->large_g = first_graph;
+    ws->large_n = first_node;
+    ws->large_e = first_edge;
+    return GNNB_OK;
+}
+
 int gnnb_workspace_set_max_graph_nodes(gnnb_workspace *ws, int n)
 {
     if (!ws || n < 0)
@@ -502,7 +551,12 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
         return fail(GNNB_ERR_GRAPH, "an earlier batch on this workspace was flagged as malformed (its results were "
                                     "unspecified); gnnb_workspace_check reports and clears the flags");
     }
+    if (ws->large_g >= 0 && (ws->large_g > num_graphs || ws->large_n > num_nodes || ws->large_e > num_edges))
+        return fail(GNNB_ERR_INVALID, "large segment (graph %d, node %d, edge %d) lies outside the batch (%d, %d, %d)",
+                    ws->large_g, ws->large_n, ws->large_e, num_graphs, num_nodes, num_edges);
     BatchTables &t = ws->t;
+    t.promise_graphs = ws->large_g >= 0 ? ws->large_g : num_graphs; // the promise covers graphs [0, promise_graphs)
+    t.tile_lo = 0;
     t.node_ptr = node_ptr_dev;
     t.num_graphs = num_graphs;
     t.num_nodes = num_nodes;
@@ -515,11 +569,11 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
         ws->max_graph_nodes > 0) {
         // (a 2-layer fp32 GCN stack runs k_gcn2_zf with its 96-row stages; everything else k_gcn2_fused)
         const bool zf = ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && options().fuse_zf && !options().math;
-        const int stage_rows = zf ? zf_stage_rows() : options().math ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
+        const int stage_rows = zf ? zf_stage_rows(ws->desc.in_dim) : options().math ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
         while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > stage_rows)
             t.tile_rows >>= 1;
         // very large batches: coarser tiles (while a tile still fits a stage) keep the per-workgroup tile table in LDS
-        const long tile_cap = zf ? gcn2_zf_tile_capacity() : gcn2_fused_tile_capacity();
+        const long tile_cap = zf ? gcn2_zf_tile_capacity(ws->desc.in_dim) : gcn2_fused_tile_capacity();
         while ((num_nodes + t.tile_rows - 1) / t.tile_rows > tile_cap && ws->max_graph_nodes + 2 * t.tile_rows - 1 <= stage_rows)
             t.tile_rows <<= 1;
     }
@@ -748,7 +802,7 @@ static hipError_t launch_conv_stack(const gnnb_model *model, gnnb_workspace *ws,
     hipError_t he = hipErrorNotSupported;
     if (!deep.gin && L == 2) // two GCN layers, fp32: the transform-first form with 96-row stages (k_stack_zf.hip)
         he = launch_gcn2_zf(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim, model->conv[1][0],
-                            model->conv[1][1], d.out_dim, d.activation, d.pools, d.num_pools, ws->pooled, s);
+                            model->conv[1][1], d.out_dim, d.activation, d.pools, d.num_pools, ws->pooled, s, model->zf_w1f);
     *path = GNNB_PATH_STACK_ZF;
     if (he == hipErrorNotSupported) {
         *path = GNNB_PATH_STACK;

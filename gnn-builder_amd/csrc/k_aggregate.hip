@@ -239,7 +239,7 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
     const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
     const int4 *__restrict__ node_rec, const int32_t *__restrict__ col, const float *__restrict__ dinv,
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_edge, int num_tiles, int N, int E, int w,
-    int glog2, int cap, int ecap, int nslots, int slot_bytes, int slack, float eps)
+    int glog2, int cap, int ecap, int nslots, int slot_bytes, int slack, float eps, int tile_lo)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HASQ = MODE == GNNB_AGG_PNA, HASREC = MODE != GNNB_AGG_COPY, HASDINV = MODE == GNNB_AGG_GCN;
@@ -249,7 +249,9 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
     const int nw = blockDim.x >> 6;
     // the workgroup's waves share the ring: wave sw of sn issues 1/sn of a stage's DMA and reduces 1/sn of its rows
     const int sw = wave, sn = nw;
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    // (tile_lo > 0: only the tiles of the caller's large segment, see gnnb_workspace_set_large_segment)
+    const int t0 = tile_lo + (int)(((long long)blockIdx.x * (num_tiles - tile_lo)) / gridDim.x),
+              t1 = tile_lo + (int)(((long long)(blockIdx.x + 1) * (num_tiles - tile_lo)) / gridDim.x);
     if (t0 >= t1)
         return; // (workgroup-uniform)
 #ifdef GNNB_PROBE
@@ -437,19 +439,14 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
                                           float *out, int w, float eps, hipStream_t s)
 {
     const Options &o = options();
-    if (t.num_tiles <= 0)
+    const int tile_lo = std::min(std::max(t.tile_lo, 0), t.num_tiles);
+    if (t.num_tiles - tile_lo <= 0)
         return hipSuccess;
     const int nvec = w / VEC;
     int glog2 = 0;
     while ((1 << glog2) < nvec && glog2 < 6)
         glog2++;
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int devid = 0;
-        hipDeviceProp_t prop;
-        num_cus = (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
-                      ? prop.multiProcessorCount : 256;
-    }
+    const int num_cus = device_cu_count();
     // per staged row: the row itself (PNA: p and q), its 32-B record, its normaliser, and 4 CSR entries (a stage
     // whose CSR slice is longer than 4 per row -- multigraphs, hubs -- is cut shorter by the planner)
     constexpr int ECAP_PER_ROW = 4;
@@ -468,7 +465,7 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
     const size_t lds = (size_t)ns * slot_bytes;
     // persistent: `wgs` workgroups per CU; fewer when the batch has fewer tiles than rings
     int grid = num_cus * wgs;
-    grid = std::min(grid, t.num_tiles);
+    grid = std::min(grid, t.num_tiles - tile_lo);
     if (grid < 1)
         grid = 1;
     auto launch = [&](auto kern) -> hipError_t {
@@ -479,7 +476,7 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, x, selfq, out, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_edge, t.num_tiles, t.num_nodes, t.num_edges, w, glog2, cap,
-                           cap * ECAP_PER_ROW, ns, slot_bytes, std::max(t.tile_rows / 2, 1) + 2, eps);
+                           cap * ECAP_PER_ROW, ns, slot_bytes, std::max(t.tile_rows / 2, 1) + 2, eps, tile_lo);
         return hipGetLastError();
     };
     if (o.agg_nt_store)

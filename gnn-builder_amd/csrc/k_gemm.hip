@@ -1256,13 +1256,7 @@ static hipError_t launch_linear_wlds(const GemmArgs &g, const float *w, int ldw,
                                      float *y, int M, int N, int act, hipStream_t s)
 {
     const int K = g.k[0];
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int devid = 0;
-        hipDeviceProp_t prop;
-        num_cus = (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
-                      ? prop.multiProcessorCount : 256;
-    }
+    const int num_cus = device_cu_count();
     const int slot = 16 * K * 4;
     // ring depth: what fits beside W in the CU's 160 KiB of LDS, at most 4.  A unit is requested ns - 1 units before
     // it is needed, piece by piece inside the MFMA stream.  Measured (tools/bench_gemm.py): ns = 2 beats ns = 3 at the
@@ -1336,13 +1330,7 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
                 if (e != hipSuccess)
                     return e;
             }
-            static int num_cus = 0;
-            if (num_cus == 0) {
-                int devid = 0;
-                hipDeviceProp_t prop;
-                num_cus = (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
-                              ? prop.multiProcessorCount : 256;
-            }
+            const int num_cus = device_cu_count();
             const int tm = (M + DM - 1) / DM, tn = (N + DN - 1) / DN, tiles = tm * tn;
             // two 64-KB workgroups are resident per CU and share its matrix pipe: what has to come out even is the
             // work per CU.  The last, partial round of tiles (all of them when there are fewer tiles than CUs) goes out

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     int32_t *__restrict__ col, int32_t *__restrict__ eid, int4 *__restrict__ node_rec, float *__restrict__ dinv,
     float *__restrict__ amp, float *__restrict__ att, float delta,
     int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int32_t *__restrict__ tile_graph,
-    int32_t *__restrict__ graph_ptr, int tile_rows, int num_tiles, int max_graph_nodes_hint, int drop_self,
+    int32_t *__restrict__ graph_ptr, int tile_rows, int num_tiles, int max_graph_nodes_hint, int promise_graphs, int drop_self,
     int32_t *__restrict__ err, int32_t *__restrict__ err_host)
 {
     __shared__ int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             e1 = e0; // no usable edge range: the rows get empty records
     }
     const int n = n1 - n0, ne = e1 - e0;
-    if (max_graph_nodes_hint > 0 && n > max_graph_nodes_hint && lane == 0)
+    if (max_graph_nodes_hint > 0 && n > max_graph_nodes_hint && g < promise_graphs && lane == 0)
         flag_batch(err, err_host, 8); // the caller's max_graph_nodes promise does not hold for this batch
     if (n > PREP_FAST_NODES || ne > PREP_FAST_EDGES) { // wave-uniform
         prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, eid, node_rec, dinv, amp, att, delta, drop_self, err, err_host);
@@ -409,12 +409,12 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
         hipLaunchKernelGGL(k_graph_prep<64>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err, t.err_host_dev);
+                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, drop_self_loops, t.err, t.err_host_dev);
     else
         hipLaunchKernelGGL(k_graph_prep<256>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, drop_self_loops, t.err, t.err_host_dev);
+                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, drop_self_loops, t.err, t.err_host_dev);
     return hipGetLastError();
 }
 

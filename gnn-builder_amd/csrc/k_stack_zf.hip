@@ -48,17 +48,23 @@ namespace gnnb {
 // HBM traffic = x + tables in, [B, np*h1] out (as k_gcn2_fused).  Bound: fp32 MFMA.
 // Needs: GCN, exactly two layers, fp32 math mode, F0 <= 32, h0 in {32,64,128}, h1 <= 128 (h1 % 4 == 0), and the caller's
 // promise max_graph_nodes <= 96 - (tile_rows - 1) (validated by graph prep).
-// Two shapes (runtime option zf_shape): 1 = ONE workgroup of 16 waves per CU, stages of up to 160 rows (10 MFMA units)
-// -- all waves of a CU move through the phases together, so the narrow VALU phases never compete with another
-// workgroup's MFMA stream (a VALU instruction that does costs a whole 32-cycle MFMA slot: they share the issue port and a
-// single wave cannot issue fast enough to keep the MFMA waves out); 0 = two workgroups of 8 waves, stages of up to 96 rows.
+// Two shapes (runtime option zf_shape): 1 = ONE workgroup of 16 waves per CU, stages of up to 176 rows (11 MFMA units)
+// -- a CU's share of the BASELINE config 2 batch (288 rows +- one graph) is always TWO stages (with a 160-row capacity
+// one workgroup in a few hundred found no graph boundary inside the window that lets two stages hold its rows and
+// ran a third: the kernel ends with its slowest workgroup), ~140 KB of LDS leaves room for the readout / graph-prep
+// kernels of the other batches in flight; 0 = two workgroups of 8 waves per CU, stages of up to 96 rows (158 KB: nothing
+// co-resides).  Solo launches are ~2 us faster in shape 0 (the two workgroups hide each other's latencies), the
+// three-stream pipeline of bench.py is faster in shape 1 (78.6 vs 75.2 M graphs/s).
 static constexpr int ZF_TCAP = 128;          // tile-table entries a workgroup keeps in LDS
 #ifndef ZF_PRIO
 #define ZF_PRIO 2
 #endif
 
 // accumulate NU 16-row units (rows row0[k] + li) x the wave's 16-column slice over K = 16 KQ:
-// acc[k] += A[rows of unit k][:] . Wslice^T.  Fragments of k block q+1 are requested before the MFMAs of block q.
+// acc[k] += Wslice . A[rows of unit k][:]^T -- the TRANSPOSED tile (weight fragment as the first MFMA operand), so that
+// lane (li, lg) ends up with FOUR CONSECUTIVE columns 16 s + 4 lg .. + 3 of row row0[k] + li: the tile goes back to LDS as
+// one conflict-free ds_write_b128 per lane and unit instead of four ds_write_b32 (64 B/clk/CU; the H and Z write-backs
+// were ~1 k cycles per stage each).  Fragments of k block q+1 are requested before the MFMAs of block q.
 template <int KQ, int NU>
 __device__ __forceinline__ void zf_mma(const float *__restrict__ A, int lda, const float (&wr)[KQ * 4], const int (&row0)[NU],
                                        int li, int lg, f32x4 (&acc)[NU])
@@ -83,7 +89,7 @@ __device__ __forceinline__ void zf_mma(const float *__restrict__ A, int lda, con
 #pragma unroll
             for (int k = 0; k < NU; k++) {
                 const float av = t == 0 ? a4[k].x : (t == 1 ? a4[k].y : (t == 2 ? a4[k].z : a4[k].w));
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[q * 4 + t], acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + t], av, acc[k], 0, 0, 0);
             }
         if (q + 1 < KQ) {
 #pragma unroll
@@ -97,14 +103,21 @@ struct ZfStage {
     int ta, tb, nb, rows, ga, gb, e0, ne;
 };
 
-template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS, int CH>
+template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS>
 __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_graph, const int32_t *__restrict__ tile_edge,
     const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, int N, int E, const float *__restrict__ W0,
-    const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ b1,
-    int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled)
+    const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ W1f,
+    const float *__restrict__ b1, int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled
+#ifdef GNNB_ZF_ABLATE
+    , int dbg // development only (-DGNNB_ZF_ABLATE): bit 0 skips P1, 1 skips P0', 2 skips M1, 3 skips M0, 4 skips the Z write
+#define ZF_ON(bit) (!(dbg & (1 << (bit))))
+#else
+#define ZF_ON(bit) true
+#endif
+)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ZF_CAP = 16 * ZF_UNITS, G2_NW = NW, G2_WG = NW * 64, G2_TCAP = ZF_TCAP;
@@ -136,7 +149,12 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     int32_t *stile = reinterpret_cast<int32_t *>(SCOLb + 2 * ECAP * 4);
     int32_t *sgraph = stile + (G2_TCAP + 1);
     int32_t *sedge = sgraph + (G2_TCAP + 1);
+    float *SB1 = reinterpret_cast<float *>(sedge + (G2_TCAP + 1) + 1); // b1 zero-padded to 128 floats (3 x 129 table entries + 1: 16-B aligned)
 
+#ifdef GNNB_ZF_ABLATE
+    if (dbg & 32)
+        return; // (launch overhead alone)
+#endif
     const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
     const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
     if (t1 <= t0)
@@ -150,16 +168,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     while ((16 << cs1l) < h1)
         cs1l++; // h <= 128 -> <= 3
     const int nrg0 = G2_NW >> cs0l, nrg1 = G2_NW >> cs1l;
-    // lanes per row in P1: the next power of two >= h1 / (4 CH) (CH float4 chunks per lane: gl, gl + Gl)
-    int glog2 = 2;
-    while ((4 * CH << glog2) < h1 && glog2 < 5)
-        glog2++;
-    const int Gl = 1 << glog2;
 
     // ---- weight slices -> registers (16 output columns x K per layer and wave), biases
-    float w0r[KQ0 * 4];
-    float bias0;
-    float4 bias1[CH];
+    float w0r[KQ0 * 4], w1r[KQ1 * 4];
+    float4 bias0;
     {
         const int li = lane & 15, lg = lane >> 4;
         const int n0c = (wave & ((1 << cs0l) - 1)) * 16 + li, n1c = (wave & ((1 << cs1l) - 1)) * 16 + li;
@@ -174,13 +186,22 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             w0r[q * 4 + 2] = v.z;
             w0r[q * 4 + 3] = v.w;
         }
-        bias0 = (n0c < h0 && b0) ? b0[n0c] : 0.0f;
-        const int gl = lane & (Gl - 1);
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            bias1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b1 && (gl + c * Gl) * 4 < h1)
-                bias1[c] = *reinterpret_cast<const float4 *>(b1 + (gl + c * Gl) * 4); // (h1 % 4 == 0, b1 16-B aligned: checked by the launcher)
+        for (int q = 0; q < KQ1; q++) {
+            const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (W1f) // fragment-order copy (gnnb_model_create): one contiguous KiB per load instruction of the wave
+                v = reinterpret_cast<const float4 *>(W1f)[(((wave & ((1 << cs1l) - 1)) * KQ1 + q) * 4 + lg) * 16 + li];
+            else if (n1c < h1)
+                v = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + k);
+            w1r[q * 4 + 0] = v.x;
+            w1r[q * 4 + 1] = v.y;
+            w1r[q * 4 + 2] = v.z;
+            w1r[q * 4 + 3] = v.w;
+        }
+        {   // bias of the four columns this lane holds after M0 (h0 is a multiple of 16; b0 may be unaligned)
+            const int c4 = (wave & ((1 << cs0l) - 1)) * 16 + 4 * lg;
+            bias0 = (c4 < h0 && b0) ? make_float4(b0[c4], b0[c4 + 1], b0[c4 + 2], b0[c4 + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
@@ -189,6 +210,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         sgraph[i] = min(max(tile_graph[t0 + i], 0), num_graphs);
         sedge[i] = min(max(tile_edge[t0 + i], 0), E);
     }
+    if (tid < 128)
+        SB1[tid] = (b1 && tid < h1) ? b1[tid] : 0.0f;
     __syncthreads();
 
     // ---- balanced stage plan: the rows that are left are cut into the fewest stages that can hold them, of EQUAL
@@ -277,10 +300,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #pragma unroll
     for (int q = 0; q < KQ0 * 4; q++)
         asm volatile("" : "+v"(w0r[q]));
-    asm volatile("" : "+v"(bias0));
-#pragma unroll
-    for (int c = 0; c < CH; c++)
-        asm volatile("" : "+v"(bias1[c].x), "+v"(bias1[c].y), "+v"(bias1[c].z), "+v"(bias1[c].w));
+    asm volatile("" : "+v"(bias0.x), "+v"(bias0.y), "+v"(bias0.z), "+v"(bias0.w));
     dma_wait_all();
     __syncthreads();
 
@@ -377,7 +397,16 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #define ZF_PT(i) do { } while (0)
 #endif
 
+#ifdef GNNB_ZF_ABLATE
+    if (dbg & 64)
+        return; // (launch + tables + weights + first DMA landed)
+#endif
     phase_p0(cur, 0, tid, 0);
+    // (the W1 slice, first needed by M1: its loads had the whole prologue to land; pinned HERE so that no wait for it
+    // is left inside the stage loop -- see the note on w0r above)
+#pragma unroll
+    for (int q = 0; q < KQ1 * 4; q++)
+        asm volatile("" : "+v"(w1r[q]));
     ZfStage nxt = plan(cur.tb);
     g2_barrier();
     ZF_PT(0);
@@ -401,27 +430,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         // ---- top: the next stage's inputs start their way to LDS (ROWS: P0 of `cur` was its last reader)
         issue_small(nxt, b ^ 1, tv & 63, wv);
         issue_rows(nxt, b ^ 1, tv & 63, wv);
-        // the wave's W1 slice (16 columns x K) -> registers, requested here and first used behind M0 and a barrier.  It
-        // is re-read (from L2: every CU reads the same 64 KB) in every stage so that its 32 registers are free during
-        // P1 / P0, which need them for two rows of eight values in flight per lane
-        float w1r[KQ1 * 4];
-        {
-            const int n1c_ = (wv & ((1 << cs1l) - 1)) * 16 + li;
-#pragma unroll
-            for (int q = 0; q < KQ1; q++) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n1c_ < h1)
-                    v = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c_ * h0 + 16 * q + 4 * lg); // h0 == 16 * KQ1
-                w1r[q * 4 + 0] = v.x;
-                w1r[q * 4 + 1] = v.y;
-                w1r[q * 4 + 2] = v.z;
-                w1r[q * 4 + 3] = v.w;
-            }
-        }
         ZF_PT(1);
 
         // ---- M0: H = act(A0 . W0^T + b0)   (wave: column slice x row group)
-        {
+        if (ZF_ON(3)) {
             const int n0c = (wv & ((1 << cs0l) - 1)) * 16 + li;
             const int rg0 = wv >> cs0l;
             auto m0 = [&](auto nutag, int ubase) {
@@ -434,12 +446,12 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 zf_mma<KQ0, NU>(A0, LD0, w0r, row0, li, lg, acc);
-                if (n0c < h0) {
+                if (n0c < h0) { // (h0 is 32, 64 or 128: the lane's four columns are all inside when its slice is)
 #pragma unroll
                     for (int k = 0; k < NU; k++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++)
-                            H[(row0[k] + lg * 4 + r) * ldh + n0c] = act_t<ACT>(acc[k][r] + bias0);
+                        *reinterpret_cast<float4 *>(H + (row0[k] + li) * ldh + (n0c - li) + 4 * lg) =
+                            make_float4(act_t<ACT>(acc[k][0] + bias0.x), act_t<ACT>(acc[k][1] + bias0.y),
+                                        act_t<ACT>(acc[k][2] + bias0.z), act_t<ACT>(acc[k][3] + bias0.w));
                 }
             };
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #pragma unroll
         for (int k = 0; k < ZMAX; k++)
             z[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        {
+        if (ZF_ON(2)) {
             auto m1 = [&](auto nutag, auto basetag) {
                 constexpr int NU = decltype(nutag)::value, UB = decltype(basetag)::value;
                 int row0[NU];
@@ -511,32 +523,39 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         ZF_PT(5);
 
         // ---- ZW: Z -> H in place
-        if (n1c < h1) {
+        if ((n1c - li) + 4 * lg < h1 && ZF_ON(4)) { // (h1 % 4 == 0: the lane's four columns are inside or outside together)
 #pragma unroll
             for (int k = 0; k < ZMAX; k++)
-                if (k < nu1) {
-                    const int row0 = (rg1 + k * nrg1) * 16 + lg * 4;
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        H[(row0 + r) * ldh + n1c] = z[k][r];
-                }
+                if (k < nu1)
+                    *reinterpret_cast<float4 *>(H + ((rg1 + k * nrg1) * 16 + li) * ldh + (n1c - li) + 4 * lg) =
+                        make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
         }
         g2_barrier(); // Z complete
         ZF_PT(6);
 
-        // ---- P1 + pooling: graph gi of the stage is reduced by wave gi mod NW.  A lane holds CH float4 chunks of the row
-        // (chunks gl, gl + Gl, ...: Gl lanes per row), the wave's 64 / Gl lane groups take the graph's rows round robin and
-        // IN ORDER: out_i = act(sum_j c_ij Z_j + c_ii Z_i + b1)  (CSR order, self last, as the reference's gcn_conv), summed
-        // / maxed per lane, then combined across the lane groups (fixed order) and stored: 16-B stores, one per lane,
-        // chunk, graph and pool (reference global_add/mean/max_pool, gnn_builder_lib.h:2709-2803).  With two chunks per
-        // lane (h1 > 64) the per-row overhead (record, offsets, loop) is paid once per 8 values and a graph of 18 rows
-        // is five passes of the wave instead of nine.
+        // ---- P1 + pooling.  A TASK is (graph of the stage, column part): the stage's graphs x CS column parts are dealt
+        // round robin to the waves, CS in {1, 2, 4} chosen so that every wave has a task when the stage has few graphs
+        // (BASELINE config 2: 8 graphs x 2 parts on 16 waves).  Inside a task a lane holds one float4 chunk of a row,
+        // Gl = h1 / (4 CS) lanes make a row, and the wave's S = 64 / Gl lane groups take the graph's rows round robin and
+        // IN ORDER: out_i = act(sum_j c_ij Z_j + c_ii Z_i + b1)  (CSR order, self last, as the reference's gcn_conv),
+        // summed / maxed per lane, combined across the lane groups with row-swap / DPP steps (fixed order) and stored
+        // with 16-B stores (reference global_add/mean/max_pool, gnn_builder_lib.h:2709-2803).  Splitting COLUMNS, not
+        // rows, between waves keeps every pooled value inside one wave: no partial results cross waves.
         const int ngr = cur.gb - cur.ga;
+        int csl = 0; // log2(CS)
         {
+            const int nv = h1 >> 2; // float4 chunks per row
+            const bool pow2 = (nv & (nv - 1)) == 0;
+            while (pow2 && csl < 2 && (ngr << (csl + 1)) <= G2_NW && (nv >> (csl + 1)) >= 4)
+                csl++;
+        }
+        if (ZF_ON(0)) {
             typedef Vf<4> V;
-            const int gl = tv & (Gl - 1), sr = (tv & 63) >> glog2, S = 64 >> glog2;
-            const char *Hl = reinterpret_cast<const char *>(H) + gl * 16; // this lane's first chunk of row 0
-            const int choff = Gl * 16;                                    // byte distance of its next chunk
+            int glog2 = 2; // lanes per row: the next power of two >= chunks per part
+            while ((4 << glog2) < (h1 >> csl) && glog2 < 5)
+                glog2++;
+            const int Gl = 1 << glog2, S = 64 >> glog2;
+            const int gl = tv & (Gl - 1), sr = (tv & 63) >> glog2;
             const int4 *REC = reinterpret_cast<const int4 *>(RECb + (size_t)b * rec_b);
             const char *sbase = smem + rows_b + (size_t)b * small_b;
             const float *sdinv = reinterpret_cast<const float *>(sbase);
@@ -544,64 +563,48 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             const int32_t *scol = reinterpret_cast<const int32_t *>(SCOLb + (size_t)b * ECAP * 4);
             const bool col_lds = cur.ne <= ECAP;
             const int e0 = cur.e0;
-            auto reduce_graph = [&](int gi, int r0g, int r1g) { // wave-uniform row range of graph ga + gi
+            const int wpart = (h1 >> csl); // columns per part
+            auto reduce_graph = [&](int gi, int cpart, int r0g, int r1g) { // wave-uniform row range of graph ga + gi
                 r0g = max(__builtin_amdgcn_readfirstlane(r0g) - nb, 0);
                 r1g = min(__builtin_amdgcn_readfirstlane(r1g) - nb, rows);
-                V sum[CH], mx[CH];
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    sum[c] = V::splat(0.0f);
-                    mx[c] = V::splat(-INFINITY);
-                }
+                const bool lane_on = gl * 4 < wpart;
+                const int col0 = lane_on ? cpart * wpart + gl * 4 : 0; // this lane's first column
+                const char *Hl = reinterpret_cast<const char *>(H) + col0 * 4; // its chunk of row 0
+                const float4 bias = *reinterpret_cast<const float4 *>(SB1 + col0);
+                V sum = V::splat(0.0f), mx = V::splat(-INFINITY);
                 const int n = max(r1g - r0g, 0);
-                const int niter = (n + S - 1) >> (6 - glog2);
-                int row = r0g + sr;
-                int rc_ = row < r1g ? row : r0g; // (clamped: inactive lanes re-read the first row)
-                int4 ra = make_int4(0, 0, 0, 0), rcf = ra, rd = ra;
-                if (n > 0) {
-                    ra = REC[3 * rc_];
-                    rcf = REC[3 * rc_ + 1];
-                    rd = REC[3 * rc_ + 2];
-                }
-#ifdef GNNB_PROBE
-                const unsigned long long pl0 = clock64();
-#endif
-#pragma unroll 1
-                for (int it = 0; it < niter; it++) {
-                    const bool active = row < r1g;
-                    const int4 ja = ra, ca = rcf, da = rd;
-                    const int rowc = rc_;
-                    row += S;
-                    rc_ = row < r1g ? row : r0g;
-                    if (it + 1 < niter) {
-                        ra = REC[3 * rc_];
-                        rcf = REC[3 * rc_ + 1];
-                        rd = REC[3 * rc_ + 2];
-                    }
-                    const char *p0_ = Hl + ja.x, *p1_ = Hl + ja.y, *p2_ = Hl + ja.z, *p3_ = Hl + ja.w, *ps_ = Hl + rowc * ldhb;
-                    V nv[CH][5];
-#pragma unroll
-                    for (int c = 0; c < CH; c++) { // unused slots alias the row itself (coefficient 0)
-                        nv[c][0] = V::load(reinterpret_cast<const float *>(p0_ + c * choff));
-                        nv[c][1] = V::load(reinterpret_cast<const float *>(p1_ + c * choff));
-                        nv[c][2] = V::load(reinterpret_cast<const float *>(p2_ + c * choff));
-                        nv[c][3] = V::load(reinterpret_cast<const float *>(p3_ + c * choff));
-                        nv[c][4] = V::load(reinterpret_cast<const float *>(ps_ + c * choff));
-                    }
-                    V acc[CH];
-#pragma unroll
-                    for (int c = 0; c < CH; c++) {
-                        acc[c] = vmul(nv[c][0], V::splat(__int_as_float(ca.x)));
-                        acc[c] = vadd(acc[c], vmul(nv[c][1], V::splat(__int_as_float(ca.y))));
-                        acc[c] = vadd(acc[c], vmul(nv[c][2], V::splat(__int_as_float(ca.z))));
-                        acc[c] = vadd(acc[c], vmul(nv[c][3], V::splat(__int_as_float(ca.w))));
-                    }
+                // Row loop, written for instruction count (in this phase every instruction of the wave is on the
+                // workgroup's critical path, and VALU issue is what the phase is bound by): running pointers instead of
+                // per-row address arithmetic, no software prefetch (its register rotation cost ten moves per row; the other
+                // waves of the SIMD cover the two LDS round trips), full passes without predication and one predicated
+                // tail pass, maxima through v_max_f32 directly (fmaxf adds a canonicalising v_max per operand).
+                const char *prec = reinterpret_cast<const char *>(REC) + (r0g + sr) * 48;
+                const char *pself = Hl + (r0g + sr) * ldhb;
+                const int dself = ldhb << (6 - glog2), drec = 48 << (6 - glog2);
+                auto vmax_raw = [](float a, float b2) {
+                    float r;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b2));
+                    return r;
+                };
+                auto one_row = [&](bool active) {
+                    const int4 ja = *reinterpret_cast<const int4 *>(prec);
+                    const int4 ca = *reinterpret_cast<const int4 *>(prec + 16);
+                    const int4 da = *reinterpret_cast<const int4 *>(prec + 32);
+                    const V n0 = V::load(reinterpret_cast<const float *>(Hl + ja.x)); // unused slots alias the row itself (coefficient 0)
+                    const V n1 = V::load(reinterpret_cast<const float *>(Hl + ja.y));
+                    const V n2 = V::load(reinterpret_cast<const float *>(Hl + ja.z));
+                    const V n3 = V::load(reinterpret_cast<const float *>(Hl + ja.w));
+                    const V self = V::load(reinterpret_cast<const float *>(pself));
+                    V acc;
+                    acc.v = bias;
+                    acc = vadd(acc, vmul(n0, V::splat(__int_as_float(ca.x))));
+                    acc = vadd(acc, vmul(n1, V::splat(__int_as_float(ca.y))));
+                    acc = vadd(acc, vmul(n2, V::splat(__int_as_float(ca.z))));
+                    acc = vadd(acc, vmul(n3, V::splat(__int_as_float(ca.w))));
                     if (da.z > 4) { // degree > 4: the rest of the CSR row (slice of `col` in LDS; two loops, see P0)
                         auto more = [&](int j) {
-                            const float cj = __int_as_float(da.w) * sdinv[j];
-#pragma unroll
-                            for (int c = 0; c < CH; c++)
-                                acc[c] = vadd(acc[c], vmul(V::load(reinterpret_cast<const float *>(Hl + j * ldhb + c * choff)), V::splat(cj)));
+                            acc = vadd(acc, vmul(V::load(reinterpret_cast<const float *>(Hl + j * ldhb)),
+                                                 V::splat(__int_as_float(da.w) * sdinv[j])));
                         };
                         if (col_lds) {
                             for (int k = da.y + 4; k < da.y + da.z; k++)
@@ -611,69 +614,95 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                                 more(col[k] - nb);
                         }
                     }
-#pragma unroll
-                    for (int c = 0; c < CH; c++) {
-                        acc[c] = vadd(acc[c], vmul(nv[c][4], V::splat(__int_as_float(da.x))));
-                        V o;
-                        o.v = make_float4(act_t<ACT>(acc[c].v.x + bias1[c].x), act_t<ACT>(acc[c].v.y + bias1[c].y),
-                                          act_t<ACT>(acc[c].v.z + bias1[c].z), act_t<ACT>(acc[c].v.w + bias1[c].w));
-                        if (active) {
-                            sum[c] = vadd(sum[c], o);
-                            mx[c] = vmax(mx[c], o);
-                        }
+                    acc = vadd(acc, vmul(self, V::splat(__int_as_float(da.x))));
+                    V o;
+                    o.v = make_float4(act_t<ACT>(acc.v.x), act_t<ACT>(acc.v.y), act_t<ACT>(acc.v.z), act_t<ACT>(acc.v.w));
+                    if (active) {
+                        sum = vadd(sum, o);
+                        mx.v = make_float4(vmax_raw(mx.v.x, o.v.x), vmax_raw(mx.v.y, o.v.y), vmax_raw(mx.v.z, o.v.z), vmax_raw(mx.v.w, o.v.w));
                     }
+                };
+#ifdef GNNB_PROBE
+                const unsigned long long pl0 = clock64();
+#endif
+                const int nfull = n >> (6 - glog2), ntail = n & (S - 1);
+#pragma unroll 1
+                for (int it = 0; it < nfull; it++) {
+                    one_row(true);
+                    prec += drec;
+                    pself += dself;
+                }
+                if (ntail) {
+                    const bool active = sr < ntail;
+                    if (!active) { // (inactive lane groups re-read the graph's first row)
+                        prec = reinterpret_cast<const char *>(REC) + r0g * 48;
+                        pself = Hl + r0g * ldhb;
+                    }
+                    one_row(active);
                 }
 #ifdef GNNB_PROBE
                 pt[10] += clock64() - pl0; // (the row loop alone)
 #endif
-                // combine the lane groups (same chunks, different rows): xor butterflies over the row-group bits
-                for (int m = Gl; m < 64; m <<= 1) {
+                // combine the lane groups (same chunk, different rows): lanes l and l ^ m for the row-group bits m
+                // (DPP row rotations inside a 16-lane row, then the gfx950 row swaps: no LDS round trip); one branch on
+                // the group size per STEP, the eight values (four sums, four maxima) inside it
+                {
+                    float v[8] = {sum.v.x, sum.v.y, sum.v.z, sum.v.w, mx.v.x, mx.v.y, mx.v.z, mx.v.w};
+                    auto comb = [&](int i, float o) { v[i] = i < 4 ? v[i] + o : vmax_raw(v[i], o); };
+                    if (Gl <= 4) {
 #pragma unroll
-                    for (int c = 0; c < CH; c++) {
-                        sum[c].v.x += __shfl_xor(sum[c].v.x, m);
-                        sum[c].v.y += __shfl_xor(sum[c].v.y, m);
-                        sum[c].v.z += __shfl_xor(sum[c].v.z, m);
-                        sum[c].v.w += __shfl_xor(sum[c].v.w, m);
-                        mx[c].v.x = fmaxf(mx[c].v.x, __shfl_xor(mx[c].v.x, m));
-                        mx[c].v.y = fmaxf(mx[c].v.y, __shfl_xor(mx[c].v.y, m));
-                        mx[c].v.z = fmaxf(mx[c].v.z, __shfl_xor(mx[c].v.z, m));
-                        mx[c].v.w = fmaxf(mx[c].v.w, __shfl_xor(mx[c].v.w, m));
+                        for (int i = 0; i < 8; i++)
+                            comb(i, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[i]), 0x124, 0xf, 0xf, false))); // row_ror:4
                     }
-                }
-                if (sr == 0) {
+                    if (Gl <= 8) {
 #pragma unroll
-                    for (int c = 0; c < CH; c++) {
-                        const int col0 = (gl + c * Gl) * 4;
-                        if (col0 < h1) {
+                        for (int i = 0; i < 8; i++)
+                            comb(i, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[i]), 0x128, 0xf, 0xf, false))); // row_ror:8
+                    }
+                    if (Gl <= 16) {
 #pragma unroll
-                            for (int kk = 0; kk < 3; kk++) {
-                                if (kk >= np)
-                                    break;
-                                V rr = sum[c];
-                                if (pools[kk] == GNNB_POOL_MEAN)
-                                    rr = n > 0 ? vmul(sum[c], V::splat(1.0f / (float)n)) : V::splat(0.0f);
-                                else if (pools[kk] == GNNB_POOL_MAX)
-                                    rr = n > 0 ? mx[c] : V::splat(0.0f);
-                                rr.store(pooled + ((size_t)(cur.ga + gi) * np + kk) * h1 + col0);
-                            }
+                        for (int i = 0; i < 8; i++) {
+                            auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+                            v[i] = i < 4 ? __uint_as_float(q[0]) + __uint_as_float(q[1]) : vmax_raw(__uint_as_float(q[0]), __uint_as_float(q[1]));
                         }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+                        v[i] = i < 4 ? __uint_as_float(q[0]) + __uint_as_float(q[1]) : vmax_raw(__uint_as_float(q[0]), __uint_as_float(q[1]));
+                    }
+                    sum.v = make_float4(v[0], v[1], v[2], v[3]);
+                    mx.v = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (sr == 0 && lane_on) {
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) {
+                        if (kk >= np)
+                            break;
+                        V rr = sum;
+                        if (pools[kk] == GNNB_POOL_MEAN)
+                            rr = n > 0 ? vmul(sum, V::splat(1.0f / (float)n)) : V::splat(0.0f);
+                        else if (pools[kk] == GNNB_POOL_MAX)
+                            rr = n > 0 ? mx : V::splat(0.0f);
+                        rr.store(pooled + ((size_t)(cur.ga + gi) * np + kk) * h1 + col0);
                     }
                 }
             };
             // two loops, not one with a choice inside: a select between the LDS table and global memory is
             // if-converted into flat loads (+ a full vmcnt/lgkmcnt drain per graph)
             const int nlds = min(ngr, GMAX);
-            for (int gi = wv; gi < nlds; gi += G2_NW)
-                reduce_graph(gi, sgp[gi], sgp[gi + 1]);
-            for (int gi = nlds + ((wv - nlds) & (G2_NW - 1)); gi < ngr; gi += G2_NW) // a pile of empty graphs
-                reduce_graph(gi, node_ptr[cur.ga + gi], node_ptr[cur.ga + gi + 1]);
+            const int ntask = nlds << csl;
+            for (int t = wv; t < ntask; t += G2_NW)
+                reduce_graph(t >> csl, t & ((1 << csl) - 1), sgp[t >> csl], sgp[(t >> csl) + 1]);
+            for (int gi = nlds + ((wv - nlds) & (G2_NW - 1)); gi < ngr; gi += G2_NW) // a pile of empty graphs (then csl = 0)
+                reduce_graph(gi, 0, node_ptr[cur.ga + gi], node_ptr[cur.ga + gi + 1]);
         }
         ZF_PT(7);
 
         // ---- P0 of the NEXT stage (its rows landed before the last barrier but one), starting on the first wave that
         // had no graph to reduce
-        if (nxt.ta < t1)
-            phase_p0(nxt, b ^ 1, tv, ngr & (G2_NW - 1));
+        if (nxt.ta < t1 && ZF_ON(1))
+            phase_p0(nxt, b ^ 1, tv, (ngr << csl) & (G2_NW - 1));
         ZF_PT(8);
         cur = nxt;
         nxt = plan(cur.tb);
@@ -685,40 +714,46 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #endif
     }
 #ifdef GNNB_PROBE
-    if (lane == 0 && blockIdx.x < 512 && wave < 8) {
-        unsigned long long *o = g_probe + 8 * 8192 + (blockIdx.x * 8 + wave) * 16; // second half: other kernels stamp the first
+    if (lane == 0 && blockIdx.x * NW < 4096) {
+        unsigned long long *o = g_probe + 8 * 8192 + (blockIdx.x * NW + wave) * 16; // second half: other kernels stamp the first
         o[0] = pw0;
         o[1] = wall_clock64();
         for (int i = 0; i < 11; i++)
             o[2 + i] = pt[i];
         o[13] = clock64() - pt0;
         o[14] = (unsigned long long)nst;
+        o[15] = (unsigned long long)(stile[t1 - t0] - stile[0]) | ((unsigned long long)(sgraph[t1 - t0] - sgraph[0]) << 32); // rows | graphs
     }
 #endif
 }
 
-int zf_stage_rows() { return options().zf_shape ? 160 : 96; }
-long gcn2_zf_tile_capacity()
+// (input widths above 16 take two MFMA k blocks per row of A0: with 176-row stages the carve would pass 160 KB, so those
+// models run the 96-row shape)
+static bool zf_wide_shape(int f0) { return options().zf_shape && f0 <= 16; }
+int zf_stage_rows(int f0) { return zf_wide_shape(f0) ? 176 : 96; }
+long gcn2_zf_tile_capacity(int f0)
 {
     int devid = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
         cus = prop.multiProcessorCount;
-    return (long)(ZF_TCAP - 2) * (options().zf_shape ? 1 : 2) * cus;
+    return (long)(ZF_TCAP - 2) * (zf_wide_shape(f0) ? 1 : 2) * cus;
 }
 
 hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                           int h0, const float *w1, const float *b1, int h1, int act,
-                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s)
+                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1f)
 {
     const Options &o = options();
     if (!o.fuse_gcn2 || !o.fuse_zf || o.math || t.num_nodes <= 0)
         return hipErrorNotSupported;
-    const int cap = zf_stage_rows();
+    const int cap = zf_stage_rows(f0);
     if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > cap)
         return hipErrorNotSupported; // no promise that whole graphs fit a stage
     if (f0 < 1 || f0 > 32 || !(h0 == 32 || h0 == 64 || h0 == 128) || h1 < 4 || h1 > 128 || (h1 & 3))
         return hipErrorNotSupported;
+    if (w1f && (((uintptr_t)w1f) & 15))
+        w1f = nullptr;
     if ((((uintptr_t)w1) & 15) || (((uintptr_t)pooled) & 15) || (((uintptr_t)x) & 3) || (b1 && (((uintptr_t)b1) & 15)))
         return hipErrorNotSupported;
     const int kq0 = f0 <= 16 ? 1 : 2, kq1 = h0 / 16;
@@ -728,13 +763,15 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
     const int ldh = (h0 > h1 ? h0 : h1) + 4;
     const int ecap = cap <= 96 ? 512 : 1024;
     const size_t lds = (size_t)rows_b + 2 * (size_t)small_b + (size_t)cap * 16 * kq0 * 4 + (size_t)cap * ldh * 4 +
-                       2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 3 * (size_t)(ZF_TCAP + 1) * 4;
+                       2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 3 * (size_t)(ZF_TCAP + 1) * 4 + 4 + 512;
+    if (lds > 160 * 1024)
+        return hipErrorNotSupported;
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
     hipError_t rc = hipErrorNotSupported;
-    auto go3 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag, auto chtag) {
+    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
-        constexpr int NW = decltype(nwtag)::value, NU = decltype(utag)::value, CH = decltype(chtag)::value;
-        auto kern = k_gcn2_zf<ACT, KQ0, KQ1, NW, NU, CH>;
+        constexpr int NW = decltype(nwtag)::value, NU = decltype(utag)::value;
+        auto kern = k_gcn2_zf<ACT, KQ0, KQ1, NW, NU>;
         if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess) {
             rc = hipErrorNotSupported;
             return;
@@ -770,23 +807,22 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
             return;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, f0, t.node_rec, t.col, t.dinv,
-                           t.tile_first, t.tile_graph, t.tile_edge, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, t.num_edges, w0, b0, h0, w1, b1, h1,
-                           p0, p1, p2, num_pools, pooled);
+                           t.tile_first, t.tile_graph, t.tile_edge, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, t.num_edges, w0, b0, h0, w1, w1f, b1, h1,
+                           p0, p1, p2, num_pools, pooled
+#ifdef GNNB_ZF_ABLATE
+                           , getenv("GNNB_ZF_DBG") ? atoi(getenv("GNNB_ZF_DBG")) : 0
+#endif
+        );
         rc = hipGetLastError();
     };
-    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag) {
-        if (h1 > 64)
-            go3(atag, q0tag, q1tag, nwtag, utag, IntTag<2>{});
-#ifndef GNNB_DEV_FAST
-        else
-            go3(atag, q0tag, q1tag, nwtag, utag, IntTag<1>{});
-#endif
-    };
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
-        if (o.zf_shape)
-            go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<10>{});
-        else
-            go2(atag, q0tag, q1tag, IntTag<8>{}, IntTag<6>{});
+        if constexpr (decltype(q0tag)::value == 1) { // (the wide shape exists for one-block input widths only)
+            if (zf_wide_shape(f0)) {
+                go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{});
+                return;
+            }
+        }
+        go2(atag, q0tag, q1tag, IntTag<8>{}, IntTag<6>{});
     };
     auto go_q = [&](auto atag) {
         if (kq0 == 1 && kq1 == 8) go(atag, IntTag<1>{}, IntTag<8>{});

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development check of the transform-first GCN stack kernel (k_gcn2_zf) on the BASELINE config 2 batch: parity
+"""Development check (uses the oracle: lives under tests/) of the transform-first GCN stack kernel (k_gcn2_zf) on the BASELINE config 2 batch: parity
 against the C oracle on sampled graphs and against k_gcn2_fused, launch-loop times of both (HIP events)."""
 import sys
 from pathlib import Path
@@ -19,12 +19,16 @@ for seed in (0, 5):
     cm = runtime.CompiledModel.from_model(model, b.num_graphs, b.num_nodes, b.num_edges, max_graph_nodes=mg)
     bd = tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr))
     outs = {}
+    keep = []
     for zf in (1, 0, 2):
         runtime.set_option("fuse_zf", 1 if zf else 0)
         runtime.set_option("zf_shape", 0 if zf == 2 else 1)
-        outs[zf] = cm.forward(*bd).cpu().numpy()
-        cm.check()
-        print(f"seed {seed} zf={zf}: path {cm.last_path()}, finite {np.isfinite(outs[zf]).all()}")
+        # (a workspace of its own per variant: the pooled matrix of another variant's run must not show through)
+        cmv = runtime.CompiledModel.from_model(model, b.num_graphs, b.num_nodes, b.num_edges, max_graph_nodes=mg)
+        outs[zf] = cmv.forward(*bd).cpu().numpy()
+        cmv.check()
+        print(f"seed {seed} zf={zf}: path {cmv.last_path()}, finite {np.isfinite(outs[zf]).all()}")
+        keep.append(cmv)
     runtime.set_option("fuse_zf", 1)
     runtime.set_option("zf_shape", 1)
     print(f"  max |zf - fused| = {np.abs(outs[1] - outs[0]).max():.3e}, |zf shape 0 - fused| = {np.abs(outs[2] - outs[0]).max():.3e} (scale {np.abs(outs[0]).max():.3f})")

@@ -621,7 +621,7 @@ def test_fused_narrow_layer_equals_separate_kernels(dev, conv, fin):
                                                  (11, 32, 128, "gelu", ("mean",)), (20, 128, 64, "sigmoid", ("add", "mean", "max")),
                                                  (11, 64, 20, "relu", ("add",))])
 @pytest.mark.parametrize("pad_to_tile", [False, True])
-@pytest.mark.parametrize("zf", [1, 0])
+@pytest.mark.parametrize("zf", [1, 2, 0])
 def test_fused_gcn_stack_equals_layerwise_and_oracle(dev, fin, h0, h1, act, pools, pad_to_tile, zf):
     """The persistent 2-layer GCN kernels (graphs staged once in LDS: k_gcn2_zf, the default, which transforms the last
     layer before aggregating it, and k_gcn2_fused) vs the layer-by-layer path vs the oracle, on molecule batches plus
@@ -642,11 +642,13 @@ def test_fused_gcn_stack_equals_layerwise_and_oracle(dev, fin, h0, h1, act, pool
     ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
     cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)
     try:
-        runtime.set_option("fuse_zf", zf)
+        runtime.set_option("fuse_zf", 1 if zf else 0)
+        runtime.set_option("zf_shape", 0 if zf == 2 else 1)  # (1: one 16-wave workgroup per CU; 2 here: two 8-wave ones)
         fused = cm.forward(*to_dev(batch, dev)).cpu().numpy()
         assert cm.last_path() == ("stack_zf" if zf else "stack")
     finally:
         runtime.set_option("fuse_zf", 1)
+        runtime.set_option("zf_shape", 1)
     cm.check()
     cm.set_max_graph_nodes(0)  # no promise -> layer-by-layer path
     layerwise = cm.forward(*to_dev(batch, dev)).cpu().numpy()
@@ -915,12 +917,14 @@ def test_linear_dma_tail_split_is_bit_identical(dev, M, N, K):
 
 @pytest.mark.parametrize("promise,math,zf", [(34, 0, 0), (50, 0, 0), (55, 0, 0), (57, 0, 0), (58, 0, 0), (61, 0, 0), (62, 0, 0),
                                              (41, 1, 1), (45, 1, 1), (46, 1, 1),
-                                             (34, 0, 1), (62, 0, 1), (85, 0, 1), (89, 0, 1), (92, 0, 1), (93, 0, 1), (94, 0, 1)])
+                                             (34, 0, 1), (62, 0, 1), (89, 0, 1), (120, 0, 1), (169, 0, 1), (172, 0, 1), (173, 0, 1), (174, 0, 1),
+                                             (89, 0, 2), (93, 0, 2), (94, 0, 2)])
 def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math, zf):
     """k_gcn2_fused: graphs of up to 57 nodes fit one 64-row stage with the default 8-row node tiles, up to 61 with 4-row
     tiles (graph prep picks the tile size from the promise): ESOL-sized molecules (n_max 55) take the fused stack.  62 is
     past the limit: the layer-by-layer path answers, same numbers.  The opt-in bf16x6 mode keeps 48-row stages (limit 45).
-    k_gcn2_zf (the default for two fp32 GCN layers) has 96-row stages: 89 nodes with 8-row tiles, 93 with 4-row tiles."""
+    k_gcn2_zf (the default for two fp32 GCN layers) has 176-row stages (one 16-wave workgroup per CU): 169 nodes with 8-row
+    tiles, 173 with 4-row tiles; zf = 2 selects its other shape (two 8-wave workgroups per CU, 96-row stages: 89 / 93)."""
     model = make_model("gcn", in_dim=9, hidden=128, layers=2, out_dim=128, act="relu", pools=("add", "mean", "max"), task_out=4)
     rng = np.random.default_rng(promise)
     graphs = []
@@ -934,14 +938,15 @@ def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math, zf):
     ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
     try:
         runtime.set_option("math", math)
-        runtime.set_option("fuse_zf", zf)
+        runtime.set_option("fuse_zf", 1 if zf else 0)
+        runtime.set_option("zf_shape", 0 if zf == 2 else 1)
         cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
         got = cm.forward(*to_dev(batch, dev)).cpu().numpy()
         cm.check()
         assert np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
         # which path ran: reported by the workspace; the stack's timed entry refuses when it is not eligible
         xd = torch.from_numpy(batch.x).to(dev)
-        limit = 45 if math else (93 if zf else 61)
+        limit = 45 if math else {0: 61, 1: 173, 2: 93}[zf]
         if promise <= limit:
             assert cm.last_path() == ("stack_zf" if zf and not math else "stack")
             assert cm.gcn_stack_timed(xd, 2) > 0.0
@@ -952,6 +957,7 @@ def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math, zf):
     finally:
         runtime.set_option("math", 0)
         runtime.set_option("fuse_zf", 1)
+        runtime.set_option("zf_shape", 1)
 
 
 @pytest.mark.parametrize("conv,shape,promise", [("gcn", "qm9", True), ("gin", "molhiv", False), ("pna", "qm9", False)])

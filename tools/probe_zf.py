@@ -19,7 +19,8 @@ torch.cuda.synchronize()
 assert cm.last_path() == "stack_zf", cm.last_path()
 lib = runtime.load_library(); n = 16 * 8192
 buf = (C.c_ulonglong * n)(); lib.gnnb_probe_read(buf, n)
-pall = np.frombuffer(buf, dtype=np.uint64)[8 * 8192:8 * 8192 + 16 * 4096].reshape(512, 8, 16).astype(np.float64)
+NW = 16 if int(os.environ.get("GNNB_ZF_SHAPE", "1")) else 8
+pall = np.frombuffer(buf, dtype=np.uint64)[8 * 8192:8 * 8192 + 16 * 4096].reshape(4096 // NW, NW, 16).astype(np.float64)
 p = pall[:, 0, :]
 p = p[p[:, 14] > 0]
 life = (p[:, 1] - p[:, 0]) / 100
@@ -32,7 +33,14 @@ names = ["prologue (tables, weights, first DMA, P0 of stage 0)", "issue next DMA
 for i, nm in enumerate(names):
     per = p[:, 2 + i] / (1 if i == 0 else p[:, 14])
     print(f"  {nm:52s} {100 * (p[:, 2 + i] / p[:, 13]).mean():5.1f}%  {per.mean():8.0f} cycles" + ("" if i == 0 else "/stage"))
+rows = (p[:, 15].astype(np.uint64) & np.uint64(0xffffffff)).astype(np.float64)
+graphs = (p[:, 15].astype(np.uint64) >> np.uint64(32)).astype(np.float64)
+end = (p[:, 1] - p[:, 0].min()) / 100
+start = (p[:, 0] - p[:, 0].min()) / 100
+print("lifetime us percentiles 5/25/50/75/95/100:", np.percentile(life, [5, 25, 50, 75, 95, 100]).round(2).tolist())
+print("start us percentiles 50/95/100:", np.percentile(start, [50, 95, 100]).round(2).tolist(), " end us 50/95/100:", np.percentile(end, [50, 95, 100]).round(2).tolist())
+print(f"rows per workgroup {rows.min():.0f}..{rows.max():.0f} (mean {rows.mean():.1f}); corr(lifetime, rows) {np.corrcoef(life, rows)[0, 1]:.2f}, corr(lifetime, graphs) {np.corrcoef(life, graphs)[0, 1]:.2f}, corr(lifetime, start) {np.corrcoef(life, start)[0, 1]:.2f}")
 print("per-wave cycles/stage (mean over workgroups):")
 pa = pall[pall[:, 0, 14] > 0]
-for wv in range(8):
+for wv in range(NW):
     print(f"  wave {wv}: " + " ".join(f"{(pa[:, wv, 2 + i] / (1 if i == 0 else pa[:, wv, 14])).mean():7.0f}" for i in range(11)))
