@@ -165,6 +165,31 @@ def from_pyg_batch(x, edge_index, batch=None, ptr=None, num_graphs=None) -> Grap
     return GraphBatch(x=x, coo=coo.reshape(-1, 2), node_ptr=node_ptr.astype(np.int32), edge_ptr=edge_ptr.astype(np.int32))
 
 
+def order_large_last(batch: GraphBatch, max_graph_nodes: int):
+    """Reorder a batch so that the graphs with more than ``max_graph_nodes`` nodes come last (stable inside both
+    groups): the layout ``gnnb_workspace_set_large_segment`` asks for.  Returns ``(ordered batch, perm, (first_graph,
+    first_node, first_edge))`` with ``ordered.graph(i) == batch.graph(perm[i])``; outputs of the ordered batch go back to the
+    caller's order with ``out[np.argsort(perm)]``.  ``first_graph == ordered.num_graphs`` when no graph is large."""
+    sizes = np.diff(batch.node_ptr)
+    large = sizes > int(max_graph_nodes)
+    perm = np.concatenate([np.flatnonzero(~large), np.flatnonzero(large)]).astype(np.int64)
+    first_graph = int((~large).sum())
+    if not large.any():
+        return batch, perm, (batch.num_graphs, batch.num_nodes, batch.num_edges)
+    nptr, eptr = batch.node_ptr.astype(np.int64), batch.edge_ptr.astype(np.int64)
+    nsz, esz = sizes[perm].astype(np.int64), np.diff(eptr)[perm]
+    new_nptr = np.concatenate([[0], np.cumsum(nsz)])
+    new_eptr = np.concatenate([[0], np.cumsum(esz)])
+    # rows / edges of graph perm[i] move to [new_nptr[i], new_nptr[i+1]) / [new_eptr[i], new_eptr[i+1])
+    node_src = np.concatenate([np.arange(nptr[g], nptr[g + 1]) for g in perm]) if batch.num_nodes else np.zeros(0, np.int64)
+    edge_src = np.concatenate([np.arange(eptr[g], eptr[g + 1]) for g in perm]) if batch.num_edges else np.zeros(0, np.int64)
+    shift = np.repeat(new_nptr[:-1] - nptr[perm], esz)          # per moved edge: new minus old node offset of its graph
+    coo = (batch.coo[edge_src].astype(np.int64) + shift[:, None]).astype(np.int32) if batch.num_edges else batch.coo.copy()
+    ordered = GraphBatch(x=np.ascontiguousarray(batch.x[node_src]), coo=np.ascontiguousarray(coo).reshape(-1, 2),
+                         node_ptr=new_nptr.astype(np.int32), edge_ptr=new_eptr.astype(np.int32))
+    return ordered, perm, (first_graph, int(new_nptr[first_graph]), int(new_eptr[first_graph]))
+
+
 def shard_bounds(node_ptr: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
     """Contiguous graph ranges per rank, cut on the cumulative NODE count so every GPU gets
     ~N_tot/world_size nodes; graphs are never split."""

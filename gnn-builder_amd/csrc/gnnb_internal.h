@@ -56,6 +56,10 @@ struct Options {
     int fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
     int fuse_zf;       // 1 = a 2-layer fp32 GCN stack takes k_gcn2_zf (last layer transformed before it is aggregated, 96-row
                        //     stages) instead of k_gcn2_fused (default); needs fuse_gcn2
+    int large_fork;    // a batch's large segment: 2 = through k_conv_rows on the caller's stream behind the stack kernel (default:
+                       //     measured best with batches in flight: C3t 15.0 M graphs/s), 1 = k_conv_rows on a forked stream (shortest
+                       //     single forward, 13.5 M in the pipeline: the stack kernels leave no register space for a co-resident
+                       //     wave, so the fork only reorders), 0 = through the big layer-by-layer kernels (14.2 M)
     int zf_shape;      // k_gcn2_zf: 1 = one 16-wave workgroup per CU, 176-row stages (default); 0 = two 8-wave workgroups, 96-row stages
     int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it (k_gcn2_fused), 0 = layer by layer
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
@@ -135,6 +139,12 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
 hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                           int h0, const float *w1, const float *b1, int h1, int act,
                           const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1_frag_order = nullptr);
+
+// One GCN / GIN conv layer for node rows [row_lo, N) in the small-footprint form that co-resides with the stack kernels
+// (k_conv_rows.hip: the large segment of a batch).  hipErrorNotSupported: widths beyond 128 or another conv type.
+hipError_t launch_conv_rows(const BatchTables &t, int conv_type, const float *x, int K, const float *w1, const float *b1,
+                            const float *w2, const float *b2, int Nout, const float *skip, float *y, int row_lo, int act,
+                            float eps, hipStream_t s);
 
 // dst = src put on the ap_fixed<W, I> grid (truncate, wrap); dst may alias src
 hipError_t launch_quantize(const float *src, float *dst, size_t n, int W, int I, hipStream_t s);

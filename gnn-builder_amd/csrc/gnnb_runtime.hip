@@ -57,7 +57,7 @@ Options &options()
                         env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_GEMM_DMA", 1),
                         env_int("GNNB_GEMM_WLDS", 1),             env_int("GNNB_GEMM_WLDS_SLOTS", 2),
-                        env_int("GNNB_FUSE_NARROW", 1),     env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_ZF_SHAPE", 1),
+                        env_int("GNNB_FUSE_NARROW", 1),     env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 1),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
                         env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 1)};
@@ -168,6 +168,9 @@ struct gnnb_workspace {
     // "large segment" of the NEXT batches (gnnb_workspace_set_large_segment): graphs [large_g, B) -- nodes from large_n,
     // edges from large_e -- are exempt from the max_graph_nodes promise and run layer by layer; -1 = no such segment
     int large_g = -1, large_n = -1, large_e = -1;
+    // fork / join for the large segment: its small kernels run on `side` beside the stack kernel on the caller's stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int device = 0;
     int32_t *err_host = nullptr; // host-mapped word the prep kernel drops "flagged" into (lazy detection, see gnnb_graph_prep)
     char *stage = nullptr;   // device staging of the host-buffer entry (x | coo | node_ptr | edge_ptr | out), sized for
@@ -220,6 +223,8 @@ int gnnb_set_option(const char *name, int value)
         o.fuse_zf = value;
     else if (!strcmp(name, "zf_shape") && value >= 0 && value <= 1)
         o.zf_shape = value;
+    else if (!strcmp(name, "large_fork") && value >= 0 && value <= 2)
+        o.large_fork = value;
     else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
         o.fuse_head = value;
     else if (!strcmp(name, "head_split") && value >= 0 && value <= 1)
@@ -499,6 +504,12 @@ void gnnb_workspace_destroy(gnnb_workspace *ws)
         (void)hipFree(ws->stage);
     if (ws->err_host)
         (void)hipHostFree(ws->err_host);
+    if (ws->ev_fork)
+        (void)hipEventDestroy(ws->ev_fork);
+    if (ws->ev_join)
+        (void)hipEventDestroy(ws->ev_join);
+    if (ws->side)
+        (void)hipStreamDestroy(ws->side);
     delete ws;
 }
 
@@ -792,21 +803,201 @@ static G2Deep gcn_stack_middle_layers(const gnnb_model *model)
     return g;
 }
 
+// The conv layers one by one (gather-aggregate + GEMM kernels) on the node rows [row_lo, N) of the prepared batch:
+// row_lo = 0 is the whole batch; row_lo > 0 the caller's large segment (gnnb_workspace_set_large_segment), whose first
+// node tile is tile_lo.  Aggregations index the batch-global buffers (sources are batch-global ids) and walk the tiles
+// from tile_lo; the GEMMs take the row range as a pointer offset.  *out_cur = the last layer's output matrix ([N, width],
+// rows below row_lo untouched).
+static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, int row_lo, int tile_lo,
+                           const float **out_cur, void *stream)
+{
+    const gnnb_model_desc &d = model->desc;
+    const int N = ws->t.num_nodes, M = N - row_lo;
+    int rc;
+    const bool fpx = d.fpx_w > 0;
+    auto quant = [&](float *buf, size_t n) -> int {
+        if (!fpx)
+            return GNNB_OK;
+        GNNB_HIP_TRY(launch_quantize(buf, buf, n, d.fpx_w, d.fpx_i, (hipStream_t)stream));
+        return GNNB_OK;
+    };
+    BatchTables tv = ws->t;
+    tv.tile_lo = tile_lo;
+    auto aggregate = [&](int kind, const float *x, const float *selfq, float *out, int w, float eps) -> int {
+        if (M <= 0)
+            return GNNB_OK;
+        GNNB_HIP_TRY(launch_aggregate(tv, kind, x, selfq, out, w, eps, (hipStream_t)stream));
+        return GNNB_OK;
+    };
+    auto R = [&](const float *p, int width) { return p ? p + (size_t)row_lo * width : p; }; // row range of a [N, width] matrix
+    auto Rw = [&](float *p, int width) { return p + (size_t)row_lo * width; };
+    const bool whole = row_lo == 0;
+    const float *cur = x_dev;
+    int which = 0;
+    for (int l = 0; l < d.num_layers; l++) {
+        const LayerDims ld = layer_dims(d, l);
+        const int fi = ld.fin, fo = ld.fout;
+        const std::vector<const float *> &p = model->conv[l];
+        // skip connection on middle layers only (models.py:562-564); fused into the GEMM epilogue
+        const float *skip = (d.skip && l != 0 && l != d.num_layers - 1) ? cur : nullptr;
+        float *nxt = ws->act[which];
+        if ((const float *)nxt == cur) { // never write the buffer being read
+            which ^= 1;
+            nxt = ws->act[which];
+        }
+        switch (d.conv_type) {
+        case GNNB_CONV_GCN:
+            // aggregate at the input width, then transform (the reference's order, lib:1346-1379)
+            if (whole && options().fuse_narrow && fi <= 32) {
+                hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_GCN, 0.f, cur, fi, fi, p[0], fi, p[1], skip, nxt,
+                                                   fo, d.activation, (hipStream_t)stream);
+                if (he == hipSuccess)
+                    break;
+                if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
+            }
+            if ((rc = aggregate(GNNB_AGG_GCN, cur, nullptr, ws->agg, fi, 0.f)))
+                return rc;
+            if ((rc = linear1(R(ws->agg, fi), fi, fi, p[0], fi, p[1], R(skip, fi), Rw(nxt, fo), M, fo, d.activation, stream)))
+                return rc;
+            break;
+        case GNNB_CONV_GIN: {
+            bool fused = false;
+            if (whole && options().fuse_narrow && fi <= 32) {
+                hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_SUM, d.gin_eps, cur, fi, fi, p[0], fi, p[1], nullptr,
+                                                   ws->tmp0, fo, GNNB_ACT_RELU, (hipStream_t)stream);
+                if (he == hipSuccess)
+                    fused = true;
+                else if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
+            }
+            if (!fused) {
+                if ((rc = aggregate(GNNB_AGG_SUM, cur, nullptr, ws->agg, fi, d.gin_eps)))
+                    return rc;
+                if ((rc = linear1(R(ws->agg, fi), fi, fi, p[0], fi, p[1], nullptr, Rw(ws->tmp0, fo), M, fo, GNNB_ACT_RELU, stream)))
+                    return rc;
+            }
+            if ((rc = linear1(R(ws->tmp0, fo), fo, fo, p[2], fo, p[3], R(skip, fo), Rw(nxt, fo), M, fo, d.activation, stream)))
+                return rc;
+            break;
+        }
+        case GNNB_CONV_SAGE: {
+            if (whole && options().fuse_narrow && 2 * fi <= 32) {
+                // narrow input: [mean_j x_j | x_i] is produced inside the GEMM's A stage (K = 2 F_in)
+                hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_MEAN, 0.f, cur, fi, 2 * fi, p[0], 2 * fi, p[1], skip, nxt,
+                                                   fo, d.activation, (hipStream_t)stream, fi);
+                if (he == hipSuccess)
+                    break;
+                if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
+            }
+            if ((rc = aggregate(GNNB_AGG_MEAN, cur, nullptr, ws->agg, fi, 0.f)))
+                return rc;
+            gnnb_gemm_seg segs[2] = {{R(ws->agg, fi), nullptr, fi, fi}, {R(cur, fi), nullptr, fi, fi}};
+            if ((rc = gnnb_linear(segs, 2, p[0], 2 * fi, p[1], R(skip, fi), Rw(nxt, fo), M, fo, d.activation, stream)))
+                return rc;
+            break;
+        }
+        case GNNB_CONV_PNA: {
+            // h_ij = Wpre [x_i || x_j] + b  ==  (Wpre[:, :F] x_i + b) + Wpre[:, F:] x_j
+            float *q = ws->tmp0, *pp = ws->tmp1;
+            if ((rc = linear1(R(cur, fi), fi, fi, p[0], 2 * fi, p[1], nullptr, Rw(q, fi), M, fi, GNNB_ACT_NONE, stream)))
+                return rc;
+            if ((rc = linear1(R(cur, fi), fi, fi, p[0] + fi, 2 * fi, nullptr, nullptr, Rw(pp, fi), M, fi, GNNB_ACT_NONE, stream)))
+                return rc;
+            if ((rc = aggregate(GNNB_AGG_PNA, pp, q, ws->agg, fi, 0.f)))
+                return rc;
+            // [x | A | amp.A | att.A] . Wpost^T without materialising the 13F concat
+            gnnb_gemm_seg segs[4] = {{R(cur, fi), nullptr, fi, fi},
+                                     {R(ws->agg, 4 * fi), nullptr, 4 * fi, 4 * fi},
+                                     {R(ws->agg, 4 * fi), ws->t.amp + row_lo, 4 * fi, 4 * fi},
+                                     {R(ws->agg, 4 * fi), ws->t.att + row_lo, 4 * fi, 4 * fi}};
+            float *hid = ws->tmp0; // q is dead after the aggregate
+            if ((rc = gnnb_linear(segs, 4, p[2], 13 * fi, p[3], nullptr, Rw(hid, fo), M, fo, GNNB_ACT_NONE, stream)))
+                return rc;
+            if ((rc = linear1(R(hid, fo), fo, fo, p[4], fo, p[5], R(skip, fo), Rw(nxt, fo), M, fo, d.activation, stream)))
+                return rc;
+            break;
+        }
+        }
+        if ((rc = quant(Rw(nxt, fo), (size_t)M * fo)))
+            return rc;
+        cur = nxt;
+        which ^= 1;
+    }
+
+    *out_cur = cur;
+    return GNNB_OK;
+}
+
 // The LDS-resident conv stack + pooling for this model on the prepared batch -> ws->pooled.  hipErrorNotSupported when
 // no stack kernel takes the model / batch (the caller runs layer by layer); *path says which kernel ran.
-static hipError_t launch_conv_stack(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, const G2Deep &deep,
-                                    hipStream_t s, int *path)
+// The large segment through the small-footprint per-layer kernel (k_conv_rows) + pooling, all on stream `s`; fills
+// ws->pooled rows [large_g, B).  hipErrorNotSupported (nothing launched) when a layer does not suit that kernel.
+static hipError_t large_segment_small(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, hipStream_t s)
+{
+    const gnnb_model_desc &d = model->desc;
+    if (d.conv_type != GNNB_CONV_GCN && d.conv_type != GNNB_CONV_GIN)
+        return hipErrorNotSupported;
+    for (int l = 0; l < d.num_layers; l++) {
+        const LayerDims ld = layer_dims(d, l);
+        if (ld.fin > 128 || ld.fout > 128)
+            return hipErrorNotSupported;
+    }
+    if ((d.in_dim & 3) == 0 && (((uintptr_t)x_dev) & 15))
+        return hipErrorNotSupported;
+    const float *cur = x_dev;
+    int which = 0;
+    for (int l = 0; l < d.num_layers; l++) {
+        const LayerDims ld = layer_dims(d, l);
+        const std::vector<const float *> &p = model->conv[l];
+        const float *skip = (d.skip && l != 0 && l != d.num_layers - 1) ? cur : nullptr;
+        float *nxt = ws->act[which];
+        if ((const float *)nxt == cur) {
+            which ^= 1;
+            nxt = ws->act[which];
+        }
+        const bool gin = d.conv_type == GNNB_CONV_GIN;
+        hipError_t he = launch_conv_rows(ws->t, d.conv_type, cur, ld.fin, p[0], p[1], gin ? p[2] : nullptr, gin ? p[3] : nullptr,
+                                         ld.fout, skip, nxt, ws->large_n, d.activation, d.gin_eps, s);
+        if (he != hipSuccess)
+            return he; // (NotSupported can only come from the first layer's checks above: nothing is half done)
+        cur = nxt;
+        which ^= 1;
+    }
+    const int gw = gnn_out_width(d), B = ws->t.num_graphs;
+    return launch_global_pool(cur, ws->t.graph_ptr + ws->large_g, B - ws->large_g, gw, d.pools, d.num_pools,
+                              ws->pooled + (size_t)ws->large_g * d.num_pools * gw, s);
+}
+
+// The batch tables restricted to the graphs the max_graph_nodes promise covers: everything, or -- with a large segment --
+// graphs [0, large_g) = nodes [0, large_n) = edges [0, large_e).  The stack kernels clamp every table entry to these
+// counts, so a tile that begins in the small segment ends at its last node.
+static BatchTables small_segment(const gnnb_workspace *ws)
+{
+    BatchTables t = ws->t;
+    if (ws->large_g >= 0 && ws->large_g < t.num_graphs) {
+        t.num_graphs = ws->large_g;
+        t.num_nodes = ws->large_n;
+        t.num_edges = ws->large_e;
+        t.num_tiles = (t.num_nodes + t.tile_rows - 1) / t.tile_rows;
+    }
+    return t;
+}
+
+static hipError_t launch_conv_stack(const gnnb_model *model, gnnb_workspace *ws, const BatchTables &t, const float *x_dev,
+                                    const G2Deep &deep, hipStream_t s, int *path)
 {
     const gnnb_model_desc &d = model->desc;
     const int L = d.num_layers;
     hipError_t he = hipErrorNotSupported;
     if (!deep.gin && L == 2) // two GCN layers, fp32: the transform-first form with 96-row stages (k_stack_zf.hip)
-        he = launch_gcn2_zf(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim, model->conv[1][0],
+        he = launch_gcn2_zf(t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim, model->conv[1][0],
                             model->conv[1][1], d.out_dim, d.activation, d.pools, d.num_pools, ws->pooled, s, model->zf_w1f);
     *path = GNNB_PATH_STACK_ZF;
     if (he == hipErrorNotSupported) {
         *path = GNNB_PATH_STACK;
-        he = launch_gcn2_fused(ws->t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
+        he = launch_gcn2_fused(t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim,
                                model->conv[L - 1][0], model->conv[L - 1][1], d.out_dim, d.activation, d.pools,
                                d.num_pools, ws->pooled, s, deep);
     }
@@ -855,9 +1046,56 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
 
     // ---- fused path: the whole GCN stack (two or more layers) + pooling in one persistent kernel, then the MLP head
     const G2Deep deep = gcn_stack_middle_layers(model);
-    if (!fpx && deep.nl >= 2 && d.mlp_num_linear <= 8) {
-        hipError_t he = launch_conv_stack(model, ws, x_dev, deep, (hipStream_t)stream, &ws->last_path);
+    // With a large segment (graphs the promise does not cover, ordered last by the caller) the stack runs on the graphs
+    // in front of it and the large ones go layer by layer into the same pooled matrix: one oversized molecule no longer
+    // sends the whole batch down the layer-by-layer path.  (large_g = 0: every graph is large -> layer by layer below.)
+    const bool seg = ws->large_g >= 0 && ws->large_g < B;
+    if (!fpx && deep.nl >= 2 && d.mlp_num_linear <= 8 && !(seg && ws->large_g == 0)) {
+        // The large segment first, FORKED: its kernels are built to run beside the stack kernel (k_conv_rows.hip), so they
+        // go on the workspace's side stream behind an event on the caller's stream and are joined in front of the readout.
+        // (Capturable: the side stream joins a capture through the event and is joined back.)
+        bool forked = false;
+        if (seg) {
+            if (!ws->side) {
+                if (hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ws->side = nullptr;
+                }
+            }
+            if (ws->side && options().large_fork == 1) {
+                GNNB_HIP_TRY(hipEventRecord(ws->ev_fork, (hipStream_t)stream));
+                GNNB_HIP_TRY(hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
+                hipError_t hl = large_segment_small(model, ws, x_dev, ws->side);
+                if (hl != hipSuccess && hl != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "large-segment launch failed: %s", hipGetErrorString(hl));
+                forked = hl == hipSuccess;
+                // (joined below whether or not anything ran on the side stream: the wait is on what was recorded)
+                GNNB_HIP_TRY(hipEventRecord(ws->ev_join, ws->side));
+            }
+        }
+        hipError_t he = launch_conv_stack(model, ws, small_segment(ws), x_dev, deep, (hipStream_t)stream, &ws->last_path);
+        if (seg && ws->side && options().large_fork == 1)
+            GNNB_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ws->ev_join, 0));
         if (he == hipSuccess) {
+            if (seg && !forked && options().large_fork == 2) { // the small kernels on the caller's stream, behind the stack
+                hipError_t hl = large_segment_small(model, ws, x_dev, (hipStream_t)stream);
+                if (hl != hipSuccess && hl != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "large-segment launch failed: %s", hipGetErrorString(hl));
+                forked = hl == hipSuccess;
+            }
+            if (seg && forked) {
+                ws->last_path |= GNNB_PATH_LARGE_LAYERWISE;
+            } else if (seg) {
+                const float *lcur = nullptr;
+                if ((rc = run_conv_layers(model, ws, x_dev, ws->large_n, ws->large_n / ws->t.tile_rows, &lcur, stream)))
+                    return rc;
+                const int gwl = gnn_out_width(d);
+                GNNB_HIP_TRY(launch_global_pool(lcur, ws->t.graph_ptr + ws->large_g, B - ws->large_g, gwl, d.pools, d.num_pools,
+                                                ws->pooled + (size_t)ws->large_g * d.num_pools * gwl, (hipStream_t)stream));
+                ws->last_path |= GNNB_PATH_LARGE_LAYERWISE;
+            }
             HeadArgs head;
             memset(&head, 0, sizeof(head));
             head.nlin = d.mlp_num_linear;
@@ -894,99 +1132,9 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
     }
 
     ws->last_path = GNNB_PATH_LAYERWISE;
-    const float *cur = x_dev;
-    int which = 0;
-    for (int l = 0; l < d.num_layers; l++) {
-        const LayerDims ld = layer_dims(d, l);
-        const int fi = ld.fin, fo = ld.fout;
-        const std::vector<const float *> &p = model->conv[l];
-        // skip connection on middle layers only (models.py:562-564); fused into the GEMM epilogue
-        const float *skip = (d.skip && l != 0 && l != d.num_layers - 1) ? cur : nullptr;
-        float *nxt = ws->act[which];
-        if ((const float *)nxt == cur) { // never write the buffer being read
-            which ^= 1;
-            nxt = ws->act[which];
-        }
-        switch (d.conv_type) {
-        case GNNB_CONV_GCN:
-            // aggregate at the input width, then transform (the reference's order, lib:1346-1379)
-            if (options().fuse_narrow && fi <= 32) {
-                hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_GCN, 0.f, cur, fi, fi, p[0], fi, p[1], skip, nxt,
-                                                   fo, d.activation, (hipStream_t)stream);
-                if (he == hipSuccess)
-                    break;
-                if (he != hipErrorNotSupported)
-                    return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
-            }
-            if ((rc = gnnb_aggregate(ws, GNNB_AGG_GCN, cur, nullptr, ws->agg, fi, 0.f, stream)))
-                return rc;
-            if ((rc = linear1(ws->agg, fi, fi, p[0], fi, p[1], skip, nxt, N, fo, d.activation, stream)))
-                return rc;
-            break;
-        case GNNB_CONV_GIN: {
-            bool fused = false;
-            if (options().fuse_narrow && fi <= 32) {
-                hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_SUM, d.gin_eps, cur, fi, fi, p[0], fi, p[1], nullptr,
-                                                   ws->tmp0, fo, GNNB_ACT_RELU, (hipStream_t)stream);
-                if (he == hipSuccess)
-                    fused = true;
-                else if (he != hipErrorNotSupported)
-                    return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
-            }
-            if (!fused) {
-                if ((rc = gnnb_aggregate(ws, GNNB_AGG_SUM, cur, nullptr, ws->agg, fi, d.gin_eps, stream)))
-                    return rc;
-                if ((rc = linear1(ws->agg, fi, fi, p[0], fi, p[1], nullptr, ws->tmp0, N, fo, GNNB_ACT_RELU, stream)))
-                    return rc;
-            }
-            if ((rc = linear1(ws->tmp0, fo, fo, p[2], fo, p[3], skip, nxt, N, fo, d.activation, stream)))
-                return rc;
-            break;
-        }
-        case GNNB_CONV_SAGE: {
-            if (options().fuse_narrow && 2 * fi <= 32) {
-                // narrow input: [mean_j x_j | x_i] is produced inside the GEMM's A stage (K = 2 F_in)
-                hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_MEAN, 0.f, cur, fi, 2 * fi, p[0], 2 * fi, p[1], skip, nxt,
-                                                   fo, d.activation, (hipStream_t)stream, fi);
-                if (he == hipSuccess)
-                    break;
-                if (he != hipErrorNotSupported)
-                    return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
-            }
-            if ((rc = gnnb_aggregate(ws, GNNB_AGG_MEAN, cur, nullptr, ws->agg, fi, 0.f, stream)))
-                return rc;
-            gnnb_gemm_seg segs[2] = {{ws->agg, nullptr, fi, fi}, {cur, nullptr, fi, fi}};
-            if ((rc = gnnb_linear(segs, 2, p[0], 2 * fi, p[1], skip, nxt, N, fo, d.activation, stream)))
-                return rc;
-            break;
-        }
-        case GNNB_CONV_PNA: {
-            // h_ij = Wpre [x_i || x_j] + b  ==  (Wpre[:, :F] x_i + b) + Wpre[:, F:] x_j
-            float *q = ws->tmp0, *pp = ws->tmp1;
-            if ((rc = linear1(cur, fi, fi, p[0], 2 * fi, p[1], nullptr, q, N, fi, GNNB_ACT_NONE, stream)))
-                return rc;
-            if ((rc = linear1(cur, fi, fi, p[0] + fi, 2 * fi, nullptr, nullptr, pp, N, fi, GNNB_ACT_NONE, stream)))
-                return rc;
-            if ((rc = gnnb_aggregate(ws, GNNB_AGG_PNA, pp, q, ws->agg, fi, 0.f, stream)))
-                return rc;
-            // [x | A | amp.A | att.A] . Wpost^T without materialising the 13F concat
-            gnnb_gemm_seg segs[4] = {{cur, nullptr, fi, fi},
-                                     {ws->agg, nullptr, 4 * fi, 4 * fi},
-                                     {ws->agg, ws->t.amp, 4 * fi, 4 * fi},
-                                     {ws->agg, ws->t.att, 4 * fi, 4 * fi}};
-            float *hid = ws->tmp0; // q is dead after the aggregate
-            if ((rc = gnnb_linear(segs, 4, p[2], 13 * fi, p[3], nullptr, hid, N, fo, GNNB_ACT_NONE, stream)))
-                return rc;
-            if ((rc = linear1(hid, fo, fo, p[4], fo, p[5], skip, nxt, N, fo, d.activation, stream)))
-                return rc;
-            break;
-        }
-        }
-        if ((rc = quant(nxt, (size_t)N * fo)))
-            return rc;
-        cur = nxt;
-        which ^= 1;
-    }
+    const float *cur = nullptr;
+    if ((rc = run_conv_layers(model, ws, x_dev, 0, 0, &cur, stream)))
+        return rc;
 
     const int gw = gnn_out_width(d);
     bool pooled_done = false;
@@ -1157,7 +1305,7 @@ int gnnb_gcn_stack_timed(const gnnb_model *model, gnnb_workspace *ws, const floa
     if (deep.nl < 2)
         return fail(GNNB_ERR_INVALID, "the fused stack exists for GCN / GIN models of two or more layers");
     hipStream_t s = (hipStream_t)stream;
-    auto launch = [&]() { return launch_conv_stack(model, ws, x_dev, deep, s, &ws->last_path); };
+    auto launch = [&]() { return launch_conv_stack(model, ws, small_segment(ws), x_dev, deep, s, &ws->last_path); };
     hipEvent_t e0, e1;
     GNNB_HIP_TRY(hipEventCreate(&e0));
     GNNB_HIP_TRY(hipEventCreate(&e1));

@@ -73,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "gnnb_version", "gnnb_last_error", "gnnb_device_count", "gnnb_stream_sync",
     "gnnb_model_num_params", "gnnb_model_create", "gnnb_model_destroy", "gnnb_model_get_desc",
     "gnnb_workspace_create", "gnnb_workspace_destroy", "gnnb_workspace_bytes", "gnnb_workspace_set_max_graph_nodes",
-    "gnnb_workspace_last_path",
+    "gnnb_workspace_last_path", "gnnb_workspace_set_large_segment",
     "gnnb_forward_batched", "gnnb_forward_prepared", "gnnb_forward_batched_host", "gnnb_workspace_check",
     "gnnb_graph_prep", "gnnb_graph_tables_to_host", "gnnb_aggregate", "gnnb_linear", "gnnb_global_pool",
     "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
@@ -138,6 +138,7 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
         lib.gnnb_set_option.argtypes = [C.c_char_p, C.c_int]
         lib.gnnb_workspace_set_max_graph_nodes.argtypes = [C.c_void_p, C.c_int]
         lib.gnnb_workspace_last_path.argtypes = [C.c_void_p]
+        lib.gnnb_workspace_set_large_segment.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         lib.gnnb_aggregate_timed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_int, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         lib.gnnb_linear_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
@@ -261,7 +262,14 @@ class CompiledModel:
     def last_path(self) -> str:
         """Which kernels the last forward on this workspace ran: "layerwise", "stack" (k_gcn2_fused) or "stack_zf"
         (k_gcn2_zf); "none" before the first forward.  Diagnostics only."""
-        return PATH_NAMES.get(int(self.lib.gnnb_workspace_last_path(self._ws)), "?")
+        v = int(self.lib.gnnb_workspace_last_path(self._ws))
+        return PATH_NAMES.get(v & 15, "?") + ("+large_layerwise" if v & 16 else "")
+
+    def set_large_segment(self, first_graph: int = -1, first_node: int = -1, first_edge: int = -1) -> None:
+        """Graphs [first_graph, B) of the following batches are exempt from the max_graph_nodes promise and run layer by
+        layer while the rest takes the LDS-resident stack (``gnnb_workspace_set_large_segment``); the caller orders the
+        batch so that they come last (``batching.order_large_last``).  No arguments: no large segment."""
+        _check(self.lib.gnnb_workspace_set_large_segment(self._ws, int(first_graph), int(first_node), int(first_edge)))
 
     @property
     def out_dim(self) -> int:

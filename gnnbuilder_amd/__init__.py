@@ -33,7 +33,7 @@ from .utils import (
     compute_median_nodes_and_edges,
 )
 from .code_gen import FPX, Project
-from .batching import GraphBatch, from_pyg_batch, pack_graphs, shard_batch, shard_bounds
+from .batching import GraphBatch, from_pyg_batch, order_large_last, pack_graphs, shard_batch, shard_bounds
 
 __all__ = [
     "Project", "FPX",
@@ -41,5 +41,5 @@ __all__ = [
     "PNAConv_GNNB", "SAGEConv_GNNB",
     "compute_average_degree", "compute_average_nodes_and_edges", "compute_max_nodes_and_edges",
     "compute_median_degree", "compute_median_nodes_and_edges",
-    "GraphBatch", "from_pyg_batch", "pack_graphs", "shard_batch", "shard_bounds",
+    "GraphBatch", "from_pyg_batch", "order_large_last", "pack_graphs", "shard_batch", "shard_bounds",
 ]

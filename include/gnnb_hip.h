@@ -124,7 +124,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
 void gnnb_workspace_destroy(gnnb_workspace *ws);
 size_t gnnb_workspace_bytes(const gnnb_workspace *ws);
 /* Promise that no graph of the batches run on this workspace has more than `n` nodes (0 = no
- * promise, the default).  Small molecules (n <= 61; 45 in the opt-in bf16x6 math mode; 89 for a 2-layer fp32 GCN) let whole graphs be staged in LDS, which enables
+ * promise, the default).  Small molecules (n <= 61; 45 in the opt-in bf16x6 math mode; 169 for a 2-layer fp32 GCN) let whole graphs be staged in LDS, which enables
  * the fused conv-stack kernels.  The promise is VALIDATED on the device by every graph prep: a
  * larger graph makes gnnb_workspace_check() return GNNB_ERR_GRAPH (the reference's MAX_NODES, by
  * contrast, is never checked: model.cpp.jinja:5-22).  Callers that never call the check still find out: the NEXT
@@ -140,9 +140,22 @@ enum {
     GNNB_PATH_NONE = 0,      /* no forward yet */
     GNNB_PATH_LAYERWISE = 1, /* per layer: gather-aggregate + GEMM kernels */
     GNNB_PATH_STACK = 2,     /* whole conv stack + pooling in k_gcn2_fused (GCN / GIN, graphs <= 61 nodes) */
-    GNNB_PATH_STACK_ZF = 3   /* 2-layer fp32 GCN in k_gcn2_zf (last layer transformed before aggregation, graphs <= 89 nodes) */
+    GNNB_PATH_STACK_ZF = 3,  /* 2-layer fp32 GCN in k_gcn2_zf (last layer transformed before aggregation, graphs <= 169 nodes) */
+    GNNB_PATH_LARGE_LAYERWISE = 16 /* flag, or-ed to a STACK value: the batch had a large segment that ran layer by layer */
 };
 int gnnb_workspace_last_path(const gnnb_workspace *ws);
+
+/* Large segment.  The stack kernels stage WHOLE graphs in LDS, hence the max_graph_nodes promise.  A batch that holds a few
+ * graphs beyond it (real ogbg-molhiv: 99 % of the molecules have <= 57 atoms, the largest 222) need not give the path up:
+ * the caller orders the batch so that those graphs come LAST and names the first of them -- graph index, its first node
+ * row and its first edge row (host integers: launch sizes depend on them).  Graphs [0, first_graph) keep the promise
+ * (still validated on the device) and run in the stack kernel; graphs [first_graph, num_graphs) are unrestricted and run
+ * through the layer-by-layer kernels; both halves fill one pooled matrix and share the readout.  The setting applies to
+ * every following gnnb_graph_prep / forward on the workspace until it is changed; first_graph < 0 removes it.  The
+ * reference has no counterpart: its MAX_NODES is a compile-time array bound of the generated model
+ * (templates/model.cpp.jinja:5-22), any graph up to it takes the same dataflow.
+ * (gnnbuilder_amd.batching.order_large_last does the ordering and returns the three numbers and the permutation.) */
+int gnnb_workspace_set_large_segment(gnnb_workspace *ws, int first_graph, int first_node, int first_edge);
 
 /* ------------------------------------------------------------------ batched forward
  * x_dev        [num_nodes, in_dim] fp32 row-major, graphs concatenated

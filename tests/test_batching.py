@@ -114,3 +114,25 @@ def test_from_pyg_batch_groups_edges_stably_and_matches_pack_graphs():
         from_pyg_batch(ref.x, bad.T, batch=batch_vec)
     with pytest.raises(ValueError):
         from_pyg_batch(ref.x, ref.coo.T, batch=batch_vec[::-1])
+
+
+def test_order_large_last_is_a_stable_partition():
+    """Graphs beyond the limit move to the end (order kept inside both groups), edges follow their graphs with renumbered
+    endpoints, and the returned triple names the first large graph / node / edge."""
+    from gnnbuilder_amd import synthetic
+    from gnnbuilder_amd.batching import order_large_last
+
+    b = synthetic.make_batch("molhiv_tail", 300, seed=4)
+    sizes = np.diff(b.node_ptr)
+    o, perm, (g0, n0, e0) = order_large_last(b, 40)
+    o.validate()
+    assert sorted(perm.tolist()) == list(range(b.num_graphs))
+    assert g0 == int((sizes <= 40).sum()) and n0 == int(o.node_ptr[g0]) and e0 == int(o.edge_ptr[g0])
+    assert np.all(np.diff(perm[:g0]) > 0) and np.all(np.diff(perm[g0:]) > 0)          # stable
+    assert np.all(np.diff(o.node_ptr)[:g0] <= 40) and np.all(np.diff(o.node_ptr)[g0:] > 40)
+    for i in range(o.num_graphs):
+        xa, ca = o.graph(i)
+        xb, cb = b.graph(int(perm[i]))
+        assert np.array_equal(xa, xb) and np.array_equal(ca, cb)
+    same, perm2, seg = order_large_last(b, 10 ** 6)                                   # nothing large: the batch itself
+    assert same is b and seg == (b.num_graphs, b.num_nodes, b.num_edges) and perm2.tolist() == list(range(b.num_graphs))

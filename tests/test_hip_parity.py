@@ -1161,6 +1161,108 @@ def test_full_size_config3_on_the_fused_gin_stack(dev):
     assert np.abs(lw.forward(*args).cpu().numpy() - out_d).max() < 5e-5 * max(1.0, float(np.abs(out_d).max()))
 
 
+def _forward_with_large_segment(model, batch, limit, dev, **kw):
+    """Order the batch (graphs beyond `limit` nodes last), run it with the large segment set, return the outputs in the
+    caller's graph order plus the compiled model."""
+    from gnnbuilder_amd.batching import order_large_last
+    ordered, perm, (g0, n0, e0) = order_large_last(batch, limit)
+    small_max = int(np.diff(ordered.node_ptr)[:g0].max()) if g0 else 1
+    cm = runtime.CompiledModel.from_model(model, ordered.num_graphs, ordered.num_nodes, max(ordered.num_edges, 1),
+                                          max_graph_nodes=small_max, **kw)
+    if g0 < ordered.num_graphs:
+        cm.set_large_segment(g0, n0, e0)
+    out = cm.forward(*to_dev(ordered, dev)).cpu().numpy()
+    cm.check()
+    return out[np.argsort(perm)], cm, g0
+
+
+@pytest.mark.parametrize("fork", [2, 1, 0])
+@pytest.mark.parametrize("conv,layers,limit", [("gin", 3, 57), ("gcn", 2, 40), ("gcn", 3, 57), ("gin", 2, 30)])
+def test_large_segment_keeps_the_stack_for_the_rest_of_the_batch(dev, conv, layers, limit, fork):
+    """Graphs beyond the stage capacity no longer demote the whole batch (reference: any graph up to MAX_NODES takes the
+    same dataflow, model.cpp.jinja:5-22): ordered last and named as the large segment they run layer by layer, the rest
+    stays in the LDS-resident stack, one pooled matrix, one readout.  Heavy-tailed molhiv-shaped batch + a 300-node graph
+    + empty graphs on both sides of the boundary; against the oracle, and the path the workspace reports."""
+    model = make_model(conv, in_dim=9, hidden=128, layers=layers, out_dim=128, act="relu", pools=("add", "max", "mean"), task_out=3, seed=5)
+    b0 = synthetic.make_batch("molhiv_tail", 500, seed=11)
+    rng = np.random.default_rng(limit)
+    n_big = 300
+    big_e = np.stack([rng.integers(0, n_big, 900), rng.integers(0, n_big, 900)], 1).astype(np.int32)
+    empty = (np.zeros((0, 9), np.float32), np.zeros((0, 2), np.int32))
+    graphs = [b0.graph(g) for g in range(250)] + [empty, (rng.uniform(-1, 1, (n_big, 9)).astype(np.float32), big_e), empty] + \
+             [b0.graph(g) for g in range(250, 500)]
+    batch = pack_graphs(graphs)
+    assert int(np.diff(batch.node_ptr).max()) == n_big and (np.diff(batch.node_ptr) > limit).sum() >= 5
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    try:  # 2: the segment's small kernels (k_conv_rows) behind the stack kernel (default); 1: on a forked stream; 0: the big kernels
+        runtime.set_option("large_fork", fork)
+        out, cm, g0 = _forward_with_large_segment(model, batch, limit, dev)
+    finally:
+        runtime.set_option("large_fork", 2)
+    assert g0 < batch.num_graphs
+    assert cm.last_path() in ("stack+large_layerwise", "stack_zf+large_layerwise"), cm.last_path()
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(out - ref).max() < TOL * scale
+    # the same workspace without the segment and with an honest promise: the whole batch goes layer by layer, same numbers
+    cm.set_large_segment()
+    cm.set_max_graph_nodes(n_big)
+    from gnnbuilder_amd.batching import order_large_last
+    ordered, perm, _ = order_large_last(batch, limit)
+    lw = cm.forward(*to_dev(ordered, dev)).cpu().numpy()[np.argsort(perm)]
+    assert cm.last_path() == "layerwise"
+    assert np.abs(lw - out).max() < 5e-5 * scale
+
+
+def test_large_segment_edge_cases(dev):
+    """All graphs large (segment starts at graph 0: plain layer-by-layer run), no graph large (segment empty: plain stack
+    run), a segment outside the batch is refused, and a graph in FRONT of the segment that breaks the promise is still
+    flagged by graph prep."""
+    model = make_model("gin", in_dim=9, hidden=64, layers=2, out_dim=64, act="relu", pools=("add",), task_out=2)
+    batch = synthetic.make_batch("molhiv_tail", 200, seed=3)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    scale = max(1.0, float(np.abs(ref).max()))
+    out, cm, g0 = _forward_with_large_segment(model, batch, 2, dev)       # every graph has >= 3 nodes: all large
+    assert g0 == 0 and cm.last_path() == "layerwise" and np.abs(out - ref).max() < TOL * scale
+    out, cm, g0 = _forward_with_large_segment(model, batch, 250, dev)     # none large
+    assert g0 == batch.num_graphs and cm.last_path() == "layerwise" or cm.last_path().startswith("stack")
+    assert np.abs(out - ref).max() < TOL * scale
+    with pytest.raises(runtime.GnnbError):
+        cm.set_large_segment(batch.num_graphs + 5, batch.num_nodes, batch.num_edges)
+        cm.forward(*to_dev(batch, dev))
+    cm.set_large_segment()
+    # promise broken in front of the segment
+    sizes = np.diff(batch.node_ptr)
+    cm2 = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=int(sizes[:100].max()) - 1)
+    cm2.set_large_segment(100, int(batch.node_ptr[100]), int(batch.edge_ptr[100]))
+    cm2.forward(*to_dev(batch, dev))
+    with pytest.raises(runtime.GnnbError):
+        cm2.check()
+
+
+def test_full_size_config3_with_the_heavy_tail(dev):
+    """BASELINE config 3 at full size on a batch with the real data set's heavy tail (synthetic 'molhiv_tail': log-normal
+    sizes up to 222 nodes; about 1 graph in 100 beyond the 57-node stage limit): fused GIN stack for the bulk, layer by
+    layer for the large segment.  256 sampled graphs incl. both ends, the largest graph and EVERY large graph's neighbours
+    in the order, against the oracle; reversed order permutes the rows."""
+    model = make_model("gin", in_dim=9, hidden=128, layers=3, pools=("add",), task_out=1, seed=7)
+    B = 4096
+    batch = synthetic.make_batch("molhiv_tail", B, seed=31)
+    sizes = np.diff(batch.node_ptr)
+    assert sizes.max() > 61 and (sizes > 57).sum() >= 20
+    out_d, cm, g0 = _forward_with_large_segment(model, batch, 57, dev)
+    assert cm.last_path() == "stack+large_layerwise"
+    large = np.flatnonzero(sizes > 57)
+    idx = np.unique(np.concatenate([np.random.default_rng(3).choice(B, 200, replace=False), [0, B - 1, int(np.argmax(sizes))],
+                                    large[:40], np.clip(large[:8] + 1, 0, B - 1)]))
+    sub = pack_graphs([batch.graph(int(g)) for g in idx])
+    ref = O.forward_batched(model.spec(), canon(model), sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(out_d[idx] - ref).max() < TOL * scale
+    rev = pack_graphs([batch.graph(int(g)) for g in range(B - 1, -1, -1)])
+    out_rev, _, _ = _forward_with_large_segment(model, rev, 57, dev)
+    assert np.abs(out_rev[::-1] - out_d).max() < 2e-5 * max(1.0, float(np.abs(out_d).max()))
+
+
 # --------------------------------------------------------------------------- malformed batches stay inside the buffers
 @pytest.mark.parametrize("conv", ["gcn", "gin", "sage", "pna"])
 def test_malformed_batches_are_contained(dev, conv):
