@@ -112,6 +112,10 @@ class Project:
                 raise NotImplementedError("the fixed-point emulation implements AP_TRN / AP_WRAP (the reference's defaults)")
             if fpx.W > 32 or fpx.W - fpx.I > 24:
                 raise NotImplementedError("the fixed-point emulation takes W <= 32 and W - I <= 24")
+            if fpx.W < 2 or fpx.I < 1 or fpx.I > fpx.W:
+                # (ap_fixed<W, I> with I > W or I < 1 is legal HLS -- pure scaling -- but not a format this backend
+                # emulates: refused here rather than later, in gnnb_model_create)
+                raise ValueError(f"the fixed-point emulation takes 2 <= W and 1 <= I <= W, got FPX({fpx.W}, {fpx.I})")
         self.clock_speed = clock_speed
         if self.clock_speed <= 0:
             raise ValueError("clock_speed must be > 0")

@@ -559,6 +559,9 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     // host-mapped word without synchronising: it reports what has already run, never the batch being enqueued now.
     if (ws->err_host && *(volatile int32_t *)ws->err_host != 0) {
         *(volatile int32_t *)ws->err_host = 0;
+        // reported now: the device word is cleared as well (in stream order), or a later gnnb_workspace_check would blame
+        // a good batch for it
+        (void)hipMemsetAsync(ws->t.err, 0, sizeof(int32_t), (hipStream_t)stream);
         return fail(GNNB_ERR_GRAPH, "an earlier batch on this workspace was flagged as malformed (its results were "
                                     "unspecified); gnnb_workspace_check reports and clears the flags");
     }
@@ -622,6 +625,29 @@ int gnnb_workspace_check(gnnb_workspace *ws, void *stream)
     return GNNB_OK;
 }
 
+// CSR slots no row owns (edges dropped by graph prep -- explicit self loops on a GCN workspace -- leave a gap at the end of
+// their graph's segment, whose slots hold stale data) read -1 in the host copies
+static int mark_unused_slots(gnnb_workspace *ws, int32_t *slots, hipStream_t s)
+{
+    const int N = ws->t.num_nodes, E = ws->t.num_edges;
+    if (!slots || E <= 0)
+        return GNNB_OK;
+    std::vector<int32_t> rec((size_t)std::max(N, 1) * 8);
+    if (N > 0)
+        GNNB_HIP_TRY(hipMemcpyAsync(rec.data(), ws->t.node_rec, (size_t)N * 32, hipMemcpyDeviceToHost, s));
+    GNNB_HIP_TRY(hipStreamSynchronize(s));
+    std::vector<char> used((size_t)E, 0);
+    for (int v = 0; v < N; v++) {
+        const long start = rec[(size_t)v * 8], deg = rec[(size_t)v * 8 + 1];
+        for (long k = std::max(start, 0L); k < std::min(start + deg, (long)E); k++)
+            used[(size_t)k] = 1;
+    }
+    for (int k = 0; k < E; k++)
+        if (!used[(size_t)k])
+            slots[k] = -1;
+    return GNNB_OK;
+}
+
 int gnnb_graph_tables_to_host(gnnb_workspace *ws, int32_t *row_ptr, int32_t *col, int32_t *in_deg,
                               void *stream)
 {
@@ -640,7 +666,7 @@ int gnnb_graph_tables_to_host(gnnb_workspace *ws, int32_t *row_ptr, int32_t *col
     if (in_deg)
         for (int i = 0; i < N; i++)
             in_deg[i] = rec[(size_t)i * 8 + 1];
-    return GNNB_OK;
+    return mark_unused_slots(ws, col, s);
 }
 
 int gnnb_edge_index_table_to_host(gnnb_workspace *ws, int32_t *edge_index_table, void *stream)
@@ -651,7 +677,7 @@ int gnnb_edge_index_table_to_host(gnnb_workspace *ws, int32_t *edge_index_table,
         GNNB_HIP_TRY(hipMemcpyAsync(edge_index_table, ws->t.eid, (size_t)ws->t.num_edges * 4, hipMemcpyDeviceToHost,
                                     (hipStream_t)stream));
     GNNB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return GNNB_OK;
+    return mark_unused_slots(ws, edge_index_table, (hipStream_t)stream);
 }
 
 int gnnb_aggregate_edges(gnnb_workspace *ws, const float *x_dev, const float *edge_term_dev, float *out_dev,

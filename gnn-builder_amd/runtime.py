@@ -221,6 +221,7 @@ class CompiledModel:
     def __init__(self, spec: dict, params: Sequence, max_graphs: int, max_nodes: int, max_edges: int,
                  max_graph_nodes: int = 0):
         self.lib = load_library(require_gpu=True)
+        self._N = self._E = self._B = 0  # sizes of the prepared batch (graph_prep / forward)
         self.spec = dict(spec)
         self.desc = make_desc(spec)
         host = [np.ascontiguousarray(np.asarray(p.detach().cpu().numpy() if hasattr(p, "detach") else p,
@@ -309,8 +310,12 @@ class CompiledModel:
             out = torch.empty((B, self.out_dim), dtype=torch.float32, device=x.device)
         else:
             _require(out, "out", torch.float32, 2, self.out_dim)
+            if out.shape[0] != B or out.device != x.device:
+                raise GnnbError(f"out must be [{B}, {self.out_dim}] on {x.device}, got {tuple(out.shape)} on {out.device}")
         _check(self.lib.gnnb_forward_batched(self._model, self._ws, _dptr(x), _dptr(coo), _dptr(node_ptr),
                                              _dptr(edge_ptr), B, N, E, _dptr(out), _stream_ptr(stream)))
+        self._keep = (coo, node_ptr, edge_ptr)
+        self._N, self._E, self._B = N, E, B  # (the batch is prepared now: the stage-level entry points may follow)
         return out
 
     def _check_batch(self, x, coo, node_ptr, edge_ptr) -> None:
@@ -335,8 +340,14 @@ class CompiledModel:
     def forward_prepared(self, x, out=None, stream=None):
         import torch
         _require(x, "x", torch.float32, 2, int(self.desc.in_dim))
+        if int(x.shape[0]) != self._N:
+            raise GnnbError(f"x has {int(x.shape[0])} rows, the prepared batch has {self._N} nodes")
         if out is None:
             out = torch.empty((self._B, self.out_dim), dtype=torch.float32, device=x.device)
+        else:
+            _require(out, "out", torch.float32, 2, self.out_dim)
+            if out.shape[0] != self._B or out.device != x.device:
+                raise GnnbError(f"out must be [{self._B}, {self.out_dim}] on {x.device}, got {tuple(out.shape)} on {out.device}")
         _check(self.lib.gnnb_forward_prepared(self._model, self._ws, _dptr(x), _dptr(out), _stream_ptr(stream)))
         return out
 
@@ -371,8 +382,15 @@ class CompiledModel:
         import torch
         _require(x, "x", torch.float32, 2)
         w = int(x.shape[1])
+        ow = 4 * w if kind == "pna" else w
+        if self_term is not None:
+            _require(self_term, "self_term", torch.float32, 2, w)
         if out is None:
-            out = torch.empty((x.shape[0], 4 * w if kind == "pna" else w), dtype=torch.float32, device=x.device)
+            out = torch.empty((x.shape[0], ow), dtype=torch.float32, device=x.device)
+        else:
+            _require(out, "out", torch.float32, 2, ow)
+            if out.shape[0] != x.shape[0] or out.device != x.device:
+                raise GnnbError(f"out must be [{int(x.shape[0])}, {ow}] on {x.device}")
         _check(self.lib.gnnb_aggregate(self._ws, AGG[kind], _dptr(x),
                                        _dptr(self_term) if self_term is not None else None, _dptr(out), w,
                                        float(eps), _stream_ptr(stream)))
@@ -387,8 +405,22 @@ class CompiledModel:
     def aggregate_edges(self, x, edge_term, eps: float = 0.0, out=None, stream=None):
         """GINE aggregate: ``(1 + eps) x_i + sum_j relu(x_j + edge_term[e])``; ``edge_term`` [E, width] in COO order."""
         import torch
+        # raw pointers cross the C ABI: the kernel reads edge_term[eid * width] for every CSR slot and x[j * width] for
+        # every source -- a short, narrower, int64, CPU or strided tensor would be read out of bounds or reinterpreted
+        _require(x, "x", torch.float32, 2)
+        w = int(x.shape[1])
+        if int(x.shape[0]) != self._N:
+            raise GnnbError(f"x has {int(x.shape[0])} rows, the prepared batch has {self._N} nodes")
+        _require(edge_term, "edge_term", torch.float32, 2, w)
+        if int(edge_term.shape[0]) != self._E or edge_term.device != x.device:
+            raise GnnbError(f"edge_term must be [{self._E}, {w}] on {x.device} (one row per COO edge of the prepared batch), "
+                            f"got {tuple(edge_term.shape)} on {edge_term.device}")
         if out is None:
             out = torch.empty_like(x)
+        else:
+            _require(out, "out", torch.float32, 2, w)
+            if out.shape[0] != x.shape[0] or out.device != x.device:
+                raise GnnbError(f"out must be {tuple(x.shape)} on {x.device}")
         _check(self.lib.gnnb_aggregate_edges(self._ws, _dptr(x), _dptr(edge_term), _dptr(out), int(x.shape[1]),
                                              float(eps), _stream_ptr(stream)))
         return out

@@ -188,7 +188,20 @@ int gnnb_workspace_check(gnnb_workspace *ws, void *stream);
 
 /* compute_degree_tables + compute_neighbor_tables for a whole batch
  * (gnn_builder_lib.h:1051-1124): fills the workspace's row_ptr[N+1], col[E]
- * (CSR by destination, stable in COO order), in-degree, node tiles. */
+ * (CSR by destination, stable in COO order), in-degree, node tiles.
+ *
+ * Explicit self loops.  The tables belong to the MODEL the workspace was created for: on a GCN workspace an edge (v, v) of
+ * the input is NOT entered (PyG's gcn_norm replaces the self loops of the input by exactly one per node, which every GCN
+ * aggregate adds itself; the reference C++ would count it on top of its own self term, gnn_builder_lib.h:1234-1278, and
+ * disagrees with its own PyTorch golden there).  Consequences for the stage entry points: on a GCN workspace
+ * gnnb_aggregate(GNNB_AGG_SUM / MEAN / LG / SIMPLE) and gnnb_aggregate_edges do not see those edges either; on any other
+ * workspace gnnb_aggregate(GNNB_AGG_GCN) counts an explicit self loop as an ordinary edge.  Dropped edges leave a gap at
+ * the end of their graph's CSR segment: row_ptr holds row STARTS (a row's length is in_deg, not a difference of row_ptr),
+ * and the unused col / edge-index slots of a segment read -1 in the *_to_host copies.
+ *
+ * A malformed batch (GNNB_ERR_GRAPH from gnnb_workspace_check) is reported ONCE: the check, or the lazy report of the next
+ * gnnb_graph_prep on the workspace -- which returns GNNB_ERR_GRAPH WITHOUT having enqueued the batch it was called with --
+ * clears the device flag, so a later check speaks about later batches only. */
 int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *node_ptr_dev,
                     const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges,
                     float pna_delta, void *stream);
@@ -200,7 +213,11 @@ typedef enum gnnb_agg {
     GNNB_AGG_GCN = 0,  /* sum_j x_j/sqrt((1+d_i)(1+d_j)) + x_i/(1+d_i)   gnn_builder_lib.h:1213-1289 */
     GNNB_AGG_SUM = 1,  /* sum_j x_j + (1+eps) x_i                         gnn_builder_lib.h:1389-1437,1525-1535 */
     GNNB_AGG_MEAN = 2, /* mean_j x_j (0 if no neighbour)                  gnn_builder_lib.h:2161-2209 */
-    GNNB_AGG_PNA = 3,  /* [max|min|mean|std]_j (q_i + p_j), out width 4w  gnn_builder_lib.h:1750-1834, PyG std */
+    GNNB_AGG_PNA = 3,  /* [max|min|mean|std]_j (q_i + p_j), out width 4w  gnn_builder_lib.h:1750-1834, PyG std:
+                        * sqrt(max(E[h^2] - E[h]^2, 1e-5)), 0 where <= sqrt(1e-5) -- so a node of in-degree 0 or 1 gets std 0
+                        * (and max = min = mean = 0 at in-degree 0).  The reference holds no golden vector for such nodes
+                        * (its fixture graph has in-degrees 2..11); the values follow from the formula that reproduces
+                        * tb_pna_output.bin to 1.2e-7 */
     GNNB_AGG_LG = 4,   /* sum_j x_j/sqrt(d_i d_j), no self term, 0 where d_i d_j = 0   gnn_builder_lib.h:2350-2499 (lg_conv) */
     GNNB_AGG_SIMPLE = 5, /* sum_j x_j, no self term                           gnn_builder_lib.h:2501-2634 (simple_conv) */
     GNNB_AGG_COPY = 6  /* out = x: the kernel's launch shape and bytes with no gather (calibration of the roofline) */

@@ -107,6 +107,9 @@ def test_constructor_validation_matches_the_reference():
         gnnb.Project("p", model, "regression", None, "/tmp", float_or_fixed="fixed", fpx=gnnb.FPX(16, 10, Q="AP_RND"))
     with pytest.raises(Exception, match="I must be <= 33"):
         gnnb.FPX(64, 40)
+    for w_, i_ in ((8, 9), (8, 0)):  # I > W, I < 1: refused by the Project, not later by gnnb_model_create
+        with pytest.raises(ValueError):
+            gnnb.Project("p", model, "regression", None, "/tmp", float_or_fixed="fixed", fpx=gnnb.FPX(w_, i_))
     p = gnnb.Project("p", model, "regression", None, "/tmp")
     with pytest.raises(NotImplementedError):
         p.run_vitis_hls_synthesis()

@@ -134,6 +134,42 @@ def test_gcn_explicit_self_loops_follow_pyg(dev):
     with torch.no_grad():                                      # and the torch model definition agrees
         t = model(torch.from_numpy(x), torch.from_numpy(coo.T.astype(np.int64))).numpy()[0]
     assert np.abs(t - pyg).max() < 1e-5
+    # the three dropped self-loop edges leave three CSR slots unowned: they read -1 in the host copies, every other slot
+    # holds a source of its row / the COO row it came from (gnnb_hip.h, gnnb_graph_prep)
+    row_ptr, col, in_deg = cm.tables_to_host()
+    eid = cm.edge_index_table_to_host()
+    assert (col == -1).sum() == 3 and (eid == -1).sum() == 3 and np.array_equal(col == -1, eid == -1)
+    assert in_deg.sum() == int(keep.sum())
+    for v in range(n):
+        slots = np.arange(row_ptr[v], row_ptr[v] + in_deg[v])
+        assert np.array_equal(coo[eid[slots], 1], np.full(len(slots), v)) and np.array_equal(coo[eid[slots], 0], col[slots])
+
+
+def test_stage_entry_points_refuse_mismatched_tensors(dev):
+    """Raw pointers cross the C ABI (advisor finding): the GINE aggregate reads edge_term[edge * width] for every CSR slot
+    and x[source * width] -- a short, narrower, int64, CPU or strided tensor, or an `out` of another shape, is refused by
+    the binding instead of being read out of bounds.  The sizes of the prepared batch are known after forward() too."""
+    model = plain_model("gin", 8, 8)
+    x, coo = G.graph()
+    batch = pack_graphs([(x, coo)])
+    cm = runtime.CompiledModel.from_model(model, 1, G.N, G.E)
+    xd, cood, nptr, eptr = to_dev(batch, dev)
+    cm.forward(xd, cood, nptr, eptr)                           # (prepares the batch: no separate graph_prep call)
+    assert cm.edge_index_table_to_host().shape[0] == G.E
+    et = torch.rand(G.E, 8, device=dev)
+    good = cm.aggregate_edges(xd, et)
+    assert good.shape == xd.shape
+    for bad_x, bad_et, bad_out in ((xd, et[:-1], None), (xd, et[:, :4].contiguous(), None), (xd, et.double(), None),
+                                   (xd, et.cpu(), None), (xd, et.T.contiguous().T, None), (xd[:-1], et, None),
+                                   (xd, et, torch.empty(G.N, 4, device=dev)), (xd, et, torch.empty(G.N - 1, 8, device=dev))):
+        with pytest.raises(runtime.GnnbError):
+            cm.aggregate_edges(bad_x, bad_et, out=bad_out)
+    with pytest.raises(runtime.GnnbError):
+        cm.aggregate("sum", xd, out=torch.empty(G.N, 4, device=dev))
+    with pytest.raises(runtime.GnnbError):
+        cm.forward_prepared(xd, out=torch.empty(3, cm.out_dim, device=dev))
+    with pytest.raises(runtime.GnnbError):
+        cm.forward(xd, cood, nptr, eptr, out=torch.empty(1, cm.out_dim + 1, device=dev))
 
 
 @pytest.mark.parametrize("kind,golden", [("simple", "tb_simple_output"), ("lg", "tb_lgconv_output")])
@@ -235,7 +271,7 @@ def test_malformed_batch_is_reported(dev):
 
 def test_flagged_batch_is_reported_lazily_without_a_check(dev):
     """A caller that never calls check(): the forward after a flagged batch has RUN raises (host-mapped flag read without
-    synchronisation); check() then reports and clears the device-side flags, and the workspace works again.  Covers a
+    synchronisation) and clears the flags; a flag is reported once, by whichever comes first -- that lazy report or check().  Covers a
     broken max_graph_nodes promise on the fused GCN stack, the case the advisor singled out."""
     model = make_model("gcn", in_dim=11, hidden=32, layers=2, task_out=1)
     good = synthetic.make_batch("qm9", 64, seed=0)
@@ -245,9 +281,11 @@ def test_flagged_batch_is_reported_lazily_without_a_check(dev):
     cm.forward(*args)                    # runs (contained), flags the batch on the device
     torch.cuda.synchronize()
     with pytest.raises(runtime.GnnbError, match="earlier batch"):
-        cm.forward(*args)
+        cm.forward(*args)                # (reported; the batch of THIS call was not enqueued)
+    cm.check()                           # reported once: the lazy report cleared the device flag too (advisor, round 2)
+    cm.forward(*args)                    # flagged again ...
     with pytest.raises(runtime.GnnbError, match="malformed batch"):
-        cm.check()
+        cm.check()                       # ... and this time the check is what reports (and clears) it
     cm.set_max_graph_nodes(int(np.diff(good.node_ptr).max()))
     out = cm.forward(*args).cpu().numpy()
     cm.check()
