@@ -38,8 +38,9 @@ struct BatchTables {
 
 constexpr int GNNB_G2_STAGE_ROWS = 64;     // rows per stage of the fused 2-layer GCN kernel (4 MFMA units)
 constexpr int GNNB_G2_STAGE_ROWS_BF6 = 48; // ... in the opt-in bf16x6 math mode (3 units)
-int zf_stage_rows(int f0);  // rows per stage of the transform-first 2-layer GCN kernel k_gcn2_zf for input width f0 (176 or 96)
-long gcn2_zf_tile_capacity(int f0); // node tiles it can walk in one launch
+// rows per stage of the transform-first 2-layer GCN kernel k_gcn2_zf for input width f0 and the promised graph size (176 or 96)
+int zf_stage_rows(int f0, int promise);
+long gcn2_zf_tile_capacity(int f0, int promise); // node tiles it can walk in one launch
 
 struct Options {
     int tile_rows;    // node-tile granularity (rows; tiles are cut at graph boundaries)
@@ -60,7 +61,8 @@ struct Options {
                        //     measured best with batches in flight: C3t 15.0 M graphs/s), 1 = k_conv_rows on a forked stream (shortest
                        //     single forward, 13.5 M in the pipeline: the stack kernels leave no register space for a co-resident
                        //     wave, so the fork only reorders), 0 = through the big layer-by-layer kernels (14.2 M)
-    int zf_shape;      // k_gcn2_zf: 1 = one 16-wave workgroup per CU, 176-row stages (default); 0 = two 8-wave workgroups, 96-row stages
+    int zf_shape;      // k_gcn2_zf: 0 = two 8-wave workgroups per CU, 96-row stages; 1 = one 16-wave workgroup, 176-row stages;
+                       //     2 = shape 0 while the promised graph size fits its stages, else shape 1 (default)
     int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it (k_gcn2_fused), 0 = layer by layer
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
     int head_small;    // 1 = readout on a pooled matrix with the small-footprint kernel that co-resides with the

@@ -57,7 +57,7 @@ Options &options()
                         env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_GEMM_DMA", 1),
                         env_int("GNNB_GEMM_WLDS", 1),             env_int("GNNB_GEMM_WLDS_SLOTS", 2),
-                        env_int("GNNB_FUSE_NARROW", 1),     env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 1),
+                        env_int("GNNB_FUSE_NARROW", 1),     env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
                         env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 1)};
@@ -221,7 +221,7 @@ int gnnb_set_option(const char *name, int value)
         o.fuse_gcn2 = value;
     else if (!strcmp(name, "fuse_zf") && value >= 0 && value <= 1)
         o.fuse_zf = value;
-    else if (!strcmp(name, "zf_shape") && value >= 0 && value <= 1)
+    else if (!strcmp(name, "zf_shape") && value >= 0 && value <= 2)
         o.zf_shape = value;
     else if (!strcmp(name, "large_fork") && value >= 0 && value <= 2)
         o.large_fork = value;
@@ -583,11 +583,12 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
         ws->max_graph_nodes > 0) {
         // (a 2-layer fp32 GCN stack runs k_gcn2_zf with its 96-row stages; everything else k_gcn2_fused)
         const bool zf = ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && options().fuse_zf && !options().math;
-        const int stage_rows = zf ? zf_stage_rows(ws->desc.in_dim) : options().math ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
+        const bool bf6 = options().math && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2; // (the only bf16x6 stack form)
+        const int stage_rows = zf ? zf_stage_rows(ws->desc.in_dim, ws->max_graph_nodes) : bf6 ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
         while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > stage_rows)
             t.tile_rows >>= 1;
         // very large batches: coarser tiles (while a tile still fits a stage) keep the per-workgroup tile table in LDS
-        const long tile_cap = zf ? gcn2_zf_tile_capacity(ws->desc.in_dim) : gcn2_fused_tile_capacity();
+        const long tile_cap = zf ? gcn2_zf_tile_capacity(ws->desc.in_dim, ws->max_graph_nodes) : gcn2_fused_tile_capacity();
         while ((num_nodes + t.tile_rows - 1) / t.tile_rows > tile_cap && ws->max_graph_nodes + 2 * t.tile_rows - 1 <= stage_rows)
             t.tile_rows <<= 1;
     }

@@ -765,12 +765,14 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     if (!o.fuse_gcn2 || t.num_nodes <= 0)
         return hipErrorNotSupported;
     // more than two layers: fp32 mode only, middle weights 16-B aligned (float4 slice loads)
-    if (deep.nl < 2 || (deep.nl > 2 && (o.math || !deep.wmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3))))
+    // (the opt-in bf16x6 math mode exists for the plain two-layer GCN form only: deeper GCN stacks and GIN stacks run their
+    // fp32 kernel in either mode -- the mode may never make a model slower by sending it down the layer-by-layer path)
+    if (deep.nl < 2 || (deep.nl > 2 && (!deep.wmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3))))
         return hipErrorNotSupported;
     // GIN stacks: fp32 mode, hidden == out (every wide matrix h0 x h0), biases present
-    if (deep.gin && (o.math || h1 != h0 || !deep.wmid || !deep.bmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3)))
+    if (deep.gin && (h1 != h0 || !deep.wmid || !deep.bmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3)))
         return hipErrorNotSupported;
-    const int math = o.math ? 1 : 0;
+    const int math = (o.math && deep.nl == 2 && !deep.gin) ? 1 : 0;
     const int cap = 16 * g2_units(math);
     if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > cap)
         return hipErrorNotSupported; // no promise that whole graphs fit a stage

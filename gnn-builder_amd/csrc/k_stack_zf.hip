@@ -103,6 +103,10 @@ struct ZfStage {
     int ta, tb, nb, rows, ga, gb, e0, ne;
 };
 
+// REGISTER BUDGET: keep this kernel at <= 104 VGPRs (`make resource-usage`).  Four waves per SIMD then leave a 96-register
+// wave slot, and with ~145 KB of LDS per CU that is what lets the readout and graph-prep kernels of the other batches in
+// flight run BESIDE it: at 111 registers the three-stream pipeline of bench.py lost 12 % (59.0 vs 52.1 us per step).
+// (The launch bound only promises four waves per SIMD = 128 registers; amdgpu_num_vgpr is ignored beside it.)
 template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS>
 __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ W1f,
     const float *__restrict__ b1, int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled
 #ifdef GNNB_ZF_ABLATE
+    , unsigned long long *dbg_span // [2]: min start / max end wall clock (100 MHz) over the workgroups of this launch
     , int dbg // development only (-DGNNB_ZF_ABLATE): bit 0 skips P1, 1 skips P0', 2 skips M1, 3 skips M0, 4 skips the Z write
 #define ZF_ON(bit) (!(dbg & (1 << (bit))))
 #else
@@ -150,8 +155,16 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     int32_t *sgraph = stile + (G2_TCAP + 1);
     int32_t *sedge = sgraph + (G2_TCAP + 1);
     float *SB1 = reinterpret_cast<float *>(sedge + (G2_TCAP + 1) + 1); // b1 zero-padded to 128 floats (3 x 129 table entries + 1: 16-B aligned)
+    int4 *SPLAN = reinterpret_cast<int4 *>(SB1 + 128);                 // the stage after next, planned by ONE wave (2 x int4)
+    float *SB0 = reinterpret_cast<float *>(SPLAN + 2);                 // b0 zero-padded to 128 floats
 
 #ifdef GNNB_ZF_ABLATE
+    if (dbg_span && threadIdx.x == 0)
+        atomicMin(dbg_span, wall_clock64());
+    struct SpanEnd {
+        unsigned long long *p;
+        __device__ ~SpanEnd() { if (p && threadIdx.x == 0) atomicMax(p + 1, wall_clock64()); }
+    } span_end{dbg_span};
     if (dbg & 32)
         return; // (launch overhead alone)
 #endif
@@ -159,7 +172,6 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
     if (t1 <= t0)
         return;
-    // (the weight loads go out FIRST: they depend on nothing and their latency then overlaps the tile-table round trip)
     // ---- wave roles: layer L has ncs_L = pow2ceil(h_L / 16) column slices of 16 and nrg_L = 8 / ncs_L row groups;
     // wave w owns slice (w mod ncs) for the units rg, rg + nrg, ... with rg = w / ncs
     int cs0l = 0, cs1l = 0;
@@ -169,49 +181,16 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         cs1l++; // h <= 128 -> <= 3
     const int nrg0 = G2_NW >> cs0l, nrg1 = G2_NW >> cs1l;
 
-    // ---- weight slices -> registers (16 output columns x K per layer and wave), biases
-    float w0r[KQ0 * 4], w1r[KQ1 * 4];
-    float4 bias0;
-    {
-        const int li = lane & 15, lg = lane >> 4;
-        const int n0c = (wave & ((1 << cs0l) - 1)) * 16 + li, n1c = (wave & ((1 << cs1l) - 1)) * 16 + li;
-#pragma unroll
-        for (int q = 0; q < KQ0; q++) {
-            const int k = 16 * q + 4 * lg;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0c < h0)
-                v = load4_guard(W0 + (size_t)n0c * f0 + k, f0 - k, false);
-            w0r[q * 4 + 0] = v.x;
-            w0r[q * 4 + 1] = v.y;
-            w0r[q * 4 + 2] = v.z;
-            w0r[q * 4 + 3] = v.w;
-        }
-#pragma unroll
-        for (int q = 0; q < KQ1; q++) {
-            const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (W1f) // fragment-order copy (gnnb_model_create): one contiguous KiB per load instruction of the wave
-                v = reinterpret_cast<const float4 *>(W1f)[(((wave & ((1 << cs1l) - 1)) * KQ1 + q) * 4 + lg) * 16 + li];
-            else if (n1c < h1)
-                v = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + k);
-            w1r[q * 4 + 0] = v.x;
-            w1r[q * 4 + 1] = v.y;
-            w1r[q * 4 + 2] = v.z;
-            w1r[q * 4 + 3] = v.w;
-        }
-        {   // bias of the four columns this lane holds after M0 (h0 is a multiple of 16; b0 may be unaligned)
-            const int c4 = (wave & ((1 << cs0l) - 1)) * 16 + 4 * lg;
-            bias0 = (c4 < h0 && b0) ? make_float4(b0[c4], b0[c4 + 1], b0[c4 + 2], b0[c4 + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
     // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
     for (int i = tid; i <= t1 - t0; i += G2_WG) {
         stile[i] = min(max(tile_first[t0 + i], 0), N);
         sgraph[i] = min(max(tile_graph[t0 + i], 0), num_graphs);
         sedge[i] = min(max(tile_edge[t0 + i], 0), E);
     }
-    if (tid < 128)
+    if (tid < 128) {
         SB1[tid] = (b1 && tid < h1) ? b1[tid] : 0.0f;
+        SB0[tid] = (b0 && tid < h0) ? b0[tid] : 0.0f;
+    }
     __syncthreads();
 
     // ---- balanced stage plan: the rows that are left are cut into the fewest stages that can hold them, of EQUAL
@@ -295,12 +274,44 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     issue_small(cur, 0, lane, wave);
     issue_rows(cur, 0, lane, wave);
 
+    // (the weights are requested HERE, behind the first stage's DMA: in front of the tile-table loads they made the
+    // workgroup's first barrier wait for 128 KB of weight fragments; now they land beside the DMA round trip and P0)
+    // ---- weight slices -> registers (16 output columns x K per layer and wave), biases
+    float w0r[KQ0 * 4], w1r[KQ1 * 4];
+    {
+        const int li = lane & 15, lg = lane >> 4;
+        const int n0c = (wave & ((1 << cs0l) - 1)) * 16 + li, n1c = (wave & ((1 << cs1l) - 1)) * 16 + li;
+#pragma unroll
+        for (int q = 0; q < KQ0; q++) {
+            const int k = 16 * q + 4 * lg;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0c < h0)
+                v = load4_guard(W0 + (size_t)n0c * f0 + k, f0 - k, false);
+            w0r[q * 4 + 0] = v.x;
+            w0r[q * 4 + 1] = v.y;
+            w0r[q * 4 + 2] = v.z;
+            w0r[q * 4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < KQ1; q++) {
+            const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (W1f) // fragment-order copy (gnnb_model_create): one contiguous KiB per load instruction of the wave
+                v = reinterpret_cast<const float4 *>(W1f)[(((wave & ((1 << cs1l) - 1)) * KQ1 + q) * 4 + lg) * 16 + li];
+            else if (n1c < h1)
+                v = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + k);
+            w1r[q * 4 + 0] = v.x;
+            w1r[q * 4 + 1] = v.y;
+            w1r[q * 4 + 2] = v.z;
+            w1r[q * 4 + 3] = v.w;
+        }
+    }
+
     // Pin every weight register through an (empty) asm: the compiler must finish the loads HERE (k_stack.hip: left
     // alone it guards their first use inside the stage loop with s_waitcnt vmcnt(0), which also waits for the DMA)
 #pragma unroll
     for (int q = 0; q < KQ0 * 4; q++)
         asm volatile("" : "+v"(w0r[q]));
-    asm volatile("" : "+v"(bias0.x), "+v"(bias0.y), "+v"(bias0.z), "+v"(bias0.w));
     dma_wait_all();
     __syncthreads();
 
@@ -446,6 +457,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 zf_mma<KQ0, NU>(A0, LD0, w0r, row0, li, lg, acc);
+                const float4 bias0 = *reinterpret_cast<const float4 *>(SB0 + (n0c - li) + 4 * lg); // (from LDS: four registers fewer across P1)
                 if (n0c < h0) { // (h0 is 32, 64 or 128: the lane's four columns are all inside when its slice is)
 #pragma unroll
                     for (int k = 0; k < NU; k++)
@@ -555,7 +567,20 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             while ((4 << glog2) < (h1 >> csl) && glog2 < 5)
                 glog2++;
             const int Gl = 1 << glog2, S = 64 >> glog2;
-            const int gl = tv & (Gl - 1), sr = (tv & 63) >> glog2;
+            // lane -> (row slot sr, chunk gl).  ds_read_b128 is served in four passes of sixteen lanes, {0-3, 12-15, 20-27},
+            // {4-11, 16-19, 28-31} and the same + 32: with the plain mapping (lanes 0-15 = slot 0 ...) at sixteen lanes per
+            // row every pass mixes chunks of TWO rows, whose bank windows (16 x 16 B each, rows 528 B apart) overlap unless
+            // the rows are a multiple of 16 apart -- a third of the kernel's LDS cycles were bank conflicts.  For Gl = 16 a
+            // row slot is therefore ONE hardware pass group (its sixteen lanes read 256 contiguous bytes: conflict-free
+            // whatever the rows), the chunk is the lane's rank inside the group; the slots of one chunk are then the lanes
+            // l, l ^ 4, l + 32, (l ^ 4) + 32.
+            int gl = tv & (Gl - 1), sr = (tv & 63) >> glog2;
+            if (Gl == 16) {
+                const int l5 = tv & 31;
+                const bool g1 = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
+                sr = ((tv & 63) >> 5) * 2 + (g1 ? 1 : 0);
+                gl = g1 ? (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16)) : (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12));
+            }
             const int4 *REC = reinterpret_cast<const int4 *>(RECb + (size_t)b * rec_b);
             const char *sbase = smem + rows_b + (size_t)b * small_b;
             const float *sdinv = reinterpret_cast<const float *>(sbase);
@@ -659,7 +684,11 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                         for (int i = 0; i < 8; i++)
                             comb(i, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[i]), 0x128, 0xf, 0xf, false))); // row_ror:8
                     }
-                    if (Gl <= 16) {
+                    if (Gl == 16) { // (slots of a chunk: lanes l and l ^ 4 -- see the lane mapping above)
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                            comb(i, __uint_as_float(__builtin_amdgcn_ds_swizzle(__float_as_uint(v[i]), 0x101F))); // xor 4 (bit mode: and 0x1f, xor 4)
+                    } else if (Gl < 16) {
 #pragma unroll
                         for (int i = 0; i < 8; i++) {
                             auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
@@ -704,10 +733,29 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         if (nxt.ta < t1 && ZF_ON(1))
             phase_p0(nxt, b ^ 1, tv, (ngr << csl) & (G2_NW - 1));
         ZF_PT(8);
+        // the stage after next: planned by ONE wave (the plan is ~150 uniform VALU / LDS instructions -- executed by all
+        // sixteen waves it was a tenth of the kernel's vector instructions) and handed over through LDS
+        if (wv == G2_NW - 1) {
+            const ZfStage pn = plan(nxt.tb);
+            if ((tv & 63) == 0) {
+                SPLAN[0] = make_int4(pn.ta, pn.tb, pn.nb, pn.rows);
+                SPLAN[1] = make_int4(pn.ga, pn.gb, pn.e0, pn.ne);
+            }
+        }
         cur = nxt;
-        nxt = plan(cur.tb);
         b ^= 1;
         g2_barrier(); // A0 / REC of the next stage complete; everybody is done with Z
+        {
+            const int4 q0 = SPLAN[0], q1 = SPLAN[1];
+            nxt.ta = __builtin_amdgcn_readfirstlane(q0.x);
+            nxt.tb = __builtin_amdgcn_readfirstlane(q0.y);
+            nxt.nb = __builtin_amdgcn_readfirstlane(q0.z);
+            nxt.rows = __builtin_amdgcn_readfirstlane(q0.w);
+            nxt.ga = __builtin_amdgcn_readfirstlane(q1.x);
+            nxt.gb = __builtin_amdgcn_readfirstlane(q1.y);
+            nxt.e0 = __builtin_amdgcn_readfirstlane(q1.z);
+            nxt.ne = __builtin_amdgcn_readfirstlane(q1.w);
+        }
         ZF_PT(9);
 #ifdef GNNB_PROBE
         nst++;
@@ -729,16 +777,52 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 
 // (input widths above 16 take two MFMA k blocks per row of A0: with 176-row stages the carve would pass 160 KB, so those
 // models run the 96-row shape)
-static bool zf_wide_shape(int f0) { return options().zf_shape && f0 <= 16; }
-int zf_stage_rows(int f0) { return zf_wide_shape(f0) ? 176 : 96; }
-long gcn2_zf_tile_capacity(int f0)
+// zf_shape 2 (default): the two-workgroup shape while the promised graph size fits its 96-row stages (it is ~2 us faster
+// per launch: the two workgroups of a CU fill each other's barrier and latency gaps), the 176-row shape beyond that
+static bool zf_wide_shape(int f0, int promise)
+{
+    const int sh = options().zf_shape;
+    return f0 <= 16 && (sh == 1 || (sh == 2 && promise + 3 > 96)); // (+ 3: the finest node tiles are 4 rows)
+}
+int zf_stage_rows(int f0, int promise) { return zf_wide_shape(f0, promise) ? 176 : 96; }
+long gcn2_zf_tile_capacity(int f0, int promise)
 {
     int devid = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
         cus = prop.multiProcessorCount;
-    return (long)(ZF_TCAP - 2) * (zf_wide_shape(f0) ? 1 : 2) * cus;
+    return (long)(ZF_TCAP - 2) * (zf_wide_shape(f0, promise) ? 1 : 2) * cus;
 }
+
+#ifdef GNNB_ZF_ABLATE
+// development only: a ring of 256 {min start, max end} slots, one per launch; gnnb_zf_dbg_spans copies them out
+static unsigned long long *g_zf_spans = nullptr;
+static int g_zf_launches = 0;
+static unsigned long long *zf_dbg_span_slot()
+{
+    if (!g_zf_spans)
+        return nullptr;
+    return g_zf_spans + 2 * (g_zf_launches++ & 255);
+}
+extern "C" int gnnb_zf_dbg_reset()
+{
+    if (!g_zf_spans)
+        (void)hipMalloc((void **)&g_zf_spans, 256 * 2 * sizeof(unsigned long long));
+    unsigned long long init[512];
+    for (int i = 0; i < 256; i++) {
+        init[2 * i] = ~0ull;
+        init[2 * i + 1] = 0ull;
+    }
+    g_zf_launches = 0;
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpy(g_zf_spans, init, sizeof(init), hipMemcpyHostToDevice);
+}
+extern "C" int gnnb_zf_dbg_spans(unsigned long long *host, int *launches)
+{
+    *launches = g_zf_launches;
+    return g_zf_spans ? (int)hipMemcpy(host, g_zf_spans, 256 * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) : -1;
+}
+#endif
 
 hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                           int h0, const float *w1, const float *b1, int h1, int act,
@@ -747,7 +831,7 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
     const Options &o = options();
     if (!o.fuse_gcn2 || !o.fuse_zf || o.math || t.num_nodes <= 0)
         return hipErrorNotSupported;
-    const int cap = zf_stage_rows(f0);
+    const int cap = zf_stage_rows(f0, t.max_graph_nodes_hint);
     if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > cap)
         return hipErrorNotSupported; // no promise that whole graphs fit a stage
     if (f0 < 1 || f0 > 32 || !(h0 == 32 || h0 == 64 || h0 == 128) || h1 < 4 || h1 > 128 || (h1 & 3))
@@ -763,7 +847,7 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
     const int ldh = (h0 > h1 ? h0 : h1) + 4;
     const int ecap = cap <= 96 ? 512 : 1024;
     const size_t lds = (size_t)rows_b + 2 * (size_t)small_b + (size_t)cap * 16 * kq0 * 4 + (size_t)cap * ldh * 4 +
-                       2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 3 * (size_t)(ZF_TCAP + 1) * 4 + 4 + 512;
+                       2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 3 * (size_t)(ZF_TCAP + 1) * 4 + 4 + 512 + 32 + 512;
     if (lds > 160 * 1024)
         return hipErrorNotSupported;
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
@@ -810,14 +894,14 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
                            t.tile_first, t.tile_graph, t.tile_edge, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, t.num_edges, w0, b0, h0, w1, w1f, b1, h1,
                            p0, p1, p2, num_pools, pooled
 #ifdef GNNB_ZF_ABLATE
-                           , getenv("GNNB_ZF_DBG") ? atoi(getenv("GNNB_ZF_DBG")) : 0
+                           , zf_dbg_span_slot(), getenv("GNNB_ZF_DBG") ? atoi(getenv("GNNB_ZF_DBG")) : 0
 #endif
         );
         rc = hipGetLastError();
     };
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
         if constexpr (decltype(q0tag)::value == 1) { // (the wide shape exists for one-block input widths only)
-            if (zf_wide_shape(f0)) {
+            if (zf_wide_shape(f0, t.max_graph_nodes_hint)) {
                 go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{});
                 return;
             }

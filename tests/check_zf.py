@@ -30,7 +30,7 @@ for seed in (0, 5):
         print(f"seed {seed} zf={zf}: path {cmv.last_path()}, finite {np.isfinite(outs[zf]).all()}")
         keep.append(cmv)
     runtime.set_option("fuse_zf", 1)
-    runtime.set_option("zf_shape", 1)
+    runtime.set_option("zf_shape", 2)
     print(f"  max |zf - fused| = {np.abs(outs[1] - outs[0]).max():.3e}, |zf shape 0 - fused| = {np.abs(outs[2] - outs[0]).max():.3e} (scale {np.abs(outs[0]).max():.3f})")
     idx = np.unique(np.concatenate([np.arange(0, 64), np.arange(b.num_graphs - 64, b.num_graphs),
                                     np.random.default_rng(1).integers(0, b.num_graphs, 128), [int(np.diff(b.node_ptr).argmax())]]))
@@ -49,4 +49,4 @@ for seed in (0, 5):
         t = [cm.gcn_stack_timed(bd[0], 200) for _ in range(3)]
         print(f"  zf={zf} shape={shape}: " + " ".join(f"{v:.2f}" for v in t) + " us per launch")
     runtime.set_option("fuse_zf", 1)
-    runtime.set_option("zf_shape", 1)
+    runtime.set_option("zf_shape", 2)

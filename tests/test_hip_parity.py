@@ -686,7 +686,7 @@ def test_fused_gcn_stack_equals_layerwise_and_oracle(dev, fin, h0, h1, act, pool
         assert cm.last_path() == ("stack_zf" if zf else "stack")
     finally:
         runtime.set_option("fuse_zf", 1)
-        runtime.set_option("zf_shape", 1)
+        runtime.set_option("zf_shape", 2)
     cm.check()
     cm.set_max_graph_nodes(0)  # no promise -> layer-by-layer path
     layerwise = cm.forward(*to_dev(batch, dev)).cpu().numpy()
@@ -956,13 +956,15 @@ def test_linear_dma_tail_split_is_bit_identical(dev, M, N, K):
 @pytest.mark.parametrize("promise,math,zf", [(34, 0, 0), (50, 0, 0), (55, 0, 0), (57, 0, 0), (58, 0, 0), (61, 0, 0), (62, 0, 0),
                                              (41, 1, 1), (45, 1, 1), (46, 1, 1),
                                              (34, 0, 1), (62, 0, 1), (89, 0, 1), (120, 0, 1), (169, 0, 1), (172, 0, 1), (173, 0, 1), (174, 0, 1),
-                                             (89, 0, 2), (93, 0, 2), (94, 0, 2)])
+                                             (89, 0, 2), (93, 0, 2), (94, 0, 2),
+                                             (29, 0, 3), (93, 0, 3), (94, 0, 3), (173, 0, 3), (174, 0, 3)])
 def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math, zf):
     """k_gcn2_fused: graphs of up to 57 nodes fit one 64-row stage with the default 8-row node tiles, up to 61 with 4-row
     tiles (graph prep picks the tile size from the promise): ESOL-sized molecules (n_max 55) take the fused stack.  62 is
     past the limit: the layer-by-layer path answers, same numbers.  The opt-in bf16x6 mode keeps 48-row stages (limit 45).
     k_gcn2_zf (the default for two fp32 GCN layers) has 176-row stages (one 16-wave workgroup per CU): 169 nodes with 8-row
-    tiles, 173 with 4-row tiles; zf = 2 selects its other shape (two 8-wave workgroups per CU, 96-row stages: 89 / 93)."""
+    tiles, 173 with 4-row tiles; zf = 2 selects its other shape (two 8-wave workgroups per CU, 96-row stages: 89 / 93); zf = 3
+    the default: the two-workgroup shape while the promise fits it, the 176-row shape beyond."""
     model = make_model("gcn", in_dim=9, hidden=128, layers=2, out_dim=128, act="relu", pools=("add", "mean", "max"), task_out=4)
     rng = np.random.default_rng(promise)
     graphs = []
@@ -977,14 +979,14 @@ def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math, zf):
     try:
         runtime.set_option("math", math)
         runtime.set_option("fuse_zf", 1 if zf else 0)
-        runtime.set_option("zf_shape", 0 if zf == 2 else 1)
+        runtime.set_option("zf_shape", {2: 0, 3: 2}.get(zf, 1))  # (zf = 3: the default, shape picked from the promise)
         cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
         got = cm.forward(*to_dev(batch, dev)).cpu().numpy()
         cm.check()
         assert np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
         # which path ran: reported by the workspace; the stack's timed entry refuses when it is not eligible
         xd = torch.from_numpy(batch.x).to(dev)
-        limit = 45 if math else {0: 61, 1: 173, 2: 93}[zf]
+        limit = 45 if math else {0: 61, 1: 173, 2: 93, 3: 173}[zf]
         if promise <= limit:
             assert cm.last_path() == ("stack_zf" if zf and not math else "stack")
             assert cm.gcn_stack_timed(xd, 2) > 0.0
@@ -995,7 +997,7 @@ def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math, zf):
     finally:
         runtime.set_option("math", 0)
         runtime.set_option("fuse_zf", 1)
-        runtime.set_option("zf_shape", 1)
+        runtime.set_option("zf_shape", 2)
 
 
 @pytest.mark.parametrize("conv,shape,promise", [("gcn", "qm9", True), ("gin", "molhiv", False), ("pna", "qm9", False)])
@@ -1197,6 +1199,26 @@ def test_full_size_config3_on_the_fused_gin_stack(dev):
     assert np.abs(out_rev[::-1] - out_d).max() < 2e-5 * max(1.0, float(np.abs(out_d).max()))
     lw = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
     assert np.abs(lw.forward(*args).cpu().numpy() - out_d).max() < 5e-5 * max(1.0, float(np.abs(out_d).max()))
+
+
+@pytest.mark.parametrize("conv,layers", [("gin", 3), ("gcn", 3), ("gin", 2)])
+def test_opt_in_math_mode_never_leaves_the_stack(dev, conv, layers):
+    """The bf16x6 math mode exists for the plain two-layer GCN stack and the GEMM kernels.  A GIN stack or a deeper GCN stack
+    keeps its fp32 stack kernel when the mode is switched on (round 2 sent those models down the layer-by-layer path:
+    math = 1 made config 3 slower)."""
+    model = make_model(conv, in_dim=9, hidden=128, layers=layers, out_dim=128, act="relu", pools=("add",), task_out=1, seed=3)
+    batch = synthetic.make_batch("molhiv", 300, seed=9)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    try:
+        runtime.set_option("math", 1)
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges,
+                                              max_graph_nodes=int(np.diff(batch.node_ptr).max()))
+        out = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+        cm.check()
+        assert cm.last_path() == "stack"
+    finally:
+        runtime.set_option("math", 0)
+    assert np.abs(out - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
 
 
 def _forward_with_large_segment(model, batch, limit, dev, **kw):
