@@ -80,8 +80,13 @@ typedef struct gnnb_model_desc {
      * (default).  Otherwise the input features, every weight and bias, every conv layer's output (after skip and
      * activation), the pooled vector and every head layer's output are put on the ap_fixed<W, I> grid:
      *     q(v) = wrap(floor(v * 2^(W-I)) / 2^(W-I))   into [-2^(I-1), 2^(I-1)).
-     * Sums inside a layer are carried in fp32 (the HLS build rounds every partial result to W bits): an accuracy-
-     * study emulation at layer boundaries, not a bit-exact ap_fixed model.  The fused kernels are not used. */
+     * Sums inside a layer are carried in fp32 (the HLS build rounds every partial result to W bits -- `linear` accumulates
+     * in F_TYPE per multiply-add, gnn_builder_lib.h:866-904): this is a LAYER-BOUNDARY study tool for accuracy against
+     * width, NOT a bit-exact ap_fixed model, and it is pinned to nothing of the reference (ap_fixed.h is a Vitis header:
+     * the fixed-point build of the library does not compile here).  What IS guaranteed, and tested: outputs lie on the
+     * grid; the HIP path and the C oracle's emulation (which differ only in the fp32 summation order inside a layer) are
+     * never more than two grid steps apart, with >= 95 % of the outputs identical for W <= 16; at W - I = 20 the finest
+     * format reproduces the float model to 1e-3.  The fused stack kernels are not used in this mode. */
     int32_t fpx_w;
     int32_t fpx_i;
 } gnnb_model_desc;

@@ -504,7 +504,11 @@ def test_fixed_point_emulation(dev, conv, W, I):
     step = 2.0 ** -(W - I)
     assert np.abs(out / step - np.round(out / step)).max() < 1e-3              # on the grid
     frac_exact = np.mean(out == ref)
-    assert np.abs(out - ref).max() <= max(40 * step, 2e-4) and frac_exact > 0.5, (np.abs(out - ref).max() / step, frac_exact)
+    # measured over six seeds per case (tests/fpx_stats.py): never more than ONE grid step apart, >= 95 % of the outputs
+    # identical for W <= 16; at FPX(32, 12) a step (2^-20) is the size of an fp32 rounding of the values themselves, so
+    # the share of identical outputs is lower there (>= 76 % measured) while the distance stays one step
+    assert np.abs(out - ref).max() <= 2 * step, (np.abs(out - ref).max() / step, frac_exact)
+    assert frac_exact >= (0.95 if W <= 16 else 0.6), frac_exact
     # fine grid == the float model
     if W == 32:
         flt = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
