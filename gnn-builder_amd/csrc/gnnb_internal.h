@@ -18,6 +18,8 @@ struct BatchTables {
     int4 *node_rec;      // [2N]  per node {rp0, deg, j0, j1}{j2, j3, -, -}: CSR row start, in-degree and
                          //       its first four sources, so one 32-B read feeds the whole gather
     float *dinv;         // [N]   GCN normaliser     1/sqrt(1 + in_degree)
+    float4 *gcoef;       // [N]   GCN: dinv_v * dinv_j of the four inline sources, 0 past the degree (launch_gcn_coef; valid when
+                         //       the workspace says so: written lazily, in front of the first layer-wise GCN aggregate of a batch)
     float *amp;          // [N]   PNA amplification  log(max(d,1)+1)/delta
     float *att;          // [N]   PNA attenuation    delta/log(max(d,1)+1)
     int32_t *tile_first; // [T+1] first node of node-tile t; tiles are cut at graph boundaries
@@ -81,6 +83,8 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s);
+// t.gcoef from t.node_rec / t.dinv: what launch_aggregate(GNNB_AGG_GCN) reads (call once per prepared batch)
+hipError_t launch_gcn_coef(const BatchTables &t, hipStream_t s);
 // GINE: out_i = (1 + eps) x_i + sum_j relu(x_j + eterm[edge]); eterm [E, width] in COO order
 hipError_t launch_aggregate_edges(const BatchTables &t, const float *x, const float *eterm, float *out, int width,
                                   float eps, hipStream_t s);

@@ -163,6 +163,7 @@ struct gnnb_workspace {
     float *pooled = nullptr;            // [max_graphs, np*d]
     float *mlp[2] = {nullptr, nullptr}; // [max_graphs, max(mlp_hidden, mlp_out)]
     bool prepared = false;
+    bool gcoef_ready = false; // t.gcoef holds the prepared batch's GCN coefficients (ensure_gcoef)
     int max_graph_nodes = 0; // caller's promise (0 = none)
     int last_path = GNNB_PATH_NONE; // which kernels the last forward on this workspace ran (gnnb_workspace_last_path)
     // "large segment" of the NEXT batches (gnnb_workspace_set_large_segment): graphs [large_g, B) -- nodes from large_n,
@@ -444,7 +445,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     };
     const size_t N = max_nodes, E = std::max(max_edges, 1), B = max_graphs;
     const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_eid = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
-                 o_att = carve(N * 4), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_gptr = carve((B + 1) * 4),
+                 o_att = carve(N * 4), o_gcoef = carve(N * 16), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_gptr = carve((B + 1) * 4),
                  o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4),
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
                  o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
@@ -465,6 +466,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->t.dinv = (float *)(b + o_dinv);
     ws->t.amp = (float *)(b + o_amp);
     ws->t.att = (float *)(b + o_att);
+    ws->t.gcoef = (float4 *)(b + o_gcoef);
     ws->t.tile_first = (int32_t *)(b + o_tile);
     ws->t.graph_ptr = (int32_t *)(b + o_gptr);
     ws->t.tile_edge = (int32_t *)(b + o_tedge);
@@ -604,6 +606,17 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     GNNB_HIP_TRY(launch_graph_prep(coo_dev, node_ptr_dev, edge_ptr_dev, t, prep_delta, drop_self,
                                    (hipStream_t)stream));
     ws->prepared = true;
+    ws->gcoef_ready = false;
+    return GNNB_OK;
+}
+
+// the GCN coefficient table of the prepared batch, once per batch, in front of the first layer-wise GCN aggregate
+static int ensure_gcoef(gnnb_workspace *ws, void *stream)
+{
+    if (ws->gcoef_ready)
+        return GNNB_OK;
+    GNNB_HIP_TRY(launch_gcn_coef(ws->t, (hipStream_t)stream));
+    ws->gcoef_ready = true;
     return GNNB_OK;
 }
 
@@ -705,6 +718,11 @@ int gnnb_aggregate(gnnb_workspace *ws, int agg_kind, const float *x_dev, const f
         return fail(GNNB_ERR_INVALID, "PNA aggregate needs the per-destination term");
     if (ws->t.num_nodes == 0)
         return GNNB_OK;
+    if (agg_kind == GNNB_AGG_GCN) {
+        int rc = ensure_gcoef(ws, stream);
+        if (rc != GNNB_OK)
+            return rc;
+    }
     GNNB_HIP_TRY(launch_aggregate(ws->t, agg_kind, x_dev, self_dev, out_dev, width, eps,
                                   (hipStream_t)stream));
     return GNNB_OK;
@@ -853,6 +871,11 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
     auto aggregate = [&](int kind, const float *x, const float *selfq, float *out, int w, float eps) -> int {
         if (M <= 0)
             return GNNB_OK;
+        if (kind == GNNB_AGG_GCN) {
+            int rc2 = ensure_gcoef(ws, stream);
+            if (rc2 != GNNB_OK)
+                return rc2;
+        }
         GNNB_HIP_TRY(launch_aggregate(tv, kind, x, selfq, out, w, eps, (hipStream_t)stream));
         return GNNB_OK;
     };

@@ -169,6 +169,89 @@ struct LdsRow {
     }
 };
 
+// Lean form of LdsRow for the float4 modes GCN, SUM, MEAN and SIMPLE, written for instruction count: the reduce phase of
+// the ring kernel is bound by vector / scalar issue (round 2: 46 vector and 58 scalar instructions per output row).
+// Differences to LdsRow: unused neighbour slots get coefficient 0 instead of a select per value (4 selects on scalars
+// instead of 16 on vector components); LDS addresses are one v_mad_u32_u24 per neighbour on bases that already hold the
+// stage's -nb offset (no per-neighbour subtraction, no 32-bit multiply); the output address is a 32-bit lane offset on
+// the stage's base pointer (no 64-bit vector arithmetic per store).  Same sums in the same order as LdsRow / AggAcc.
+typedef __attribute__((address_space(3))) const agg_f32x4 *agg_lds_f4;
+typedef __attribute__((address_space(3))) const float *agg_lds_f;
+__device__ __forceinline__ float4 agg_lds_ld4(uint32_t addr) // ds_read_b128 at an LDS byte address
+{
+    const agg_f32x4 t = *(agg_lds_f4)(uintptr_t)addr;
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+typedef __attribute__((address_space(3))) const int32_t *agg_lds_i;
+template <int MODE, bool NT>
+struct LdsRowF {
+    typedef Vf<4> V;
+    int rp0, deg;
+    uint32_t roff;
+    float di, c[4];
+    V xi, nbv[4];
+    bool valid;
+
+    // sxo  = LDS byte address of the stage's rows minus nb * w4, plus this lane's column offset
+    // sdo  = LDS byte address of its normalisers minus nb * 4 (GCN)
+    __device__ __forceinline__ void begin(bool ok, int r_, const int4 *srec, uint32_t sxo, uint32_t sx_lane,
+                                          const float *sdinv, const float4 *sgc, int w4)
+    {
+        valid = ok;
+        if (!ok)
+            return;
+        const int4 r0 = srec[2 * r_], r1 = srec[2 * r_ + 1];
+        rp0 = r0.x;
+        deg = r0.y;
+        roff = (uint32_t)__mul24(r_, w4);
+        const int jg[4] = {r0.z, r0.w, r1.x, r1.y}; // batch-global ids; unused slots alias the row itself
+        if (MODE == GNNB_AGG_GCN || MODE == GNNB_AGG_SUM)
+            xi.v = agg_lds_ld4(sx_lane + roff);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            nbv[q].v = agg_lds_ld4(sxo + (uint32_t)__mul24(jg[q], w4));
+        if (MODE == GNNB_AGG_GCN) {
+            di = sdinv[r_];
+            const float4 g = sgc[r_]; // dinv_i dinv_j of the inline neighbours, 0 past the degree (k_gcn_coef)
+            c[0] = g.x, c[1] = g.y, c[2] = g.z, c[3] = g.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                c[q] = deg > q ? 1.0f : 0.0f;
+        }
+    }
+
+    // scol_o = LDS byte address of the stage's CSR slice minus e0 * 4; obase = the stage's first output row (+ column)
+    __device__ __forceinline__ void finish(uint32_t sxo, uint32_t sdo, uint32_t scol_o, int w4, char *__restrict__ obase, float eps)
+    {
+        if (!valid)
+            return;
+        V acc;
+        // (the first term initialises the sum: 0 + v c, as AggAcc starts from zero)
+        acc = vmul(nbv[0], V::splat(c[0]));
+        acc = vadd(acc, vmul(nbv[1], V::splat(c[1])));
+        acc = vadd(acc, vmul(nbv[2], V::splat(c[2])));
+        acc = vadd(acc, vmul(nbv[3], V::splat(c[3])));
+        for (int k = rp0 + 4; k < rp0 + deg; k++) { // degree > 4: the rest of the CSR row, from the stage's slice in LDS
+            const int j = *(agg_lds_i)(uintptr_t)(scol_o + (uint32_t)k * 4u);
+            V v;
+            v.v = agg_lds_ld4(sxo + (uint32_t)__mul24(j, w4));
+            const float cj = MODE == GNNB_AGG_GCN ? di * *(agg_lds_f)(uintptr_t)(sdo + (uint32_t)j * 4u) : 1.0f;
+            acc = vadd(acc, vmul(v, V::splat(cj)));
+        }
+        V o;
+        if (MODE == GNNB_AGG_GCN)
+            o = vadd(acc, vmul(xi, V::splat(di * di)));
+        else if (MODE == GNNB_AGG_SUM)
+            o = vadd(acc, vmul(xi, V::splat(1.0f + eps)));
+        else if (MODE == GNNB_AGG_MEAN)
+            o = deg > 0 ? vmul(acc, V::splat(1.0f / (float)deg)) : acc;
+        else
+            o = acc;
+        agg_store<NT>(o, reinterpret_cast<float *>(obase + roff));
+    }
+};
+
 // The same row straight from global memory (a graph larger than an LDS stage): neighbour rows are
 // L2-side gathers, the degree comes from the node record (row_ptr holds row STARTS only: dropped edges
 // leave gaps at the end of a graph's CSR segment, so row_ptr[v+1] - row_ptr[v] is not a degree).
@@ -239,10 +322,14 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
     const float *__restrict__ x, const float *__restrict__ selfq, float *__restrict__ out,
     const int4 *__restrict__ node_rec, const int32_t *__restrict__ col, const float *__restrict__ dinv,
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_edge, int num_tiles, int N, int E, int w,
-    int glog2, int cap, int ecap, int nslots, int slot_bytes, int slack, float eps, int tile_lo)
+    int glog2, int cap, int ecap, int nslots, int slot_bytes, int slack, float eps, int tile_lo,
+    const float4 *__restrict__ gcoef)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HASQ = MODE == GNNB_AGG_PNA, HASREC = MODE != GNNB_AGG_COPY, HASDINV = MODE == GNNB_AGG_GCN;
+    // GCN, float4 rows: the coefficients dinv_i dinv_j of the four inline neighbours come precomputed (k_gcn_coef: 0 for the
+    // unused slots), one 16-B LDS read per row instead of four normaliser reads, four products and four selects
+    constexpr bool HASGC = MODE == GNNB_AGG_GCN && VEC == 4;
     constexpr int KOUT = AggOut<MODE>::K;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -263,7 +350,8 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
     const int off_q = cap * w * 4;
     const int off_rec = off_q + (HASQ ? cap * w * 4 : 0);
     const int off_dinv = off_rec + cap * 32;
-    const int off_col = off_dinv + cap * 4; // the stage's CSR slice (rows of degree > 4 read it): ecap entries
+    const int off_gc = off_dinv + ((cap * 4 + 15) & ~15);
+    const int off_col = off_gc + (HASGC ? cap * 16 : 0); // the stage's CSR slice (rows of degree > 4 read it): ecap entries
     const int nvec = w / VEC;
     const int G = 1 << glog2;       // lanes per destination row
     const int groups = 64 >> glog2; // rows a wave reduces at once
@@ -322,6 +410,13 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
                 if (c + lane < rows_)
                     dma4_to_lds_u(dinv + nb_ + c + lane, sb + off_dinv + (size_t)c * 4);
         }
+        if (HASGC) {
+            const char *gg = reinterpret_cast<const char *>(gcoef + nb_);
+            const int gbytes = rows_ * 16;
+            for (int c = sw * 1024; c < gbytes; c += sn * 1024, ops++)
+                if (c + lane * 16 < gbytes)
+                    dma16_to_lds_u(gg + c + lane * 16, sb + off_gc + c);
+        }
         if (HASREC) { // (a tracked global read of col inside the reduction would drain this wave's whole pipeline)
             for (int c = sw * 64; c < ne_; c += sn * 64, ops++)
                 if (c + lane < ne_)
@@ -339,6 +434,30 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
         const float *sdinv = reinterpret_cast<const float *>(sb + off_dinv);
         const int32_t *scol = reinterpret_cast<const int32_t *>(sb + off_col) - e0_; // indexed by the CSR slot itself
         int nst = 0;
+        if (VEC == 4 && (MODE == GNNB_AGG_GCN || MODE == GNNB_AGG_SUM || MODE == GNNB_AGG_MEAN || MODE == GNNB_AGG_SIMPLE) && nvec <= G) {
+            // lean path (LdsRowF): one column pass (a lane group covers the row), two rows per lane group in flight
+            const int w4 = w * 4;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_vptr)sb;
+            const uint32_t sx_lane = lds0 + (uint32_t)gl * 16u;
+            const uint32_t sxo = sx_lane - (uint32_t)__mul24(nb_, w4);
+            const uint32_t sdo = lds0 + (uint32_t)off_dinv - (uint32_t)nb_ * 4u;
+            const uint32_t scol_o = lds0 + (uint32_t)off_col - (uint32_t)e0_ * 4u;
+            const float4 *sgc = reinterpret_cast<const float4 *>(sb + off_gc);
+            char *obase = reinterpret_cast<char *>(out + (size_t)nb_ * w) + gl * 16;
+            const bool lane_on = gl < nvec;
+            for (int rb = sw * 2 * groups; rb < rows_; rb += sn * 2 * groups) {
+                const bool has_b = rb + groups < rows_;
+                LdsRowF<MODE == GNNB_AGG_PNA || MODE == GNNB_AGG_LG || MODE == GNNB_AGG_COPY ? GNNB_AGG_SUM : MODE, NT> A, B;
+                A.begin(lane_on && rb + grp < rows_, rb + grp, srec, sxo, sx_lane, sdinv, sgc, w4);
+                if (has_b)
+                    B.begin(lane_on && rb + groups + grp < rows_, rb + groups + grp, srec, sxo, sx_lane, sdinv, sgc, w4);
+                A.finish(sxo, sdo, scol_o, w4, obase, eps);
+                if (has_b)
+                    B.finish(sxo, sdo, scol_o, w4, obase, eps);
+                nst += has_b ? 2 : 1;
+            }
+            return nst;
+        }
         for (int rb = sw * 2 * groups; rb < rows_; rb += sn * 2 * groups) {
             const bool has_b = rb + groups < rows_; // wave-uniform: the second row's store exists or not for the whole wave
             for (int f = gl; f < nvec; f += G) {
@@ -450,7 +569,8 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
     // per staged row: the row itself (PNA: p and q), its 32-B record, its normaliser, and 4 CSR entries (a stage
     // whose CSR slice is longer than 4 per row -- multigraphs, hubs -- is cut shorter by the planner)
     constexpr int ECAP_PER_ROW = 4;
-    const size_t per_row = (size_t)w * 4 * (MODE == GNNB_AGG_PNA ? 2 : 1) + (MODE != GNNB_AGG_COPY ? 32 + 4 + 4 * ECAP_PER_ROW : 0);
+    const size_t per_row = (size_t)w * 4 * (MODE == GNNB_AGG_PNA ? 2 : 1) + (MODE != GNNB_AGG_COPY ? 32 + 4 + 4 * ECAP_PER_ROW : 0) +
+                           (MODE == GNNB_AGG_GCN && VEC == 4 ? 16 : 0);
     const int wgs = std::max(o.agg_ring_wg_per_cu, 1);
     const size_t budget = (size_t)(o.agg_lds_kb > 0 ? std::min(std::max(o.agg_lds_kb, 8), 158) : 158 / wgs) * 1024;
     int ns = std::min(std::max(o.agg_ring_slots, 1), RING_MAX_SLOTS);
@@ -461,7 +581,7 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
     nw = std::min(std::max(nw, 1), 16);
     int cap = (int)((budget / ns) / per_row);
     cap = std::min(std::max(cap, 1), 4096);
-    const int slot_bytes = (int)((((size_t)cap * per_row) + 15) & ~(size_t)15);
+    const int slot_bytes = (int)((((size_t)cap * per_row) + 31) & ~(size_t)15); // (+ 16: the normalisers are padded to 16 B)
     const size_t lds = (size_t)ns * slot_bytes;
     // persistent: `wgs` workgroups per CU; fewer when the batch has fewer tiles than rings
     int grid = num_cus * wgs;
@@ -476,7 +596,7 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, x, selfq, out, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_edge, t.num_tiles, t.num_nodes, t.num_edges, w, glog2, cap,
-                           cap * ECAP_PER_ROW, ns, slot_bytes, std::max(t.tile_rows / 2, 1) + 2, eps, tile_lo);
+                           cap * ECAP_PER_ROW, ns, slot_bytes, std::max(t.tile_rows / 2, 1) + 2, eps, tile_lo, t.gcoef);
         return hipGetLastError();
     };
     if (o.agg_nt_store)
@@ -537,6 +657,30 @@ hipError_t launch_aggregate_edges(const BatchTables &t, const float *x, const fl
     else
         hipLaunchKernelGGL(k_aggregate_edges<1>, dim3(grid), dim3(WG), 0, s, x, eterm, out, t.node_rec, t.col, t.eid,
                            t.num_nodes, width, glog2, eps);
+    return hipGetLastError();
+}
+
+// GCN coefficients of the inline neighbours: gcoef[v] = dinv_v * {dinv_j0 .. dinv_j3}, 0 for the slots past the degree.
+// A derived table like dinv itself; written once per prepared batch in front of the first layer-wise GCN aggregate
+// (the LDS-resident stack kernels compute the same products in their P0 phase and do not use it).
+__global__ __launch_bounds__(WG) void k_gcn_coef(const int4 *__restrict__ node_rec, const float *__restrict__ dinv, int N,
+                                                 float4 *__restrict__ gcoef)
+{
+    const int v = blockIdx.x * WG + threadIdx.x;
+    if (v >= N)
+        return;
+    const int4 r0 = node_rec[2 * (size_t)v], r1 = node_rec[2 * (size_t)v + 1];
+    const int deg = r0.y;
+    const float di = dinv[v];
+    gcoef[v] = make_float4(deg > 0 ? di * dinv[r0.z] : 0.0f, deg > 1 ? di * dinv[r0.w] : 0.0f, deg > 2 ? di * dinv[r1.x] : 0.0f,
+                           deg > 3 ? di * dinv[r1.y] : 0.0f);
+}
+
+hipError_t launch_gcn_coef(const BatchTables &t, hipStream_t s)
+{
+    if (t.num_nodes <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_gcn_coef, dim3((t.num_nodes + WG - 1) / WG), dim3(WG), 0, s, t.node_rec, t.dinv, t.num_nodes, t.gcoef);
     return hipGetLastError();
 }
 
