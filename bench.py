@@ -507,14 +507,21 @@ def main():
     model = build_model(w)
     if args.roofline_only:
         batch = synthetic.make_batch(w["shape"], w["batch"], seed=0)
-        mg = int(np.diff(batch.node_ptr).max())
+        seg = None
+        if w.get("large_limit"):
+            from gnnbuilder_amd.batching import order_large_last
+            batch, _, seg = order_large_last(batch, w["large_limit"])
+        mg = int(np.diff(batch.node_ptr)[:(seg[0] if seg else batch.num_graphs)].max())
         cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=mg)
+        if seg:
+            cm.set_large_segment(*seg)
         bd = tuple(torch.from_numpy(a).to(dev) for a in (batch.x, batch.coo, batch.node_ptr, batch.edge_ptr))
         alg_bytes, agg = measure_aggregate_roofline(cm, bd, w["hidden"], dev, regimes=("hbm",))
         fused = measure_fused_stack(cm, bd, (int(batch.x.shape[1]), w["hidden"], w["hidden"], len(w["pools"])),
-                                    conv=w["conv"], layers=w["layers"]) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
-        print(json.dumps({"roofline_only": True, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"],
-                          "copy_same_launch_shape": agg.get("copy_same_launch_shape"), "fused_stack": fused}))
+                                    conv=w["conv"], layers=w["layers"], seg=seg) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
+        print(json.dumps({"roofline_only": True, "workload": args.workload, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"],
+                          "copy_same_launch_shape": agg.get("copy_same_launch_shape"), "fused_stack": fused,
+                          "stack_path": cm.last_path() if fused else None}))
         return
 
     if args.shard == "one-batch":

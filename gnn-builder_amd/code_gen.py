@@ -274,12 +274,13 @@ class Project:
         if proc.returncode != 0:
             print(proc.stdout.decode("utf-8"))
             print(proc.stderr.decode("utf-8"))
-            raise Exception(f"{self.name} - Testbench build failed.")
+            raise Exception(f"{self.name} - Testbench build failed.\n" + proc.stderr.decode("utf-8")[-2000:])
         proc = subprocess.run(["./result"], cwd=self.model_dir, capture_output=True)
         if proc.returncode != 0:
             print(proc.stdout.decode("utf-8"))
             print(proc.stderr.decode("utf-8"))
-            raise Exception(f"{self.name} - Testbench execution failed (return code {proc.returncode}).")
+            raise Exception(f"{self.name} - Testbench execution failed (return code {proc.returncode}).\n"
+                            + proc.stdout.decode("utf-8")[-1000:] + proc.stderr.decode("utf-8")[-2000:])
 
         def _read(key):
             fp = self.model_dir / "tb_data" / f"{key}.txt"

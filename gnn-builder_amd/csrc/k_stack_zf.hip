@@ -55,7 +55,6 @@ namespace gnnb {
 // kernels of the other batches in flight; 0 = two workgroups of 8 waves per CU, stages of up to 96 rows (158 KB: nothing
 // co-resides).  Solo launches are ~2 us faster in shape 0 (the two workgroups hide each other's latencies), the
 // three-stream pipeline of bench.py is faster in shape 1 (78.6 vs 75.2 M graphs/s).
-static constexpr int ZF_TCAP = 128;          // tile-table entries a workgroup keeps in LDS
 #ifndef ZF_PRIO
 #define ZF_PRIO 2
 #endif
@@ -100,7 +99,7 @@ __device__ __forceinline__ void zf_mma(const float *__restrict__ A, int lda, con
 }
 
 struct ZfStage {
-    int ta, tb, nb, rows, ga, gb, e0, ne;
+    int ok, chunk, nb, rows, ga, gb, e0, ne; // ok = 0: no stage (the hand-out is exhausted)
 };
 
 // REGISTER BUDGET: keep this kernel at <= 104 VGPRs (`make resource-usage`).  Four waves per SIMD then leave a 96-register
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 )
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ZF_CAP = 16 * ZF_UNITS, G2_NW = NW, G2_WG = NW * 64, G2_TCAP = ZF_TCAP;
+    constexpr int ZF_CAP = 16 * ZF_UNITS, G2_NW = NW, G2_WG = NW * 64;
     constexpr int GMAX = ZF_CAP <= 96 ? 64 : 128; // graph boundaries of a stage kept in LDS (more: empty graphs piling up)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- LDS carve (bytes, every region 16-B aligned; LDS pointers are always derived arithmetically from `smem`:
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     //   REC    [CAP] x 48 B                  TWO buffers (P0 of the next stage writes while P1 of this one reads)
     //   SCOL   [ECAP] int32                  TWO buffers: the stage's slice of the CSR `col` array, for rows of degree > 4
     //                                        (a tracked global read there costs a full memory round trip per neighbour)
-    //   stile, sgraph, sedge                 the workgroup's run of the tile tables
+    //   SB1, SB0, SPLAN                      biases, the plan of the stage after next
     constexpr int LD0 = 16 * KQ0; // A0 row: F0 values zero-padded to whole 16-wide MFMA k blocks
     const int xs_b = ((ZF_CAP * f0 * 4) + 15) & ~15;
     const int rows_b = xs_b + ZF_CAP * 32;
@@ -151,10 +150,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     char *RECb = reinterpret_cast<char *>(H) + ZF_CAP * ldhb;
     constexpr int ECAP = ZF_CAP <= 96 ? 512 : 1024;
     char *SCOLb = RECb + 2 * rec_b;
-    int32_t *stile = reinterpret_cast<int32_t *>(SCOLb + 2 * ECAP * 4);
-    int32_t *sgraph = stile + (G2_TCAP + 1);
-    int32_t *sedge = sgraph + (G2_TCAP + 1);
-    float *SB1 = reinterpret_cast<float *>(sedge + (G2_TCAP + 1) + 1); // b1 zero-padded to 128 floats (3 x 129 table entries + 1: 16-B aligned)
+    float *SB1 = reinterpret_cast<float *>(SCOLb + 2 * ECAP * 4); // b1 zero-padded to 128 floats
     int4 *SPLAN = reinterpret_cast<int4 *>(SB1 + 128);                 // the stage after next, planned by ONE wave (2 x int4)
     float *SB0 = reinterpret_cast<float *>(SPLAN + 2);                 // b0 zero-padded to 128 floats
 
@@ -168,10 +164,27 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     if (dbg & 32)
         return; // (launch overhead alone)
 #endif
+    // ---- the workgroup's run of node tiles: equal tile counts (= equal rows up to one graph).  (A ticket hand-out of
+    // fixed-size chunks was built and measured: a chunk must fit a stage whatever its last graph's overhang, i.e. 64
+    // nominal rows of a 96-row stage, which turns two stages per workgroup into 2.25 -- three rounds, 55 us instead of 44.
+    // The planner below uses the capacity adaptively instead: what one stage's overhang takes the other gives.)
     const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
     const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
     if (t1 <= t0)
         return;
+    // Every wave keeps the run's tile-table entries in REGISTERS (lane l: tile t0 + l; the launcher keeps runs below 64
+    // tiles) and plans with v_readlane: no LDS copy of the tables, no barrier in front of the first DMA.
+    // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
+    int tf, tg, te;
+    {
+        const int ti = min(t0 + min(lane, t1 - t0), num_tiles);
+        tf = min(max(tile_first[ti], 0), N);
+        tg = min(max(tile_graph[ti], 0), num_graphs);
+        te = min(max(tile_edge[ti], 0), E);
+    }
+    auto T_first = [&](int t) { return __builtin_amdgcn_readlane(tf, __builtin_amdgcn_readfirstlane(t - t0)); };
+    auto T_graph = [&](int t) { return __builtin_amdgcn_readlane(tg, __builtin_amdgcn_readfirstlane(t - t0)); };
+    auto T_edge = [&](int t) { return __builtin_amdgcn_readlane(te, __builtin_amdgcn_readfirstlane(t - t0)); };
     // ---- wave roles: layer L has ncs_L = pow2ceil(h_L / 16) column slices of 16 and nrg_L = 8 / ncs_L row groups;
     // wave w owns slice (w mod ncs) for the units rg, rg + nrg, ... with rg = w / ncs
     int cs0l = 0, cs1l = 0;
@@ -181,12 +194,6 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         cs1l++; // h <= 128 -> <= 3
     const int nrg0 = G2_NW >> cs0l, nrg1 = G2_NW >> cs1l;
 
-    // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
-    for (int i = tid; i <= t1 - t0; i += G2_WG) {
-        stile[i] = min(max(tile_first[t0 + i], 0), N);
-        sgraph[i] = min(max(tile_graph[t0 + i], 0), num_graphs);
-        sedge[i] = min(max(tile_edge[t0 + i], 0), E);
-    }
     if (tid < 128) {
         SB1[tid] = (b1 && tid < h1) ? b1[tid] : 0.0f;
         SB0[tid] = (b0 && tid < h0) ? b0[tid] : 0.0f;
@@ -198,24 +205,19 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     // leave more than the remaining stages can hold are only taken when there is no other (then the largest).
     auto plan = [&](int ta) {
         ZfStage st;
-        st.ta = ta;
-        st.tb = ta;
-        st.nb = 0;
-        st.rows = 0;
-        st.ga = 0;
-        st.gb = 0;
-        st.e0 = 0;
-        st.ne = 0;
-        if (ta >= t1)
+        st.ok = ta < t1;
+        st.chunk = ta;
+        st.nb = st.rows = st.ga = st.gb = st.e0 = st.ne = 0;
+        if (!st.ok)
             return st;
-        st.nb = stile[ta - t0];
-        const int rrem = stile[t1 - t0] - st.nb; // (re-read per call: kept in a register across the stage loop it is spilled)
+        st.nb = T_first(ta);
+        const int rrem = T_first(t1) - st.nb;
         const int krem = max((rrem + ZF_CAP - 1) / ZF_CAP, 1);
         const int target = (rrem + krem - 1) / krem;
         const int rmin = rrem - (krem - 1) * ZF_CAP;
         int tb = ta + 1, bestd = 1 << 30;
         for (int c = ta + 1; c <= t1; c++) {
-            const int r = stile[c - t0] - st.nb;
+            const int r = T_first(c) - st.nb;
             if (r > ZF_CAP)
                 break;
             const int d = r < rmin ? 4096 + (rmin - r) : (r > target ? r - target : target - r);
@@ -224,19 +226,19 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                 tb = c;
             }
         }
-        st.tb = tb;
-        st.rows = max(min(stile[tb - t0] - st.nb, ZF_CAP), 0); // (> CAP only if the max_graph_nodes promise is broken)
-        st.ga = sgraph[ta - t0];
+        st.chunk = tb; // (the next stage starts here)
+        st.rows = max(min(T_first(tb) - st.nb, ZF_CAP), 0); // (> CAP only if the max_graph_nodes promise is broken)
+        st.ga = T_graph(ta);
         // (empty graphs after the last node belong to the last stage: when N is a multiple of the tile
         // size the first of them already owns tile_graph[num_tiles])
-        st.gb = max(tb == num_tiles ? num_graphs : sgraph[tb - t0], st.ga);
-        st.e0 = sedge[ta - t0];
-        st.ne = max(sedge[tb - t0] - st.e0, 0);
+        st.gb = max(tb == num_tiles ? num_graphs : T_graph(tb), st.ga);
+        st.e0 = T_edge(ta);
+        st.ne = max(T_edge(tb) - st.e0, 0);
         return st;
     };
     // the stage's rows (x, node records) -> ROWS
     auto issue_rows = [&](const ZfStage &st, int bb, int lane, int wave) {
-        if (st.ta >= t1)
+        if (!st.ok)
             return;
         dma_dwords_u(x + (size_t)st.nb * f0, smem, st.rows * f0, wave, lane, G2_NW);
         if (st.ne <= ECAP) // (a stage with more edges -- hubs, multigraphs -- reads `col` from global memory)
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     };
     // its normalisers and graph boundaries -> SMALL[bb]
     auto issue_small = [&](const ZfStage &st, int bb, int lane, int wave) {
-        if (st.ta >= t1)
+        if (!st.ok)
             return;
         // (a stage may have NO rows and still own graphs: empty graphs behind a graph that ends on the
         // tile edge -- their boundaries are still needed by the pooling)
@@ -270,9 +272,19 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     };
 
     // the first stage's inputs start their way to LDS before the weights are fetched (both are waited for below)
+    // (every wave plans the first stage for itself from its registers)
     ZfStage cur = plan(t0);
     issue_small(cur, 0, lane, wave);
     issue_rows(cur, 0, lane, wave);
+    // the second stage: planned by the last wave, handed over through LDS behind the barrier that closes the prologue's P0
+    auto publish = [&](const ZfStage &pn, int lane) {
+        if (lane == 0) {
+            SPLAN[0] = make_int4(pn.ok, pn.chunk, pn.nb, pn.rows);
+            SPLAN[1] = make_int4(pn.ga, pn.gb, pn.e0, pn.ne);
+        }
+    };
+    if (wave == G2_NW - 1)
+        publish(plan(cur.chunk), lane);
 
     // (the weights are requested HERE, behind the first stage's DMA: in front of the tile-table loads they made the
     // workgroup's first barrier wait for 128 KB of weight fragments; now they land beside the DMA round trip and P0)
@@ -418,8 +430,21 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #pragma unroll
     for (int q = 0; q < KQ1 * 4; q++)
         asm volatile("" : "+v"(w1r[q]));
-    ZfStage nxt = plan(cur.tb);
     g2_barrier();
+    auto take_plan = [&]() {
+        ZfStage st;
+        const int4 q0 = SPLAN[0], q1 = SPLAN[1];
+        st.ok = __builtin_amdgcn_readfirstlane(q0.x);
+        st.chunk = __builtin_amdgcn_readfirstlane(q0.y);
+        st.nb = __builtin_amdgcn_readfirstlane(q0.z);
+        st.rows = __builtin_amdgcn_readfirstlane(q0.w);
+        st.ga = __builtin_amdgcn_readfirstlane(q1.x);
+        st.gb = __builtin_amdgcn_readfirstlane(q1.y);
+        st.e0 = __builtin_amdgcn_readfirstlane(q1.z);
+        st.ne = __builtin_amdgcn_readfirstlane(q1.w);
+        return st;
+    };
+    ZfStage nxt = take_plan();
     ZF_PT(0);
 
     // Wave priority.  Two workgroups share a CU and fp32 MFMA and VALU instructions share one issue port: a wave in a
@@ -430,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     // whichever workgroup is in M1, and the other one's narrow phases cost what their instructions cost.
     __builtin_amdgcn_s_setprio(ZF_PRIO);
     int b = 0;
-    while (cur.ta < t1) {
+    while (cur.ok) {
         // The thread index is re-made OPAQUE every stage and every per-lane quantity is derived from it again
         // (otherwise the compiler hoists dozens of loop-invariant LDS offsets out of the stage loop and spills them)
         int tv = tid;
@@ -730,32 +755,17 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 
         // ---- P0 of the NEXT stage (its rows landed before the last barrier but one), starting on the first wave that
         // had no graph to reduce
-        if (nxt.ta < t1 && ZF_ON(1))
+        if (nxt.ok && ZF_ON(1))
             phase_p0(nxt, b ^ 1, tv, (ngr << csl) & (G2_NW - 1));
         ZF_PT(8);
-        // the stage after next: planned by ONE wave (the plan is ~150 uniform VALU / LDS instructions -- executed by all
-        // sixteen waves it was a tenth of the kernel's vector instructions) and handed over through LDS
-        if (wv == G2_NW - 1) {
-            const ZfStage pn = plan(nxt.tb);
-            if ((tv & 63) == 0) {
-                SPLAN[0] = make_int4(pn.ta, pn.tb, pn.nb, pn.rows);
-                SPLAN[1] = make_int4(pn.ga, pn.gb, pn.e0, pn.ne);
-            }
-        }
+        // the stage after next: planned by ONE wave (executed by all sixteen the plan was a tenth of the kernel's vector
+        // instructions), handed over through LDS
+        if (wv == G2_NW - 1)
+            publish(plan(nxt.chunk), tv & 63);
         cur = nxt;
         b ^= 1;
         g2_barrier(); // A0 / REC of the next stage complete; everybody is done with Z
-        {
-            const int4 q0 = SPLAN[0], q1 = SPLAN[1];
-            nxt.ta = __builtin_amdgcn_readfirstlane(q0.x);
-            nxt.tb = __builtin_amdgcn_readfirstlane(q0.y);
-            nxt.nb = __builtin_amdgcn_readfirstlane(q0.z);
-            nxt.rows = __builtin_amdgcn_readfirstlane(q0.w);
-            nxt.ga = __builtin_amdgcn_readfirstlane(q1.x);
-            nxt.gb = __builtin_amdgcn_readfirstlane(q1.y);
-            nxt.e0 = __builtin_amdgcn_readfirstlane(q1.z);
-            nxt.ne = __builtin_amdgcn_readfirstlane(q1.w);
-        }
+        nxt = take_plan();
         ZF_PT(9);
 #ifdef GNNB_PROBE
         nst++;
@@ -770,7 +780,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             o[2 + i] = pt[i];
         o[13] = clock64() - pt0;
         o[14] = (unsigned long long)nst;
-        o[15] = (unsigned long long)(stile[t1 - t0] - stile[0]) | ((unsigned long long)(sgraph[t1 - t0] - sgraph[0]) << 32); // rows | graphs
+        o[15] = 0;
     }
 #endif
 }
@@ -785,13 +795,10 @@ static bool zf_wide_shape(int f0, int promise)
     return f0 <= 16 && (sh == 1 || (sh == 2 && promise + 3 > 96)); // (+ 3: the finest node tiles are 4 rows)
 }
 int zf_stage_rows(int f0, int promise) { return zf_wide_shape(f0, promise) ? 176 : 96; }
+static constexpr int ZF_TCAP = 62; // tiles per workgroup: the run's table lives in one register per lane (+ its end)
 long gcn2_zf_tile_capacity(int f0, int promise)
 {
-    int devid = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
-        cus = prop.multiProcessorCount;
-    return (long)(ZF_TCAP - 2) * (zf_wide_shape(f0, promise) ? 1 : 2) * cus;
+    return (long)ZF_TCAP * (zf_wide_shape(f0, promise) ? 1 : 2) * device_cu_count();
 }
 
 #ifdef GNNB_ZF_ABLATE
@@ -847,7 +854,8 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
     const int ldh = (h0 > h1 ? h0 : h1) + 4;
     const int ecap = cap <= 96 ? 512 : 1024;
     const size_t lds = (size_t)rows_b + 2 * (size_t)small_b + (size_t)cap * 16 * kq0 * 4 + (size_t)cap * ldh * 4 +
-                       2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 3 * (size_t)(ZF_TCAP + 1) * 4 + 4 + 512 + 32 + 512;
+                       2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 512 + 32 + 512;
+
     if (lds > 160 * 1024)
         return hipErrorNotSupported;
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
@@ -885,7 +893,8 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
         long long grid = (long long)cus * blocks;
         if (grid > t.num_tiles)
             grid = t.num_tiles;
-        const long long min_grid = ((long long)t.num_tiles + ZF_TCAP - 2) / (ZF_TCAP - 1);
+        // a workgroup keeps its run of the tile table in one register per lane: at most ZF_TCAP tiles per workgroup
+        const long long min_grid = ((long long)t.num_tiles + ZF_TCAP - 1) / ZF_TCAP;
         if (grid < min_grid) {
             rc = hipErrorNotSupported;
             return;
