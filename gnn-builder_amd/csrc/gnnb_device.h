@@ -51,6 +51,10 @@ static int device_cu_count()
 }
 
 static constexpr int WG = 256; // 4 wavefronts
+// wave priority of the small kernels that co-run with another batch's conv-stack kernel (graph prep, readout, k_conv_rows)
+#ifndef GNNB_GUEST_PRIO
+#define GNNB_GUEST_PRIO 3
+#endif
 
 // compile-time integer tag (generic lambdas dispatch on it)
 template <int V>

@@ -92,7 +92,7 @@ template <int ACT>
 __global__ __launch_bounds__(CR_THREADS, 5) void k_conv_rows(ConvRowsArgs p)
 {
     __shared__ __attribute__((aligned(16))) float T[CR_ROWS * CR_LD];
-    __builtin_amdgcn_s_setprio(3); // (co-runs with the conv-stack kernel of the rest of the batch: see k_graph_prep)
+    __builtin_amdgcn_s_setprio(GNNB_GUEST_PRIO); // (co-runs with the conv-stack kernel of the rest of the batch: see k_graph_prep)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int r0 = p.row_lo + blockIdx.x * CR_ROWS;

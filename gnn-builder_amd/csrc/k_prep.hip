@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     // another batch (one wave slot per SIMD is left over there) and sits on its own stream's critical path -- 37-53 us
     // instead of 7 when it queues behind sixteen MFMA-issuing waves per CU.  It is a few hundred instructions per wave;
     // letting them issue first costs the big kernel nothing measurable (C2 step 55.5 -> 54.0 us).
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(GNNB_GUEST_PRIO);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = blockIdx.x * (WG / 64) + wave;

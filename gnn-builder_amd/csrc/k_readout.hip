@@ -381,7 +381,7 @@ __global__ __launch_bounds__(HS_THREADS, 5) void k_head_small(const float *__res
                                                              float *__restrict__ out, int ldact)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __builtin_amdgcn_s_setprio(3); // (co-runs with the next batch's conv-stack kernel: see k_graph_prep)
+    __builtin_amdgcn_s_setprio(GNNB_GUEST_PRIO); // (co-runs with the next batch's conv-stack kernel: see k_graph_prep)
     float *sact = reinterpret_cast<float *>(smem); // [2][16][ldact]: ldact = widest hidden layer + 4 (padded rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;

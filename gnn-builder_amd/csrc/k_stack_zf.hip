@@ -153,6 +153,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     float *SB1 = reinterpret_cast<float *>(SCOLb + 2 * ECAP * 4); // b1 zero-padded to 128 floats
     int4 *SPLAN = reinterpret_cast<int4 *>(SB1 + 128);                 // the stage after next, planned by ONE wave (2 x int4)
     float *SB0 = reinterpret_cast<float *>(SPLAN + 2);                 // b0 zero-padded to 128 floats
+    int *STAB = reinterpret_cast<int *>(SB0 + 128);                    // the planner wave's copy of the run's tile-table entries (3 x 64)
 
 #ifdef GNNB_ZF_ABLATE
     if (dbg_span && threadIdx.x == 0)
@@ -172,8 +173,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
     if (t1 <= t0)
         return;
-    // Every wave keeps the run's tile-table entries in REGISTERS (lane l: tile t0 + l; the launcher keeps runs below 64
-    // tiles) and plans with v_readlane: no LDS copy of the tables, no barrier in front of the first DMA.
+    // Every wave fetches the run's tile-table entries into REGISTERS (lane l: tile t0 + l; the launcher keeps runs below
+    // 64 tiles) and plans the first stage with v_readlane: no LDS copy to wait for, no barrier in front of the first DMA.
+    // The registers are short-lived (holding them through the stage loop cost 8 VGPRs and with them the 96-register wave
+    // slot the other batches' kernels run in): the planner wave parks its copy in LDS and reloads it where it plans.
     // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
     int tf, tg, te;
     {
@@ -182,9 +185,11 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         tg = min(max(tile_graph[ti], 0), num_graphs);
         te = min(max(tile_edge[ti], 0), E);
     }
-    auto T_first = [&](int t) { return __builtin_amdgcn_readlane(tf, __builtin_amdgcn_readfirstlane(t - t0)); };
-    auto T_graph = [&](int t) { return __builtin_amdgcn_readlane(tg, __builtin_amdgcn_readfirstlane(t - t0)); };
-    auto T_edge = [&](int t) { return __builtin_amdgcn_readlane(te, __builtin_amdgcn_readfirstlane(t - t0)); };
+    if (wave == NW - 1) {
+        STAB[lane] = tf;
+        STAB[64 + lane] = tg;
+        STAB[128 + lane] = te;
+    }
     // ---- wave roles: layer L has ncs_L = pow2ceil(h_L / 16) column slices of 16 and nrg_L = 8 / ncs_L row groups;
     // wave w owns slice (w mod ncs) for the units rg, rg + nrg, ... with rg = w / ncs
     int cs0l = 0, cs1l = 0;
@@ -203,7 +208,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     // ---- balanced stage plan: the rows that are left are cut into the fewest stages that can hold them, of EQUAL
     // size, at tile (= graph) boundaries.  A stage takes the boundary closest to its share; boundaries that would
     // leave more than the remaining stages can hold are only taken when there is no other (then the largest).
-    auto plan = [&](int ta) {
+    auto plan = [&](int ta, int tf, int tg, int te) {
+        auto T_first = [&](int t) { return __builtin_amdgcn_readlane(tf, __builtin_amdgcn_readfirstlane(t - t0)); };
+        auto T_graph = [&](int t) { return __builtin_amdgcn_readlane(tg, __builtin_amdgcn_readfirstlane(t - t0)); };
+        auto T_edge = [&](int t) { return __builtin_amdgcn_readlane(te, __builtin_amdgcn_readfirstlane(t - t0)); };
         ZfStage st;
         st.ok = ta < t1;
         st.chunk = ta;
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 
     // the first stage's inputs start their way to LDS before the weights are fetched (both are waited for below)
     // (every wave plans the first stage for itself from its registers)
-    ZfStage cur = plan(t0);
+    ZfStage cur = plan(t0, tf, tg, te);
     issue_small(cur, 0, lane, wave);
     issue_rows(cur, 0, lane, wave);
     // the second stage: planned by the last wave, handed over through LDS behind the barrier that closes the prologue's P0
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         }
     };
     if (wave == G2_NW - 1)
-        publish(plan(cur.chunk), lane);
+        publish(plan(cur.chunk, tf, tg, te), lane);
 
     // (the weights are requested HERE, behind the first stage's DMA: in front of the tile-table loads they made the
     // workgroup's first barrier wait for 128 KB of weight fragments; now they land beside the DMA round trip and P0)
@@ -761,7 +769,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         // the stage after next: planned by ONE wave (executed by all sixteen the plan was a tenth of the kernel's vector
         // instructions), handed over through LDS
         if (wv == G2_NW - 1)
-            publish(plan(nxt.chunk), tv & 63);
+            publish(plan(nxt.chunk, STAB[tv & 63], STAB[64 + (tv & 63)], STAB[128 + (tv & 63)]), tv & 63);
         cur = nxt;
         b ^= 1;
         g2_barrier(); // A0 / REC of the next stage complete; everybody is done with Z
@@ -854,7 +862,7 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
     const int ldh = (h0 > h1 ? h0 : h1) + 4;
     const int ecap = cap <= 96 ? 512 : 1024;
     const size_t lds = (size_t)rows_b + 2 * (size_t)small_b + (size_t)cap * 16 * kq0 * 4 + (size_t)cap * ldh * 4 +
-                       2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 512 + 32 + 512;
+                       2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 512 + 32 + 512 + 768;
 
     if (lds > 160 * 1024)
         return hipErrorNotSupported;

@@ -2,7 +2,10 @@
 # Collect the round's rocprofv3 evidence on a GPU box (run through gpurun); outputs under gpurun_out/prof/.
 #   tools/profile_r.sh [workloads ...]      (default: c2 c3 c3t c4 c5)
 # Per workload w:
-#   bench_$w/     rocprofv3 --kernel-trace --stats of `python3 bench.py --workload w --steps 100` (+ its JSON line)
+#   plain_$w.log  `python3 bench.py --workload w --steps 100` WITHOUT the profiler: the JSON line that is kept (under the
+#                 profiler the back-to-back HIP-event loops of the roofline legs run up to 2x slower -- its per-dispatch
+#                 instrumentation -- so the line printed there is not a measurement of them)
+#   bench_$w/     rocprofv3 --kernel-trace --stats of the same command: the per-kernel table
 #   roofline_$w/  the same of `bench.py --workload w --roofline-only` (HBM-regime gather-aggregate loop, its copy
 #                 calibration, the conv-stack loop where the workload has one)
 #   pmc_$w_*/     one --pmc pass per counter group over the roofline-only command (counters are never collected together
@@ -16,6 +19,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 WL=${@:-c2 c3 c3t c4 c5}
 for w in $WL; do
   extra=""; [ "$w" != "c2" ] && extra="--no-cpu-baseline"
+  python3 bench.py --workload $w --steps 100 $extra > "$OUT/plain_$w.log" 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_$w" -o bench -- python3 bench.py --workload $w --steps 100 $extra > "$OUT/bench_$w.log" 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/roofline_$w" -o roofline -- python3 bench.py --workload $w --roofline-only > "$OUT/roofline_$w.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_${w}_fetch" -o fetch -- python3 bench.py --workload $w --roofline-only > "$OUT/pmc_${w}_fetch.log" 2>&1
@@ -31,4 +35,4 @@ done
 # keep the merge small: the per-dispatch traces are not needed once the stats exist
 find "$OUT" -name "*kernel_trace.csv" -delete
 find "$OUT" -name "*.csv" | xargs ls -la | head -60
-tail -c 400 "$OUT"/bench_*.log
+tail -c 400 "$OUT"/plain_*.log

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 CSVs that tools/profile_r.sh leaves under gpurun_out/prof/ into the small tracked summaries under
 profiles/ (usage: summarize_profile.py [gpurun_out/prof] [tag]).  Per workload w:
-  <tag>_<w>_bench_kernel_stats.csv     per-kernel stats of `bench.py --workload w --steps 100` (+ <tag>_<w>_bench.json, its line)
+  <tag>_<w>_bench_kernel_stats.csv     per-kernel stats of `bench.py --workload w --steps 100` under rocprofv3
+  <tag>_<w>_bench.json                 the JSON line of the same command run WITHOUT the profiler (profile_r.sh says why)
   <tag>_<w>_roofline_kernel_stats.csv  ... of `bench.py --workload w --roofline-only`
   <tag>_<w>_aggregate_pmc.json         HBM traffic per launch of the GCN gather-aggregate kernel at this workload's width
                                        (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, as MI355X_MICROARCH.md's HBM section prescribes)
@@ -66,7 +67,8 @@ for wdir in sorted(src.glob("bench_*")):
     stats = list(wdir.rglob("bench_kernel_stats.csv"))
     if stats:
         kernel_stats(stats[0], dst / f"{tag}_{w}_bench_kernel_stats.csv", f"python3 bench.py --workload {w} --steps 100  (N=1)")
-    lines = [l for l in (src / f"bench_{w}.log").read_text().splitlines() if l.startswith("{")]
+    plain = src / f"plain_{w}.log"
+    lines = [l for l in plain.read_text().splitlines() if l.startswith("{")] if plain.exists() else []
     if lines:
         (dst / f"{tag}_{w}_bench.json").write_text(json.dumps(json.loads(lines[-1]), indent=1) + "\n")
     rl = src / f"roofline_{w}.log"
