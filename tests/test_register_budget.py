@@ -1,0 +1,57 @@
+"""Register budgets the pipeline depends on, read from the BUILT library's code-object metadata (no GPU, no recompile).
+
+The conv-stack kernel k_gcn2_zf runs four waves per SIMD; at <= 104 VGPRs they leave one 96-register wave slot per SIMD, and
+that slot is where graph prep and the readout of the other batches in flight run (at 109 registers the
+three-stream step went from 52 to 58 us without any test noticing)."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB = ROOT / "gnn-builder_amd" / "libgnnb_hip.so"
+LLVM = Path("/opt/rocm/lib/llvm/bin")
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def kernel_registers(tmp_path):
+    """{mangled kernel name: (vgprs, agprs)} over every device code object bundled into the library."""
+    fat = tmp_path / "fat.bin"
+    subprocess.run([str(LLVM / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(LIB), str(tmp_path / "unused.so")],
+                   check=True, capture_output=True)
+    data = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), data)]
+    out = {}
+    for i, a in enumerate(starts):
+        blob = tmp_path / f"bundle{i}.bin"
+        blob.write_bytes(data[a:starts[i + 1] if i + 1 < len(starts) else len(data)])
+        co = tmp_path / f"dev{i}.co"
+        r = subprocess.run([str(LLVM / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={blob}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True)
+        if r.returncode != 0 or not co.exists() or co.stat().st_size == 0:
+            continue
+        notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        for entry in notes.split("\n  - ")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", entry)
+            vg = re.search(r"\.vgpr_count:\s+(\d+)", entry)
+            ag = re.search(r"\.agpr_count:\s+(\d+)", entry)
+            if name and vg:
+                out[name.group(1)] = (int(vg.group(1)), int(ag.group(1)) if ag else 0)
+    return out
+
+
+@pytest.mark.skipif(not LIB.exists() or shutil.which(str(LLVM / "llvm-readelf")) is None, reason="library or LLVM tools missing")
+def test_kernels_that_share_a_cu_keep_their_register_budgets(tmp_path):
+    regs = kernel_registers(tmp_path)
+    # the BASELINE model family: ReLU (ACT 0), input width <= 16 (KQ0 1).  (Widths of 17 .. 32 hold a second A0 fragment set
+    # -- 110 registers --, GELU / sigmoid / tanh need 105 .. 107: no co-residency promised there)
+    zf = {k: v for k, v in regs.items() if re.search(r"k_gcn2_zfILi0ELi1E", k)}
+    assert len(zf) >= 6, f"k_gcn2_zf instantiations not found among {len(regs)} kernels"
+    for k, (v, a) in zf.items():
+        assert v + a <= 104, f"{k}: {v} VGPRs + {a} AGPRs > 104 -- closes the 96-register slot beside four waves per SIMD"
+    guests = {k: v for k, v in regs.items() if "k_graph_prep" in k or "k_head_small" in k or "k_conv_rows" in k}
+    assert guests
+    for k, (v, a) in guests.items():
+        assert v + a <= 96, f"{k}: {v} + {a} registers do not fit the slot the conv-stack kernel leaves"
