@@ -439,8 +439,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--repeats", type=int, default=5,
-                    help="the timed region of K steps is run this many times; value = the median repeat")
+    ap.add_argument("--repeats", type=int, default=11,
+                    help="the timed region of K steps is run this many times; value = the median repeat (the first two or "
+                         "three regions after start-up run ~5 %% slower -- clocks, caches -- and a 20-step region is only a "
+                         "millisecond, so five repeats put the median ON that ramp; every repeat is in the line)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches rotated per rank")
     ap.add_argument("--streams", type=int, default=3,

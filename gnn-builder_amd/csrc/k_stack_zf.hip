@@ -164,6 +164,17 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     } span_end{dbg_span};
     if (dbg & 32)
         return; // (launch overhead alone)
+    // de-phasing experiment: bits 8..15 = delay in units of 0.25 us for half of the workgroups, bits 16..17 = which half
+    // (0: the second half of the grid, 1: odd block ids, 2: odd groups of eight, 3: odd groups of 256/8)
+    if ((dbg >> 8) & 255) {
+        const int sel = (dbg >> 16) & 3, b_ = blockIdx.x;
+        const bool mine = sel == 0 ? b_ >= (int)gridDim.x / 2 : (sel == 1 ? (b_ & 1) : (sel == 2 ? ((b_ >> 3) & 1) : ((b_ >> 8) & 1)));
+        if (mine) {
+            const unsigned long long t_ = wall_clock64(), dt = 25ull * ((dbg >> 8) & 255);
+            while (wall_clock64() - t_ < dt)
+                __builtin_amdgcn_s_sleep(16);
+        }
+    }
 #endif
     // ---- the workgroup's run of node tiles: equal tile counts (= equal rows up to one graph).  (A ticket hand-out of
     // fixed-size chunks was built and measured: a chunk must fit a stage whatever its last graph's overhang, i.e. 64
