@@ -877,6 +877,12 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
 
     if (lds > 160 * 1024)
         return hipErrorNotSupported;
+#ifdef GNNB_ZF_ABLATE
+    // development: GNNB_ZF_ONE=1 asks for > 80 KB of LDS so that only ONE 8-wave workgroup fits a CU (does the MFMA phase
+    // of two waves per SIMD saturate the matrix pipe on its own?)
+    const size_t lds_req = getenv("GNNB_ZF_ONE") && atoi(getenv("GNNB_ZF_ONE")) ? std::max(lds, (size_t)96 * 1024) : lds;
+#define lds lds_req
+#endif
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
     hipError_t rc = hipErrorNotSupported;
     auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag) {
@@ -952,5 +958,8 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
 #endif
     return rc;
 }
+#ifdef GNNB_ZF_ABLATE
+#undef lds
+#endif
 
 } // namespace gnnb

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the fused conv-stack kernel (GCN / GIN, any depth) against the oracle on one GPU.
-    python tests/fuzz_fused.py [cases] [seed]      (lives under tests/: it uses the oracle, which is test infrastructure)
+    python tests/fuzz_fused.py [cases] [seed] [zf]  (lives under tests/: it uses the oracle, which is test infrastructure)
+With a third argument "zf": only 2-layer GCN models (k_gcn2_zf), promise 4..169, the stage shape (zf_shape 0 / 1 / 2) drawn per
+case, and the path the workspace reports is asserted.
 Random model shapes (depth 2..6, width 32 / 64 / 128, F_in 1..32, activation, skip, pool order), random multigraph
 batches (1..300 graphs of 0..promise nodes, promise 4..61: empty graphs, isolated nodes, self loops, duplicate edges, hubs)
 with the promise exactly met by at least one graph.  Prints the worst error; exits non-zero on a mismatch or when the
@@ -21,11 +23,12 @@ from oracle import oracle as O  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ZF = len(sys.argv) > 3 and sys.argv[3] == "zf"
 dev = torch.device("cuda:0")
 worst = 0.0
 for it in range(cases):
-    conv = rng.choice(["gcn", "gin"])
-    L = int(rng.integers(2, 7))
+    conv = "gcn" if ZF else rng.choice(["gcn", "gin"])
+    L = 2 if ZF else int(rng.integers(2, 7))
     h = int(rng.choice([32, 64, 128]))
     out = h if conv == "gin" else int(rng.choice([h, 4 * int(rng.integers(1, 33))]))
     fin = int(rng.integers(1, 33))
@@ -39,7 +42,12 @@ for it in range(cases):
         for c in model.gnn_convs:
             c.eps = eps
             c.conv.eps.fill_(eps)
-    promise = int(rng.integers(4, 62))
+    promise = int(rng.integers(4, 170 if ZF else 62))
+    shape = int(rng.integers(0, 3))
+    if ZF:
+        runtime.set_option("zf_shape", shape)
+        if shape == 0 or fin > 16:
+            promise = min(promise, 89)  # the 96-row shape (and every input wider than 16) holds graphs of up to 89 nodes
     B = int(rng.integers(1, 301))
     graphs = []
     for g in range(B):
@@ -66,7 +74,10 @@ for it in range(cases):
         took = False
     err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
     worst = max(worst, err)
-    tag = f"{conv} L={L} h={h} out={out} F={fin} {act} skip={int(skip)} pools={'/'.join(pools)} promise={promise} B={B} N={batch.num_nodes}"
+    if ZF and cm.last_path() != "stack_zf":
+        print(f"FAIL case {it}: path {cm.last_path()} (shape {shape}, promise {promise}, F={fin})")
+        sys.exit(1)
+    tag = f"{'shape ' + str(shape) + ' ' if ZF else ''}{conv} L={L} h={h} out={out} F={fin} {act} skip={int(skip)} pools={'/'.join(pools)} promise={promise} B={B} N={batch.num_nodes}"
     if not took or not err < 1e-4:
         print(f"FAIL case {it}: {tag}: fused={took} err={err:.3e}")
         sys.exit(1)
