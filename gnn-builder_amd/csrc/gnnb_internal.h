@@ -64,7 +64,7 @@ struct Options {
                        //     single forward, 13.5 M in the pipeline: the stack kernels leave no register space for a co-resident
                        //     wave, so the fork only reorders), 0 = through the big layer-by-layer kernels (14.2 M)
     int zf_shape;      // k_gcn2_zf: 0 = two 8-wave workgroups per CU, 96-row stages; 1 = one 16-wave workgroup, 176-row stages;
-                       //     2 = shape 0 while the promised graph size fits its stages, else shape 1 (default)
+                       //     2 = shape 1 wherever it exists (input widths up to 16), else shape 0 (default)
     int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it (k_gcn2_fused), 0 = layer by layer
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
     int head_small;    // 1 = readout on a pooled matrix with the small-footprint kernel that co-resides with the

@@ -48,13 +48,12 @@ namespace gnnb {
 // HBM traffic = x + tables in, [B, np*h1] out (as k_gcn2_fused).  Bound: fp32 MFMA.
 // Needs: GCN, exactly two layers, fp32 math mode, F0 <= 32, h0 in {32,64,128}, h1 <= 128 (h1 % 4 == 0), and the caller's
 // promise max_graph_nodes <= 96 - (tile_rows - 1) (validated by graph prep).
-// Two shapes (runtime option zf_shape): 1 = ONE workgroup of 16 waves per CU, stages of up to 176 rows (11 MFMA units)
-// -- a CU's share of the BASELINE config 2 batch (288 rows +- one graph) is always TWO stages (with a 160-row capacity
-// one workgroup in a few hundred found no graph boundary inside the window that lets two stages hold its rows and
-// ran a third: the kernel ends with its slowest workgroup), ~140 KB of LDS leaves room for the readout / graph-prep
-// kernels of the other batches in flight; 0 = two workgroups of 8 waves per CU, stages of up to 96 rows (158 KB: nothing
-// co-resides).  Solo launches are ~2 us faster in shape 0 (the two workgroups hide each other's latencies), the
-// three-stream pipeline of bench.py is faster in shape 1 (78.6 vs 75.2 M graphs/s).
+// Two shapes (runtime option zf_shape; 2 = default = the first where it exists): 1 = ONE workgroup of 16 waves per CU,
+// stages of up to 176 rows (11 MFMA units) -- a CU's share of the BASELINE config 2 batch (288 rows +- one graph) is always
+// TWO stages (with a 160-row capacity one workgroup in a few hundred found no graph boundary inside the window that lets
+// two stages hold its rows and ran a third: the kernel ends with its slowest workgroup), ~143 KB of LDS leave room for the
+// readout / graph-prep kernels of the other batches in flight; 0 = two workgroups of 8 waves per CU, stages of up to 96
+// rows (159 KB: nothing co-resides), the only shape for input widths of 17 .. 32.
 #ifndef ZF_PRIO
 #define ZF_PRIO 2
 #endif
@@ -219,7 +218,11 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     // ---- balanced stage plan: the rows that are left are cut into the fewest stages that can hold them, of EQUAL
     // size, at tile (= graph) boundaries.  A stage takes the boundary closest to its share; boundaries that would
     // leave more than the remaining stages can hold are only taken when there is no other (then the largest).
-    auto plan = [&](int ta, int tf, int tg, int te) {
+    // The search runs ACROSS the lanes (lane l holds tile t0 + l): the boundaries that fit a stage are a prefix of the
+    // lanes behind `ta`, their row counts ascend, so the best cut is the last one below the share or the first one at or
+    // above it -- two ballots and a comparison instead of a loop over the candidates (that loop, ~100 instructions, ran in
+    // every wave in front of the first DMA and in the planner wave every stage).
+    auto plan = [&](int ta, int tf, int tg, int te, int ln) { // ln = this lane's index
         auto T_first = [&](int t) { return __builtin_amdgcn_readlane(tf, __builtin_amdgcn_readfirstlane(t - t0)); };
         auto T_graph = [&](int t) { return __builtin_amdgcn_readlane(tg, __builtin_amdgcn_readfirstlane(t - t0)); };
         auto T_edge = [&](int t) { return __builtin_amdgcn_readlane(te, __builtin_amdgcn_readfirstlane(t - t0)); };
@@ -234,17 +237,28 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         const int krem = max((rrem + ZF_CAP - 1) / ZF_CAP, 1);
         const int target = (rrem + krem - 1) / krem;
         const int rmin = rrem - (krem - 1) * ZF_CAP;
-        int tb = ta + 1, bestd = 1 << 30;
-        for (int c = ta + 1; c <= t1; c++) {
-            const int r = T_first(c) - st.nb;
-            if (r > ZF_CAP)
-                break;
-            const int d = r < rmin ? 4096 + (rmin - r) : (r > target ? r - target : target - r);
-            if (d <= bestd) { // (ties: the later boundary, so that empty tiles are swallowed)
-                bestd = d;
-                tb = c;
+        const int rel = ta - t0;
+        const int r = tf - st.nb; // rows of a stage that ends at this lane's tile
+        const unsigned long long feas = __ballot(ln > rel && ln <= t1 - t0 && r <= ZF_CAP);
+        const unsigned long long ge = feas & __ballot(r >= target);
+        const unsigned long long lt = feas & ~ge;
+        int pick = rel + 1; // (nothing fits: the next tile alone, only if the max_graph_nodes promise is broken)
+        if (feas) {
+            const int hi = ge ? __builtin_ctzll(ge) : -1, lo = lt ? 63 - __builtin_clzll(lt) : -1;
+            if (hi < 0)
+                pick = lo;
+            else if (lo < 0)
+                pick = hi;
+            else {
+                const int r_lo = __builtin_amdgcn_readlane(r, __builtin_amdgcn_readfirstlane(lo)), r_hi = __builtin_amdgcn_readlane(r, __builtin_amdgcn_readfirstlane(hi));
+                const int d_lo = r_lo < rmin ? 4096 + (rmin - r_lo) : target - r_lo, d_hi = r_hi - target;
+                pick = d_hi <= d_lo ? hi : lo;
             }
+            // (ties: the LAST boundary with the same row count, so that empty tiles are swallowed)
+            const unsigned long long same = feas & __ballot(r == __builtin_amdgcn_readlane(r, __builtin_amdgcn_readfirstlane(pick)));
+            pick = 63 - __builtin_clzll(same);
         }
+        const int tb = t0 + pick;
         st.chunk = tb; // (the next stage starts here)
         st.rows = max(min(T_first(tb) - st.nb, ZF_CAP), 0); // (> CAP only if the max_graph_nodes promise is broken)
         st.ga = T_graph(ta);
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 
     // the first stage's inputs start their way to LDS before the weights are fetched (both are waited for below)
     // (every wave plans the first stage for itself from its registers)
-    ZfStage cur = plan(t0, tf, tg, te);
+    ZfStage cur = plan(t0, tf, tg, te, lane);
     issue_small(cur, 0, lane, wave);
     issue_rows(cur, 0, lane, wave);
     // the second stage: planned by the last wave, handed over through LDS behind the barrier that closes the prologue's P0
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         }
     };
     if (wave == G2_NW - 1)
-        publish(plan(cur.chunk, tf, tg, te), lane);
+        publish(plan(cur.chunk, tf, tg, te, lane), lane);
 
     // (the weights are requested HERE, behind the first stage's DMA: in front of the tile-table loads they made the
     // workgroup's first barrier wait for 128 KB of weight fragments; now they land beside the DMA round trip and P0)
@@ -495,19 +509,20 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                 constexpr int NU = decltype(nutag)::value;
                 int row0[NU];
                 f32x4 acc[NU];
+                // (the bias is the accumulators' initial value: the lane's four consecutive columns; from LDS: four
+                // registers fewer across P1)
+                const float4 bias0 = *reinterpret_cast<const float4 *>(SB0 + (n0c - li) + 4 * lg);
 #pragma unroll
                 for (int k = 0; k < NU; k++) {
                     row0[k] = (rg0 + (ubase + k) * nrg0) * 16;
-                    acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    acc[k] = (f32x4){bias0.x, bias0.y, bias0.z, bias0.w};
                 }
                 zf_mma<KQ0, NU>(A0, LD0, w0r, row0, li, lg, acc);
-                const float4 bias0 = *reinterpret_cast<const float4 *>(SB0 + (n0c - li) + 4 * lg); // (from LDS: four registers fewer across P1)
                 if (n0c < h0) { // (h0 is 32, 64 or 128: the lane's four columns are all inside when its slice is)
 #pragma unroll
                     for (int k = 0; k < NU; k++)
                         *reinterpret_cast<float4 *>(H + (row0[k] + li) * ldh + (n0c - li) + 4 * lg) =
-                            make_float4(act_t<ACT>(acc[k][0] + bias0.x), act_t<ACT>(acc[k][1] + bias0.y),
-                                        act_t<ACT>(acc[k][2] + bias0.z), act_t<ACT>(acc[k][3] + bias0.w));
+                            make_float4(act_t<ACT>(acc[k][0]), act_t<ACT>(acc[k][1]), act_t<ACT>(acc[k][2]), act_t<ACT>(acc[k][3]));
                 }
             };
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
@@ -602,7 +617,11 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         {
             const int nv = h1 >> 2; // float4 chunks per row
             const bool pow2 = (nv & (nv - 1)) == 0;
-            while (pow2 && csl < 2 && (ngr << (csl + 1)) <= G2_NW && (nv >> (csl + 1)) >= 4)
+            // (column parts only while the tasks fill at most HALF of the waves: the phase is bound by the instructions the
+            // SIMDs have to issue -- shared with the MFMA stream of the co-resident workgroup --, not by the longest wave,
+            // and every task pays ~150 instructions of set-up, combine and stores: one part per graph for the four or
+            // five graphs of a BASELINE config 2 stage, 42.4 instead of 43.3 us)
+            while (pow2 && csl < 2 && (ngr << (csl + 1)) <= G2_NW / 2 && (nv >> (csl + 1)) >= 4)
                 csl++;
         }
         if (ZF_ON(0)) {
@@ -780,7 +799,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         // the stage after next: planned by ONE wave (executed by all sixteen the plan was a tenth of the kernel's vector
         // instructions), handed over through LDS
         if (wv == G2_NW - 1)
-            publish(plan(nxt.chunk, STAB[tv & 63], STAB[64 + (tv & 63)], STAB[128 + (tv & 63)]), tv & 63);
+            publish(plan(nxt.chunk, STAB[tv & 63], STAB[64 + (tv & 63)], STAB[128 + (tv & 63)], tv & 63), tv & 63);
         cur = nxt;
         b ^= 1;
         g2_barrier(); // A0 / REC of the next stage complete; everybody is done with Z
@@ -806,12 +825,15 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 
 // (input widths above 16 take two MFMA k blocks per row of A0: with 176-row stages the carve would pass 160 KB, so those
 // models run the 96-row shape)
-// zf_shape 2 (default): the two-workgroup shape while the promised graph size fits its 96-row stages (it is ~2 us faster
-// per launch: the two workgroups of a CU fill each other's barrier and latency gaps), the 176-row shape beyond that
+// zf_shape 2 (default): the 176-row shape wherever it exists (input widths up to 16).  Until the planner and the
+// aggregation tasks were trimmed the two-workgroup shape was ~1-2 us faster per launch and the choice went by
+// the promised graph size; since then the wide shape is the faster one alone (40.0 vs 41.3 us at BASELINE config 2) and
+// in the three-stream pipeline (47-49 vs 52 us per step: its 143 KB leave room for the small kernels of the other batches).
 static bool zf_wide_shape(int f0, int promise)
 {
     const int sh = options().zf_shape;
-    return f0 <= 16 && (sh == 1 || (sh == 2 && promise + 3 > 96)); // (+ 3: the finest node tiles are 4 rows)
+    (void)promise;
+    return f0 <= 16 && sh != 0;
 }
 int zf_stage_rows(int f0, int promise) { return zf_wide_shape(f0, promise) ? 176 : 96; }
 static constexpr int ZF_TCAP = 62; // tiles per workgroup: the run's table lives in one register per lane (+ its end)

@@ -968,7 +968,7 @@ def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math, zf):
     past the limit: the layer-by-layer path answers, same numbers.  The opt-in bf16x6 mode keeps 48-row stages (limit 45).
     k_gcn2_zf (the default for two fp32 GCN layers) has 176-row stages (one 16-wave workgroup per CU): 169 nodes with 8-row
     tiles, 173 with 4-row tiles; zf = 2 selects its other shape (two 8-wave workgroups per CU, 96-row stages: 89 / 93); zf = 3
-    the default: the two-workgroup shape while the promise fits it, the 176-row shape beyond."""
+    the default: the 176-row shape wherever it exists (input widths up to 16)."""
     model = make_model("gcn", in_dim=9, hidden=128, layers=2, out_dim=128, act="relu", pools=("add", "mean", "max"), task_out=4)
     rng = np.random.default_rng(promise)
     graphs = []
@@ -983,7 +983,7 @@ def test_fused_gcn_stack_takes_graphs_up_to_61_nodes(dev, promise, math, zf):
     try:
         runtime.set_option("math", math)
         runtime.set_option("fuse_zf", 1 if zf else 0)
-        runtime.set_option("zf_shape", {2: 0, 3: 2}.get(zf, 1))  # (zf = 3: the default, shape picked from the promise)
+        runtime.set_option("zf_shape", {2: 0, 3: 2}.get(zf, 1))  # (zf = 3: the default)
         cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
         got = cm.forward(*to_dev(batch, dev)).cpu().numpy()
         cm.check()
