@@ -209,11 +209,6 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         cs1l++; // h <= 128 -> <= 3
     const int nrg0 = G2_NW >> cs0l, nrg1 = G2_NW >> cs1l;
 
-    if (tid < 128) {
-        SB1[tid] = (b1 && tid < h1) ? b1[tid] : 0.0f;
-        SB0[tid] = (b0 && tid < h0) ? b0[tid] : 0.0f;
-    }
-    __syncthreads();
 
     // ---- balanced stage plan: the rows that are left are cut into the fewest stages that can hold them, of EQUAL
     // size, at tile (= graph) boundaries.  A stage takes the boundary closest to its share; boundaries that would
@@ -309,6 +304,12 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     ZfStage cur = plan(t0, tf, tg, te, lane);
     issue_small(cur, 0, lane, wave);
     issue_rows(cur, 0, lane, wave);
+    // (the biases -> LDS behind the first DMA: tracked loads, nobody reads them before the two barriers that close the
+    // prologue; in front of the plan they held waves 0 and 1 back for a memory round trip)
+    if (tid < 128) {
+        SB1[tid] = (b1 && tid < h1) ? b1[tid] : 0.0f;
+        SB0[tid] = (b0 && tid < h0) ? b0[tid] : 0.0f;
+    }
     // the second stage: planned by the last wave, handed over through LDS behind the barrier that closes the prologue's P0
     auto publish = [&](const ZfStage &pn, int lane) {
         if (lane == 0) {

@@ -16,7 +16,7 @@ bd = tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_
 for shape in (1, 0):
     runtime.set_option("zf_shape", shape)
     cm.graph_prep(bd[1], bd[2], bd[3], int(bd[0].shape[0]))
-    for dbg, what in ((0, "everything"), (1, "no P1"), (2, "no P0'"), (3, "no P1, no P0'"), (4, "no M1"), (8, "no M0"), (16, "no Z write"),
+    for dbg, what in ((0, "everything"), (1, "no P1"), (3, "no P1, no P0'"), (4, "no M1"), (8, "no M0"), (16, "no Z write"),
                       (4 + 8, "no MFMA at all"), (1 + 2 + 16, "MFMA phases only"), (31, "skeleton: DMA, plan, barriers"), (32, "return at entry"), (64 + 128, "... after the first DMA, no W1 load"), (128, "everything but the W1 load"), (64, "return after the first DMA landed")):
         os.environ["GNNB_ZF_DBG"] = str(dbg)
         t = min(cm.gcn_stack_timed(bd[0], 100) for _ in range(3))
