@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ZF_CAP = 16 * ZF_UNITS, G2_NW = NW, G2_WG = NW * 64;
     constexpr int GMAX = ZF_CAP <= 96 ? 64 : 128; // graph boundaries of a stage kept in LDS (more: empty graphs piling up)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- LDS carve (bytes, every region 16-B aligned; LDS pointers are always derived arithmetically from `smem`:
     // runtime-indexed arrays of LDS pointers turn into FLAT accesses, see k_stack.hip)
     //   ROWS   xs | srec                     ONE buffer (P0 is its only reader; refilled one stage ahead)
@@ -208,6 +208,9 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     while ((16 << cs1l) < h1)
         cs1l++; // h <= 128 -> <= 3
     const int nrg0 = G2_NW >> cs0l, nrg1 = G2_NW >> cs1l;
+    constexpr int LOG2NW = NW == 16 ? 4 : 3;
+    static_assert(NW == 8 || NW == 16, "wave roles assume 8 or 16 waves");
+    const int lnrg0 = LOG2NW - cs0l, lnrg1 = LOG2NW - cs1l;
 
 
     // ---- balanced stage plan: the rows that are left are cut into the fewest stages that can hold them, of EQUAL
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         const int32_t *scol = reinterpret_cast<const int32_t *>(SCOLb + (size_t)bb * ECAP * 4);
         const bool col_lds = st.ne <= ECAP;
         const int e0 = st.e0;
-        const int wv = tv >> 6, l8 = tv & 7, r8 = (tv >> 3) & 7;
+        const int wv = __builtin_amdgcn_readfirstlane(tv >> 6), l8 = tv & 7, r8 = (tv >> 3) & 7;
         const int rows = st.rows, nb = st.nb;
         const int npass = (rows + 7) >> 3;
         for (int p = (wv - pstart) & (G2_NW - 1); p < npass; p += G2_NW) {
@@ -494,7 +497,9 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         // (otherwise the compiler hoists dozens of loop-invariant LDS offsets out of the stage loop and spills them)
         int tv = tid;
         asm volatile("" : "+v"(tv));
-        const int li = tv & 15, lg = (tv >> 4) & 3, wv = tv >> 6;
+        // (the wave index as a SCALAR: wave-dependent branches and DMA addresses then run on the scalar unit instead of as
+        // v_cmp / exec-mask sequences and 64-bit vector address arithmetic in all sixteen waves)
+        const int li = tv & 15, lg = (tv >> 4) & 3, wv = __builtin_amdgcn_readfirstlane(tv >> 6);
         const int rows = cur.rows, nb = cur.nb;
         const int units = (rows + 15) >> 4;
         // ---- top: the next stage's inputs start their way to LDS (ROWS: P0 of `cur` was its last reader)
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                             make_float4(act_t<ACT>(acc[k][0]), act_t<ACT>(acc[k][1]), act_t<ACT>(acc[k][2]), act_t<ACT>(acc[k][3]));
                 }
             };
-            const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
+            const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) >> lnrg0 : 0; // (nrg0 is a power of two)
             // (units in groups of three: register budget)
             if (nu >= 3)
                 m0(IntTag<3>{}, 0);
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         __builtin_amdgcn_s_setprio(0);
         const int n1c = (wv & ((1 << cs1l) - 1)) * 16 + li;
         const int rg1 = wv >> cs1l;
-        const int nu1 = rg1 < units ? (units - rg1 + nrg1 - 1) / nrg1 : 0;
+        const int nu1 = rg1 < units ? (units - rg1 + nrg1 - 1) >> lnrg1 : 0;
         constexpr int ZMAX = (ZF_UNITS * 8 + NW - 1) / NW; // units one wave can own (all eight column slices in use)
         static_assert(ZMAX <= 6, "M0 / M1 handle up to two groups of three units per wave");
         f32x4 z[ZMAX];
