@@ -93,7 +93,7 @@ __global__ __launch_bounds__(CR_THREADS, 5) void k_conv_rows(ConvRowsArgs p)
 {
     __shared__ __attribute__((aligned(16))) float T[CR_ROWS * CR_LD];
     __builtin_amdgcn_s_setprio(GNNB_GUEST_PRIO); // (co-runs with the conv-stack kernel of the rest of the batch: see k_graph_prep)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int r0 = p.row_lo + blockIdx.x * CR_ROWS;
     const int K = p.K, kpad = (K + 15) & ~15;

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(WG, MATH ? 2 : 3) void k_linear_reg(
     constexpr int SR = GNNB_LR_SR; // 16-row units per stage
     constexpr int EPI_LD = 36; // padded row of the epilogue transpose scratch
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int RG = 1 << rg_log2;     // row groups: waves that take different rows
     const int cw = wave >> rg_log2;  // which 32-column slice this wave owns

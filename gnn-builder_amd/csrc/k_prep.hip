@@ -193,7 +193,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     // letting them issue first costs the big kernel nothing measurable (C2 step 55.5 -> 54.0 us).
     __builtin_amdgcn_s_setprio(GNNB_GUEST_PRIO);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = blockIdx.x * (WG / 64) + wave;
     if (g > B)
         return;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_pool_mlp(const float *__restri
     float *const act_lo = reinterpret_cast<float *>(smem);
     float *wbase = reinterpret_cast<float *>(smem) + (size_t)act0_floats + act1_floats;
     const int woff[8] = {woff0, woff1, woff2, woff3, woff4, woff5, woff6, woff7};
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int g0 = blockIdx.x * HEAD_GRAPHS;
 
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(HS_THREADS, 5) void k_head_small(const float *__res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __builtin_amdgcn_s_setprio(GNNB_GUEST_PRIO); // (co-runs with the next batch's conv-stack kernel: see k_graph_prep)
     float *sact = reinterpret_cast<float *>(smem); // [2][16][ldact]: ldact = widest hidden layer + 4 (padded rows)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int g0 = blockIdx.x * 16;
     const int grow = min(g0 + li, B - 1); // (rows past the batch re-read the last graph and are dropped at the store)
