@@ -165,6 +165,85 @@ __device__ void prep_graph_scan(
 }
 
 
+// Molecule path (<= 64 nodes AND <= 64 edges: one lane per edge, one lane per node; QM9, ESOL, most of ogbg-molhiv).
+// Written for INSTRUCTION COUNT: with batches in flight this kernel runs beside the conv-stack kernel of another batch and
+// costs the pipeline what it issues.  Instead of one ballot per destination node (a loop of n iterations of
+// ~12 vector + scalar instructions), the lanes are matched on the BITS of the destination index: ceil(log2 n) ballots give
+// every edge lane the mask of the lanes with the same destination (rank among them = popcount below the lane: stable,
+// lanes are in COO order) and, from the same ballots, every NODE lane the mask of its in-edges (degree = popcount).
+__device__ __forceinline__ void prep_graph_small(
+    const int2 *__restrict__ coo, int n0, int n1, int e0, int ne, int32_t *__restrict__ row_ptr, int32_t *__restrict__ col,
+    int32_t *__restrict__ eid, int4 *__restrict__ node_rec, float *__restrict__ dinv, float *__restrict__ amp,
+    float *__restrict__ att, float delta, int drop_self, int32_t *__restrict__ err, int32_t *__restrict__ err_host,
+    int32_t *__restrict__ s_first, int lane)
+{
+    const int n = n1 - n0;
+    // ---- this lane's edge; an edge that leaves its graph is an error and is dropped, a GCN self loop is dropped silently
+    int src = n0, d = 0;
+    bool keep = false, bad = false;
+    if (lane < ne) {
+        const int2 e = coo[e0 + lane];
+        if (e.x < n0 || e.x >= n1 || e.y < n0 || e.y >= n1)
+            bad = true;
+        else if (!(drop_self && e.x == e.y)) {
+            keep = true;
+            src = e.x;
+            d = e.y - n0;
+        }
+    }
+    // ---- match on the bits of the destination: `same` = edge lanes with this lane's destination, `mine` = edge lanes
+    // whose destination is THIS lane's node index
+    const unsigned long long valid = __ballot(keep);
+    unsigned long long same = valid, mine = valid;
+    const int nbits = 32 - __builtin_clz(max(n - 1, 1)); // wave-uniform, <= 6
+    for (int b = 0; b < nbits; b++) {
+        const unsigned long long mb = __ballot(keep && ((d >> b) & 1));
+        same &= ((d >> b) & 1) ? mb : ~mb;
+        mine &= ((lane >> b) & 1) ? mb : ~mb;
+    }
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0));
+    const int deg = lane < n ? __popcll(mine) : 0;
+    // ---- row starts: inclusive wave scan of the degrees over the node lanes
+    int incl = deg;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off)
+            incl += t;
+    }
+    const int start = e0 + incl - deg;
+    if (lane < n) {
+        const int v = n0 + lane;
+        row_ptr[v] = start;
+        dinv[v] = 1.0f / sqrtf(1.0f + (float)deg);
+        if (delta > 0.0f) { // (delta <= 0: the model has no PNA layer, the scalers are not needed)
+            const int dcl = deg < 1 ? 1 : deg; // gnn_builder_lib.h:1972-1982
+            const float logd = logf((float)(dcl + 1));
+            amp[v] = logd / delta;
+            att[v] = delta / logd;
+        }
+        // default record: unused source slots alias the node itself
+        *reinterpret_cast<int4 *>(s_first + lane * 4) = make_int4(v, v, v, v);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- scatter: col[start[dst] + rank] = src (one store per edge lane), first four sources -> the node's record
+    const int st = __shfl(start, d, 64);
+    if (keep) {
+        col[st + rank] = src;
+        eid[st + rank] = e0 + lane; // COO row of this CSR slot (gnn_builder_lib.h:1126-1166)
+        if (rank < 4)
+            s_first[d * 4 + rank] = src;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+        const int4 f = *reinterpret_cast<const int4 *>(s_first + lane * 4);
+        node_rec[2 * (size_t)(n0 + lane)] = make_int4(start, deg, f.x, f.y);
+        node_rec[2 * (size_t)(n0 + lane) + 1] = make_int4(f.z, f.w, 0, 0);
+    }
+    if (bad)
+        flag_batch(err, err_host, 4);
+}
+
 // Fast path (graphs of <= 256 nodes and <= 256 edges, i.e. every molecule): lanes hold EDGES.
 // One loop over the graph's destination nodes: ballot(dst == v) gives, in a single instruction,
 // the in-degree of v (popcount) and the rank of every edge among v's in-edges (popcount of the
@@ -266,6 +345,12 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         flag_batch(err, err_host, 8); // the caller's max_graph_nodes promise does not hold for this batch
     if (n > PREP_FAST_NODES || ne > PREP_FAST_EDGES) { // wave-uniform
         prep_graph_scan(coo, n0, n1, e0, e1, row_ptr, col, eid, node_rec, dinv, amp, att, delta, drop_self, err, err_host);
+        return;
+    }
+    if (n <= 64 && ne <= 64) { // wave-uniform: the molecule path
+        prep_graph_small(coo, n0, n1, e0, ne, row_ptr, col, eid, node_rec, dinv, amp, att, delta, drop_self, err, err_host,
+                         s_first[wave], lane);
+        GNNB_STAMP_END(3);
         return;
     }
 
