@@ -205,6 +205,19 @@ __device__ inline void dma_dwords_u(const void *g, void *l, int count, int wave,
         if (c + lane < count)
             dma4_to_lds_u(gs + (size_t)(c + lane) * 4, ls + (size_t)c * 4);
 }
+// Inclusive prefix sum over the 64 lanes of a wave with DPP adds: Hillis-Steele inside each row of 16 lanes (row_shr
+// 1, 2, 4, 8; lanes without a source add 0), then the row totals (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2
+// and 3).  Six vector instructions; the __shfl_up form is six ds_bpermute round trips with ~7 instructions each.
+__device__ __forceinline__ int wave_scan_incl(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 __device__ inline void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate
 __device__ __forceinline__ void vmcnt_wait_upto(int n)

@@ -204,13 +204,7 @@ __device__ __forceinline__ void prep_graph_small(
     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0));
     const int deg = lane < n ? __popcll(mine) : 0;
     // ---- row starts: inclusive wave scan of the degrees over the node lanes
-    int incl = deg;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off)
-            incl += t;
-    }
+    const int incl = wave_scan_incl(deg);
     const int start = e0 + incl - deg;
     if (lane < n) {
         const int v = n0 + lane;
