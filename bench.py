@@ -700,8 +700,9 @@ def main():
             "value": split_rate, "unit": "graphs/s", "ms_per_step": split_ms,
             "how": "GNNB_MATH=1 / gnnb_set_option(\"math\", 1): the wide updates (A1.W1^T of the fused GCN stack, the K <= 128 "
                    "GEMMs, the large-K segmented GEMM) as 6 bf16 MFMA products per k block on an exact hi/mid/lo bf16 split of "
-                   "both operands, fp32 accumulate; NOT used for `value`.  (The fused GIN and deeper-than-two GCN stacks "
-                   "are fp32-only: with math=1 those models run layer by layer, which can be slower than the default)",
+                   "both operands, fp32 accumulate; NOT used for `value`.  (The 2-layer GCN stack keeps its fp32 kernel k_gcn2_zf, "
+                   "which is faster than the bf16x6 form of k_gcn2_fused; the fused GIN and deeper-than-two GCN stacks "
+                   "are fp32-only and stay on their fp32 stack kernel: the mode only changes the layer-by-layer GEMMs)",
             "accuracy": ("max |out - float64 evaluation| on this workload: 9.4e-8 (fp32-MFMA path 6.3e-8, scalar fp32 "
                          "reference 1.4e-7; tests/accuracy_math_modes.py)") if args.workload == "c2" else
                         ("per GEMM against a float64 product: no worse than 2x the fp32-MFMA kernel's error + 1e-7 "

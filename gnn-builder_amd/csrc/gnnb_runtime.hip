@@ -584,8 +584,8 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     if (options().fuse_gcn2 && (ws->desc.conv_type == GNNB_CONV_GCN || ws->desc.conv_type == GNNB_CONV_GIN) && ws->desc.num_layers >= 2 &&
         ws->max_graph_nodes > 0) {
         // (a 2-layer fp32 GCN stack runs k_gcn2_zf with its 96-row stages; everything else k_gcn2_fused)
-        const bool zf = ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && options().fuse_zf && !options().math;
-        const bool bf6 = options().math && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2; // (the only bf16x6 stack form)
+        const bool zf = ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && options().fuse_zf;
+        const bool bf6 = !zf && options().math && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2; // (the only bf16x6 stack form)
         const int stage_rows = zf ? zf_stage_rows(ws->desc.in_dim, ws->max_graph_nodes) : bf6 ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
         while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > stage_rows)
             t.tile_rows >>= 1;

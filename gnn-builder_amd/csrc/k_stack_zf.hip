@@ -883,7 +883,9 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
                           const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1f)
 {
     const Options &o = options();
-    if (!o.fuse_gcn2 || !o.fuse_zf || o.math || t.num_nodes <= 0)
+    // (math = 1, the opt-in bf16x6 mode, does not switch this kernel off: its fp32 form is faster than the bf16x6 form of
+    // k_gcn2_fused -- 39 vs 43 us at BASELINE config 2 -- and the mode must never be slower than the default)
+    if (!o.fuse_gcn2 || !o.fuse_zf || t.num_nodes <= 0)
         return hipErrorNotSupported;
     const int cap = zf_stage_rows(f0, t.max_graph_nodes_hint);
     if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > cap)
