@@ -197,9 +197,11 @@ struct LdsRowF {
     __device__ __forceinline__ void begin(bool ok, int r_, const int4 *srec, uint32_t sxo, uint32_t sx_lane,
                                           const float *sdinv, const float4 *sgc, int w4)
     {
+        // (lane groups without a row read the stage's FIRST row and only their store is predicated: a predicated begin
+        // merges every loaded register with its previous value behind the branch -- ~16 v_mov per row in the chain
+        // between the LDS reads and the FMAs)
         valid = ok;
-        if (!ok)
-            return;
+        r_ = ok ? r_ : 0;
         const int4 r0 = srec[2 * r_], r1 = srec[2 * r_ + 1];
         rp0 = r0.x;
         deg = r0.y;
@@ -224,8 +226,6 @@ struct LdsRowF {
     // scol_o = LDS byte address of the stage's CSR slice minus e0 * 4; obase = the stage's first output row (+ column)
     __device__ __forceinline__ void finish(uint32_t sxo, uint32_t sdo, uint32_t scol_o, int w4, char *__restrict__ obase, float eps)
     {
-        if (!valid)
-            return;
         V acc;
         // (the first term initialises the sum: 0 + v c, as AggAcc starts from zero)
         acc = vmul(nbv[0], V::splat(c[0]));
@@ -248,7 +248,8 @@ struct LdsRowF {
             o = deg > 0 ? vmul(acc, V::splat(1.0f / (float)deg)) : acc;
         else
             o = acc;
-        agg_store<NT>(o, reinterpret_cast<float *>(obase + roff));
+        if (valid)
+            agg_store<NT>(o, reinterpret_cast<float *>(obase + roff));
     }
 };
 
