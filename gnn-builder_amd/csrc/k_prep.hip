@@ -165,6 +165,24 @@ __device__ void prep_graph_scan(
 }
 
 
+// 1 / sqrt(1 + d) for the in-degrees the molecule path can meet (<= 64 edges), as correctly rounded fp32 divisions of
+// correctly rounded fp32 square roots -- bit-identical to `1.0f / sqrtf(1.0f + d)` on the device and in the oracle (hex
+// float literals; generated with numpy float32).  One load instead of the ~35 instructions of the IEEE sqrt + division.
+__device__ const float k_dinv_by_degree[65] = {
+    0x1.0000000000000p+0f, 0x1.6a09e60000000p-1f, 0x1.279a740000000p-1f, 0x1.0000000000000p-1f, 0x1.c9f25c0000000p-2f,
+    0x1.a20bd60000000p-2f, 0x1.8309200000000p-2f, 0x1.6a09e60000000p-2f, 0x1.5555560000000p-2f, 0x1.43d1360000000p-2f,
+    0x1.34bf640000000p-2f, 0x1.279a740000000p-2f, 0x1.1c01aa0000000p-2f, 0x1.11acee0000000p-2f, 0x1.08654a0000000p-2f,
+    0x1.0000000000000p-2f, 0x1.f0b6860000000p-3f, 0x1.e2b7e00000000p-3f, 0x1.d5d7ea0000000p-3f, 0x1.c9f25c0000000p-3f,
+    0x1.bee9040000000p-3f, 0x1.b4a2940000000p-3f, 0x1.ab099a0000000p-3f, 0x1.a20bd60000000p-3f, 0x1.99999a0000000p-3f,
+    0x1.91a5560000000p-3f, 0x1.8a23460000000p-3f, 0x1.8309200000000p-3f, 0x1.7c4dd60000000p-3f, 0x1.75e9740000000p-3f,
+    0x1.6fd4e80000000p-3f, 0x1.6a09e60000000p-3f, 0x1.6482d40000000p-3f, 0x1.5f3aa80000000p-3f, 0x1.5a2cd80000000p-3f,
+    0x1.5555560000000p-3f, 0x1.50b06a0000000p-3f, 0x1.4c3abe0000000p-3f, 0x1.47f1460000000p-3f, 0x1.43d1360000000p-3f,
+    0x1.3fd8080000000p-3f, 0x1.3c03660000000p-3f, 0x1.38512c0000000p-3f, 0x1.34bf640000000p-3f, 0x1.314c3e0000000p-3f,
+    0x1.2df60c0000000p-3f, 0x1.2abb440000000p-3f, 0x1.279a740000000p-3f, 0x1.24924a0000000p-3f, 0x1.21a1860000000p-3f,
+    0x1.1ec7020000000p-3f, 0x1.1c01aa0000000p-3f, 0x1.19507e0000000p-3f, 0x1.16b2900000000p-3f, 0x1.1426fc0000000p-3f,
+    0x1.11acee0000000p-3f, 0x1.0f43a40000000p-3f, 0x1.0cea620000000p-3f, 0x1.0aa07c0000000p-3f, 0x1.08654a0000000p-3f,
+    0x1.0638320000000p-3f, 0x1.0418a40000000p-3f, 0x1.0206140000000p-3f, 0x1.0000000000000p-3f, 0x1.fc0bd80000000p-4f};
+
 // Molecule path (<= 64 nodes AND <= 64 edges: one lane per edge, one lane per node; QM9, ESOL, most of ogbg-molhiv).
 // Written for INSTRUCTION COUNT: with batches in flight this kernel runs beside the conv-stack kernel of another batch and
 // costs the pipeline what it issues.  Instead of one ballot per destination node (a loop of n iterations of
@@ -209,7 +227,7 @@ __device__ __forceinline__ void prep_graph_small(
     if (lane < n) {
         const int v = n0 + lane;
         row_ptr[v] = start;
-        dinv[v] = 1.0f / sqrtf(1.0f + (float)deg);
+        dinv[v] = k_dinv_by_degree[min(deg, 64)];
         if (delta > 0.0f) { // (delta <= 0: the model has no PNA layer, the scalers are not needed)
             const int dcl = deg < 1 ? 1 : deg; // gnn_builder_lib.h:1972-1982
             const float logd = logf((float)(dcl + 1));
