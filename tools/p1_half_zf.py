@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Development only (-DGNNB_ZF_ABLATE): k_gcn2_zf with P1 walking only HALF of every graph's rows (wrong results) -- what two
+waves per graph would buy before the cost of combining their partial sums."""
+import os, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np, torch
+import bench
+from gnnbuilder_amd import runtime, synthetic
+w = bench.WORKLOADS["c2"]; dev = torch.device("cuda:0")
+model = bench.build_model(w)
+b = synthetic.make_batch(w["shape"], w["batch"], seed=0)
+cm = runtime.CompiledModel.from_model(model, b.num_graphs, b.num_nodes, b.num_edges, max_graph_nodes=int(np.diff(b.node_ptr).max()))
+bd = tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr))
+cm.graph_prep(bd[1], bd[2], bd[3], int(bd[0].shape[0]))
+for dbg, what in ((0, "everything"), (1 << 20, "P1 on half of the rows"), (1, "no P1"), (0, "everything")):
+    os.environ["GNNB_ZF_DBG"] = str(dbg)
+    t = min(cm.gcn_stack_timed(bd[0], 100) for _ in range(3))
+    print(f"{what:26s} {t:6.2f} us", flush=True)
+os.environ["GNNB_ZF_DBG"] = "0"
