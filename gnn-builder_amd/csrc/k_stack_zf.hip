@@ -666,6 +666,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                 const char *Hl = reinterpret_cast<const char *>(H) + col0 * 4; // its chunk of row 0
                 const float4 bias = *reinterpret_cast<const float4 *>(SB1 + col0);
                 V sum = V::splat(0.0f), mx = V::splat(-INFINITY);
+#ifdef GNNB_ZF_ABLATE
+                if (dbg & (1 << 20)) // (what would P1 cost if two waves shared a graph's rows?  half of the rows: WRONG results)
+                    r1g = r0g + ((r1g - r0g + 1) >> 1);
+#endif
                 const int n = max(r1g - r0g, 0);
                 // Row loop, written for instruction count (in this phase every instruction of the wave is on the
                 // workgroup's critical path, and VALU issue is what the phase is bound by): running pointers instead of
