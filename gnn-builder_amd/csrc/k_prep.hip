@@ -277,7 +277,7 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     int32_t *__restrict__ graph_ptr, int tile_rows, int num_tiles, int max_graph_nodes_hint, int promise_graphs, int drop_self,
     int32_t *__restrict__ err, int32_t *__restrict__ err_host)
 {
-    __shared__ int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node
+    __shared__ __attribute__((aligned(16))) int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node (read / written 16 B at a time)
     // Highest wave priority: with batches in flight on several streams this kernel runs BESIDE the conv-stack kernel of
     // another batch (one wave slot per SIMD is left over there) and sits on its own stream's critical path -- 37-53 us
     // instead of 7 when it queues behind sixteen MFMA-issuing waves per CU.  It is a few hundred instructions per wave;
