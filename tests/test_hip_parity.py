@@ -61,10 +61,31 @@ def edge_case_batch():
     return pack_graphs([(np.asarray(x, np.float32), np.asarray(c, np.int32)) for x, c in graphs])
 
 
-@pytest.mark.parametrize("which", ["fixture", "qm9", "molhiv", "edge"])
+def molecule_path_batch():
+    """The corners of graph prep's molecule path (<= 64 nodes and <= 64 edges, matched on the bits of the destination index):
+    exactly 64 nodes / 64 edges, 63 / 65 (just outside: the general path), node counts either side of a power of two (the
+    number of matched bits), every edge into ONE node, every edge the same edge, self loops only, isolated nodes."""
+    rng = np.random.default_rng(11)
+    graphs = []
+
+    def g(n, coo):
+        graphs.append((rng.uniform(-1, 1, (n, 8)).astype(np.float32), np.asarray(coo, np.int32).reshape(-1, 2)))
+
+    for n, e in ((64, 64), (64, 63), (63, 64), (64, 65), (65, 64), (32, 64), (33, 64), (31, 60), (17, 40), (16, 40), (2, 64), (1, 7)):
+        g(n, np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1))
+    g(40, np.stack([rng.integers(0, 40, 64), np.full(64, 39)], 1))      # a hub takes all 64 edges (rank up to 63)
+    g(40, np.tile([[3, 5]], (64, 1)))                                     # 64 copies of one edge
+    g(12, np.stack([np.arange(12), np.arange(12)], 1))                    # self loops only
+    g(50, np.zeros((0, 2)))                                               # no edges
+    g(9, [[0, 8], [8, 0], [8, 8], [1, 8]])
+    return pack_graphs(graphs)
+
+
+@pytest.mark.parametrize("which", ["fixture", "qm9", "molhiv", "edge", "molecule_path", "c2_full"])
 def test_graph_prep_bit_exact(dev, which):
     batch = {"fixture": fixture_batch, "qm9": lambda: synthetic.make_batch("qm9", 300, 1),
-             "molhiv": lambda: synthetic.make_batch("molhiv", 200, 2), "edge": edge_case_batch}[which]()
+             "molhiv": lambda: synthetic.make_batch("molhiv", 200, 2), "edge": edge_case_batch,
+             "molecule_path": molecule_path_batch, "c2_full": lambda: synthetic.make_batch("qm9", 4096, 0)}[which]()
     # (a workspace bound to a non-GCN model keeps every edge = the reference's tables; GCN: next test)
     cm = runtime.CompiledModel.from_model(plain_model("gin", batch.x.shape[1], 8), batch.num_graphs + 1,
                                           batch.num_nodes + 1, batch.num_edges + 1)
@@ -468,6 +489,23 @@ def test_whole_model_matches_oracle(dev, case):
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() < TOL, f"max err {np.abs(got - ref).max():.3e}, |ref| {np.abs(ref).max():.3e}"
+
+
+@pytest.mark.parametrize("conv,promise", [("gcn", 0), ("gcn", 65), ("gin", 0), ("sage", 0), ("pna", 0)])
+def test_molecule_path_corners_through_whole_models(dev, conv, promise):
+    """Node records (first four sources, degrees), normalisers and PNA scalers written by graph prep's molecule path on
+    its corner cases (hubs of degree 64, 64 copies of one edge, self loops only ...), checked through whole models --
+    layer by layer and, with a promise, through the conv-stack kernel -- against the oracle."""
+    batch = molecule_path_batch()
+    model = make_model(conv, in_dim=8, hidden=32, layers=2, act="relu", skip=True, pools=("add", "mean", "max"), task_out=3, seed=7)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise)
+    got = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+    cm.check()
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
+    if promise:
+        assert cm.last_path().startswith("stack")
 
 
 @pytest.mark.parametrize("cls", [torch.nn.Softmax, torch.nn.LogSoftmax])
