@@ -301,9 +301,15 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *   agg_nt_store                 launch shape of the gather-aggregate  gemm_variant, gemm_dma, gemm_tail_split,
  *   gemm_wlds, gemm_wlds_slots, gemm_max_wg_per_cu  which GEMM kernel   fuse_narrow, fuse_gcn2, fuse_head, head_small,
  *   head_split                   which launches are fused (0 = layer by layer / separate readout)
+ *   fuse_zf (default 1)          2-layer fp32 GCN stacks through k_gcn2_zf (last layer transformed before it is aggregated);
+ *                                0 = k_gcn2_fused.  zf_shape: 0 = two 8-wave workgroups per CU, 96-row stages; 1 = one 16-wave
+ *                                workgroup, 176-row stages; 2 (default) = 1 wherever it exists (input widths <= 16)
+ *   large_fork (default 2)       how a batch's large segment (gnnb_workspace_set_large_segment) runs: 2 = small per-layer
+ *                                kernels behind the stack kernel, 1 = the same on a side stream, 0 = the big layer-wise kernels
  * "math": 0 (default) = native fp32 MFMA everywhere; 1 = every wide update (the fused GCN stack's A1.W1^T, the
  * K <= 128 GEMMs, the large-K segmented GEMM) as six bf16 MFMA products of an exact 3-way bf16 split of both fp32
- * operands, fp32 accumulate (results at fp32 rounding level; GNNB_MATH=1).  Unknown names or values
+ * operands, fp32 accumulate (results at fp32 rounding level; GNNB_MATH=1); stack kernels that are faster
+ * in fp32 than any bf16x6 form (k_gcn2_zf, the GIN / deep stacks) keep running: the mode is never slower than 0.  Unknown names or values
  * out of range return GNNB_ERR_INVALID. */
 int gnnb_set_option(const char *name, int value);
 
