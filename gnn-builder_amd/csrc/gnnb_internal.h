@@ -27,6 +27,8 @@ struct BatchTables {
     int32_t *tile_graph; // [T+1] index of the graph that starts at tile_first[t] (B past the end)
     int32_t max_graph_nodes_hint; // caller's promise (0 = unknown); validated on device by prep
     int32_t promise_graphs;       // ... for graphs [0, promise_graphs) (the rest: the caller's "large segment")
+    int32_t large_n, large_e;     // node / edge offset the caller named for graph promise_graphs (-1: no large segment);
+                                  // graph prep flags the batch when they disagree with node_ptr / edge_ptr
     int32_t tile_lo;              // first node tile the gather-aggregate kernels walk (0; the large segment's first tile)
     int32_t *err;        // [1]   != 0 when the batch was malformed
     int32_t *err_host_dev; // device-visible address of the host-mapped copy of "flagged" (nullptr: none)

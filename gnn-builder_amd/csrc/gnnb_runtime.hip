@@ -572,6 +572,8 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
                     ws->large_g, ws->large_n, ws->large_e, num_graphs, num_nodes, num_edges);
     BatchTables &t = ws->t;
     t.promise_graphs = ws->large_g >= 0 ? ws->large_g : num_graphs; // the promise covers graphs [0, promise_graphs)
+    t.large_n = ws->large_g >= 0 ? ws->large_n : -1; // (checked against node_ptr / edge_ptr on the device: flag 16)
+    t.large_e = ws->large_g >= 0 ? ws->large_e : -1;
     t.tile_lo = 0;
     t.node_ptr = node_ptr_dev;
     t.num_graphs = num_graphs;
@@ -607,6 +609,20 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
                                    (hipStream_t)stream));
     ws->prepared = true;
     ws->gcoef_ready = false;
+    // The GCN coefficient table (dinv_i dinv_j of the four inline sources; read by every layer-wise GCN aggregate) is
+    // produced HERE, on the prep stream right behind the tables, whenever the batch can run layer by layer -- so that a
+    // forward captured into a hipGraph contains no lazily launched table kernel and aggregates on other streams that are
+    // ordered against the prep see a finished table.  Only a workspace whose whole batch is expected on the LDS-resident
+    // stack kernels (promise set, no large segment) skips it; should that forward fall back after all, ensure_gcoef
+    // launches the table kernel in front of the first aggregate (the one lazy case left).
+    if (ws->desc.conv_type == GNNB_CONV_GCN && num_nodes > 0) {
+        const bool stack_expected = options().fuse_gcn2 && ws->desc.num_layers >= 2 && ws->max_graph_nodes > 0 &&
+                                    ws->large_g < 0 && ws->desc.fpx_w <= 0;
+        if (!stack_expected) {
+            GNNB_HIP_TRY(launch_gcn_coef(ws->t, (hipStream_t)stream));
+            ws->gcoef_ready = true;
+        }
+    }
     return GNNB_OK;
 }
 
@@ -634,8 +650,9 @@ int gnnb_workspace_check(gnnb_workspace *ws, void *stream)
     if (ws->err_host)
         *(volatile int32_t *)ws->err_host = 0;
     if (err != 0)
-        return fail(GNNB_ERR_GRAPH, "malformed batch (flags 0x%x): ptr arrays not monotone/complete, "
-                                    "or an edge leaves its graph", err);
+        return fail(GNNB_ERR_GRAPH, "malformed batch (flags 0x%x): 1/2 ptr arrays not monotone/complete, 4 an edge leaves "
+                                    "its graph, 8 a graph exceeds the max_graph_nodes promise, 16 the large-segment offsets "
+                                    "disagree with node_ptr / edge_ptr", err);
     return GNNB_OK;
 }
 
@@ -1057,6 +1074,32 @@ static hipError_t launch_conv_stack(const gnnb_model *model, gnnb_workspace *ws,
 static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, float *out_dev,
                                  void *stream);
 
+// The side stream and its fork / join events, only for large_fork = 1 (the default, 2, never uses them): created on first
+// use -- all three or none; a partial failure destroys what was created and the large segment stays on the caller's stream.
+static bool ensure_side_stream(gnnb_workspace *ws)
+{
+    if (ws->side)
+        return true;
+    hipStream_t st = nullptr;
+    hipEvent_t ef = nullptr, ej = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&ef, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&ej, hipEventDisableTiming) == hipSuccess) {
+        ws->side = st;
+        ws->ev_fork = ef;
+        ws->ev_join = ej;
+        return true;
+    }
+    (void)hipGetLastError();
+    if (ej)
+        (void)hipEventDestroy(ej);
+    if (ef)
+        (void)hipEventDestroy(ef);
+    if (st)
+        (void)hipStreamDestroy(st);
+    return false;
+}
+
 int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev,
                           float *out_dev, void *stream)
 {
@@ -1104,29 +1147,24 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
         // The large segment first, FORKED: its kernels are built to run beside the stack kernel (k_conv_rows.hip), so they
         // go on the workspace's side stream behind an event on the caller's stream and are joined in front of the readout.
         // (Capturable: the side stream joins a capture through the event and is joined back.)
-        bool forked = false;
-        if (seg) {
-            if (!ws->side) {
-                if (hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming) != hipSuccess) {
-                    (void)hipGetLastError();
-                    ws->side = nullptr;
-                }
+        bool forked = false, side_forked = false;
+        if (seg && options().large_fork == 1 && ensure_side_stream(ws)) {
+            GNNB_HIP_TRY(hipEventRecord(ws->ev_fork, (hipStream_t)stream));
+            GNNB_HIP_TRY(hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
+            side_forked = true;
+            hipError_t hl = large_segment_small(model, ws, x_dev, ws->side);
+            // (joined whether or not anything ran on the side stream -- also in front of the error return: a side stream
+            // left forked would invalidate a capture in progress)
+            const hipError_t hj = hipEventRecord(ws->ev_join, ws->side);
+            if (hj != hipSuccess || (hl != hipSuccess && hl != hipErrorNotSupported)) {
+                if (hj == hipSuccess)
+                    (void)hipStreamWaitEvent((hipStream_t)stream, ws->ev_join, 0);
+                return fail(GNNB_ERR_HIP, "large-segment launch failed: %s", hipGetErrorString(hl != hipSuccess ? hl : hj));
             }
-            if (ws->side && options().large_fork == 1) {
-                GNNB_HIP_TRY(hipEventRecord(ws->ev_fork, (hipStream_t)stream));
-                GNNB_HIP_TRY(hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
-                hipError_t hl = large_segment_small(model, ws, x_dev, ws->side);
-                if (hl != hipSuccess && hl != hipErrorNotSupported)
-                    return fail(GNNB_ERR_HIP, "large-segment launch failed: %s", hipGetErrorString(hl));
-                forked = hl == hipSuccess;
-                // (joined below whether or not anything ran on the side stream: the wait is on what was recorded)
-                GNNB_HIP_TRY(hipEventRecord(ws->ev_join, ws->side));
-            }
+            forked = hl == hipSuccess;
         }
         hipError_t he = launch_conv_stack(model, ws, small_segment(ws), x_dev, deep, (hipStream_t)stream, &ws->last_path);
-        if (seg && ws->side && options().large_fork == 1)
+        if (side_forked)
             GNNB_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ws->ev_join, 0));
         if (he == hipSuccess) {
             if (seg && !forked && options().large_fork == 2) { // the small kernels on the caller's stream, behind the stack

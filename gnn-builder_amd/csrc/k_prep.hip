@@ -237,7 +237,11 @@ __device__ __forceinline__ void prep_graph_small(
         // default record: unused source slots alias the node itself
         *reinterpret_cast<int4 *>(s_first + lane * 4) = make_int4(v, v, v, v);
     }
+    // (the exchange through s_first crosses lanes: wave_barrier alone is not a memory ordering at the IR level, so each
+    // hand-over is a wavefront-scope release / acquire pair -- no instruction on the device, only a compiler ordering)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- scatter: col[start[dst] + rank] = src (one store per edge lane), first four sources -> the node's record
     const int st = __shfl(start, d, 64);
     if (keep) {
@@ -246,7 +250,9 @@ __device__ __forceinline__ void prep_graph_small(
         if (rank < 4)
             s_first[d * 4 + rank] = src;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < n) {
         const int4 f = *reinterpret_cast<const int4 *>(s_first + lane * 4);
         node_rec[2 * (size_t)(n0 + lane)] = make_int4(start, deg, f.x, f.y);
@@ -274,8 +280,8 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     int32_t *__restrict__ col, int32_t *__restrict__ eid, int4 *__restrict__ node_rec, float *__restrict__ dinv,
     float *__restrict__ amp, float *__restrict__ att, float delta,
     int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int32_t *__restrict__ tile_graph,
-    int32_t *__restrict__ graph_ptr, int tile_rows, int num_tiles, int max_graph_nodes_hint, int promise_graphs, int drop_self,
-    int32_t *__restrict__ err, int32_t *__restrict__ err_host)
+    int32_t *__restrict__ graph_ptr, int tile_rows, int num_tiles, int max_graph_nodes_hint, int promise_graphs, int large_n,
+    int large_e, int drop_self, int32_t *__restrict__ err, int32_t *__restrict__ err_host)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node (read / written 16 B at a time)
     // Highest wave priority: with batches in flight on several streams this kernel runs BESIDE the conv-stack kernel of
@@ -305,6 +311,12 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
         if (lane == 0)
             graph_ptr[g] = p; // the clamped copy later kernels read
     }
+    // The caller's large segment (gnnb_workspace_set_large_segment) names its first graph AND that graph's node / edge
+    // offsets; the stack kernels run on rows [0, large_n) and the layer-wise half on the rest.  A triple that disagrees
+    // with the ptr arrays of THIS batch (stale workspace state from the batch before) would leave the rows between the two
+    // boundaries to neither half: flagged here, where both arrays are read anyway.
+    if (large_n >= 0 && g == promise_graphs && lane == 0 && (node_ptr[g] != large_n || edge_ptr[g] != large_e))
+        flag_batch(err, err_host, 16);
     // Containment of malformed batches: whatever node_ptr / edge_ptr hold, every row in [0, N) leaves this
     // kernel with a record that later kernels can follow without leaving the buffers -- start and start + deg
     // inside [0, E], sources inside [0, N).  A graph's ranges are CLAMPED instead of rejected (any row r < N lies
@@ -459,7 +471,9 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- scatter: col[start[dst] + rank] = src, one store instruction per 64 edges
 #pragma unroll
     for (int c = 0; c < EC; c++) {
@@ -480,7 +494,9 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int q = 0; q < NC; q++) {
         const int vl = q * 64 + lane;
@@ -506,12 +522,12 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
         hipLaunchKernelGGL(k_graph_prep<64>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, drop_self_loops, t.err, t.err_host_dev);
+                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, t.large_n, t.large_e, drop_self_loops, t.err, t.err_host_dev);
     else
         hipLaunchKernelGGL(k_graph_prep<256>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, drop_self_loops, t.err, t.err_host_dev);
+                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, t.large_n, t.large_e, drop_self_loops, t.err, t.err_host_dev);
     return hipGetLastError();
 }
 

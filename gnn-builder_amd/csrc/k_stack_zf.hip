@@ -57,38 +57,56 @@ namespace gnnb {
 #ifndef ZF_PRIO
 #define ZF_PRIO 2
 #endif
+// build-time switches: measured alternatives of this kernel, kept compilable (same-box A/B on BASELINE config 2, wide shape:
+// DESIGN 3.5a "round 4")
+#ifndef ZF_K12         // input widths <= 12: three MFMA k steps per unit in M0 (k = lg + 4 t) instead of four: 38.9 -> 38.55 us
+#define ZF_K12 1
+#endif
+#ifndef ZF_DMA_IN_M1   // the next stage's DMA issued behind the H barrier instead of at the stage top: +-0 (wide), -0.25 us (96-row shape)
+#define ZF_DMA_IN_M1 1
+#endif
+#ifndef ZF_SWZ         // H / Z rows unpadded, 16-B chunks XOR-swizzled by the row index: LDS bank conflicts 28 % -> 0 and the
+#define ZF_SWZ 0       // kernel 1.7 us SLOWER (38.8 -> 40.5 us, 117 VGPRs): the conflicts sit in M1's fragment reads, where the
+#endif                 // LDS array is < 25 % busy -- they cost nothing; the swizzle's address arithmetic does
 
 // accumulate NU 16-row units (rows row0[k] + li) x the wave's 16-column slice over K = 16 KQ:
 // acc[k] += Wslice . A[rows of unit k][:]^T -- the TRANSPOSED tile (weight fragment as the first MFMA operand), so that
 // lane (li, lg) ends up with FOUR CONSECUTIVE columns 16 s + 4 lg .. + 3 of row row0[k] + li: the tile goes back to LDS as
 // one conflict-free ds_write_b128 per lane and unit instead of four ds_write_b32 (64 B/clk/CU; the H and Z write-backs
 // were ~1 k cycles per stage each).  Fragments of k block q+1 are requested before the MFMAs of block q.
+// kmask >= 0: the rows of A are stored with their 16-B chunks XOR-swizzled by (row & kmask) (row0 multiples of 16, so the
+// key of a lane's row is li & kmask): chunk 4 q + lg of the row sits at 4 (q ^ kq) + (lg ^ (li & 3)), kq = (li >> 2) & (kmask >> 2)
 template <int KQ, int NU>
 __device__ __forceinline__ void zf_mma(const float *__restrict__ A, int lda, const float (&wr)[KQ * 4], const int (&row0)[NU],
-                                       int li, int lg, f32x4 (&acc)[NU])
+                                       int li, int lg, f32x4 (&acc)[NU], int nt = 4, int kmask = -1)
 {
     const float *ap[NU];
+    const int lgs = kmask >= 0 ? (lg ^ (li & 3 & kmask)) : lg;
+    const int kq = kmask >= 0 ? ((li >> 2) & (kmask >> 2)) : 0;
 #pragma unroll
     for (int k = 0; k < NU; k++)
-        ap[k] = A + (row0[k] + li) * lda + lg * 4;
+        ap[k] = A + (row0[k] + li) * lda + lgs * 4;
     float4 a4[NU], an[NU];
 #pragma unroll
     for (int k = 0; k < NU; k++)
-        a4[k] = *reinterpret_cast<const float4 *>(ap[k]);
+        a4[k] = *reinterpret_cast<const float4 *>(ap[k] + 16 * kq);
 #pragma unroll
     for (int q = 0; q < KQ; q++) {
         if (q + 1 < KQ) {
 #pragma unroll
             for (int k = 0; k < NU; k++)
-                an[k] = *reinterpret_cast<const float4 *>(ap[k] + 16 * (q + 1));
+                an[k] = *reinterpret_cast<const float4 *>(ap[k] + 16 * ((q + 1) ^ kq));
         }
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < 4; t++) {
+            if (t >= nt) // (wave-uniform; nt = 3: the block's fourth k step holds zeros on both sides -- narrow inputs, ZF_K12)
+                break;
 #pragma unroll
             for (int k = 0; k < NU; k++) {
                 const float av = t == 0 ? a4[k].x : (t == 1 ? a4[k].y : (t == 2 ? a4[k].z : a4[k].w));
                 acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + t], av, acc[k], 0, 0, 0);
             }
+        }
         if (q + 1 < KQ) {
 #pragma unroll
             for (int k = 0; k < NU; k++)
@@ -141,11 +159,26 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const int rows_b = xs_b + ZF_CAP * 32;
     constexpr int small_b = ZF_CAP * 4 + ((GMAX + 1) * 4 + 15) / 16 * 16;
     constexpr int a0_b = ZF_CAP * LD0 * 4;
+#if ZF_SWZ
+    // H / Z rows: 32, 64 or 128 floats, NOT padded; the 16-B chunks of row r are stored XOR-swizzled by r & kmask.  A
+    // ds_read_b128 is served in four groups of sixteen lanes ({0-3, 12-15, 20-27}, ...): the fragment reads of M0 / M1 put
+    // rows {-4..3} at chunk lg and rows {4..11} at chunk lg + 1 into one group -- with a padded row (33 slots) two of the
+    // sixteen always met on one slot (28 % of the kernel's LDS cycles were conflicts); XOR by the row index maps the two
+    // row sets onto disjoint slot sets whatever the chunk.  The region starts on a 512-B boundary so that a row's base
+    // and its key do not share bits: P1 forms a neighbour's address as (record offset) ^ (the lane's chunk << 4).
+    const int ldh = (h0 > 64 || h1 > 64) ? 128 : ((h0 > 32 || h1 > 32) ? 64 : 32);
+    const int kmask = (ldh >= 64 ? 16 : 8) - 1;
+    const int hoff = (rows_b + 2 * small_b + a0_b + 511) & ~511;
+#else
     const int ldh = (h0 > h1 ? h0 : h1) + 4; // padded H / Z row (floats): conflict-free fragment reads, base + immediate
+    const int kmask = -1;
+    const int hoff = rows_b + 2 * small_b + a0_b;
+#endif
     const int ldhb = ldh * 4;
+    auto hswz = [&](int row) { return ZF_SWZ ? ((row & kmask) << 4) : 0; }; // a row's key, as a byte offset
     constexpr int rec_b = ZF_CAP * 48;
     float *A0 = reinterpret_cast<float *>(smem + rows_b + 2 * small_b);
-    float *H = reinterpret_cast<float *>(smem + rows_b + 2 * small_b + a0_b);
+    float *H = reinterpret_cast<float *>(smem + hoff);
     char *RECb = reinterpret_cast<char *>(H) + ZF_CAP * ldhb;
     constexpr int ECAP = ZF_CAP <= 96 ? 512 : 1024;
     char *SCOLb = RECb + 2 * rec_b;
@@ -268,6 +301,9 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         return st;
     };
     // the stage's rows (x, node records) -> ROWS
+    // (round 4: the same bytes as 16-B LDS-DMA pieces dealt one per wave -- 16 instructions per stage instead of ~40, the
+    // global side of global_load_lds_dwordx4 takes dword-aligned addresses -- are SLOWER, 40.4 vs 39.9 us: the issue phase
+    // grew from 0.9-2.2 k to 1.2-3.6 k cycles per wave; misaligned 16-B pieces cost the issuing wave more than four dword ones)
     auto issue_rows = [&](const ZfStage &st, int bb, int lane, int wave) {
         if (!st.ok)
             return;
@@ -286,12 +322,12 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         // (a stage may have NO rows and still own graphs: empty graphs behind a graph that ends on the
         // tile edge -- their boundaries are still needed by the pooling)
         char *base = smem + rows_b + (size_t)bb * small_b;
+        const int ng = min(st.gb - st.ga, GMAX) + 1;
         // 64-dword pieces, one per wave from wave 3 on: ND pieces of dinv, then NG pieces of the graph boundaries of
         // the stage (first GMAX graphs; more only if empty graphs pile up, those are read from global memory)
         constexpr int ND = (ZF_CAP + 63) / 64, NG = (GMAX + 1 + 63) / 64;
         static_assert(3 + ND + NG <= NW, "one small-DMA piece per wave");
         const int pc = wave - 3;
-        const int ng = min(st.gb - st.ga, GMAX) + 1;
         if (pc >= 0 && pc < ND) {
             if (pc * 64 + lane < st.rows)
                 dma4_to_lds_u(dinv + st.nb + pc * 64 + lane, base + pc * 256);
@@ -332,10 +368,23 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         const int n0c = (wave & ((1 << cs0l) - 1)) * 16 + li, n1c = (wave & ((1 << cs1l) - 1)) * 16 + li;
 #pragma unroll
         for (int q = 0; q < KQ0; q++) {
-            const int k = 16 * q + 4 * lg;
+            [[maybe_unused]] const int k = 16 * q + 4 * lg;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#if ZF_K12
+            // k step t of block q multiplies input feature 16 q + lg + 4 t (A0 is stored to match, phase_p0): a model of
+            // up to 12 input features (QM9: 11) leaves the fourth step of its only block empty -- M0 skips it
+            if (n0c < h0) {
+                const float *wrow = W0 + (size_t)n0c * f0;
+                const int kk = 16 * q + lg;
+                v.x = kk < f0 ? wrow[kk] : 0.f;
+                v.y = kk + 4 < f0 ? wrow[kk + 4] : 0.f;
+                v.z = kk + 8 < f0 ? wrow[kk + 8] : 0.f;
+                v.w = kk + 12 < f0 ? wrow[kk + 12] : 0.f;
+            }
+#else
             if (n0c < h0)
                 v = load4_guard(W0 + (size_t)n0c * f0 + k, f0 - k, false);
+#endif
             w0r[q * 4 + 0] = v.x;
             w0r[q * 4 + 1] = v.y;
             w0r[q * 4 + 2] = v.z;
@@ -438,10 +487,21 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #pragma unroll
                 for (int t = 0; t < T0; t++) {
                     const int f = l8 + 8 * t;
-                    A0[i * LD0 + f] = f < f0 ? acc[t] + xself[t] * (di * di) : 0.0f;
+#if ZF_K12
+                    const int fp = (f & ~15) | ((f & 3) << 2) | ((f >> 2) & 3); // (feature lg + 4 t sits at position 4 lg + t of its block)
+#else
+                    const int fp = f;
+#endif
+                    A0[i * LD0 + fp] = f < f0 ? acc[t] + xself[t] * (di * di) : 0.0f;
                 }
                 if (l8 == 0) {
+#if ZF_SWZ
+                    // (LDS byte address of the neighbour's row + its swizzle key: P1 XORs its chunk offset in)
+                    REC[3 * i] = make_int4(hoff + jl[0] * ldhb + hswz(jl[0]), hoff + jl[1] * ldhb + hswz(jl[1]),
+                                           hoff + jl[2] * ldhb + hswz(jl[2]), hoff + jl[3] * ldhb + hswz(jl[3]));
+#else
                     REC[3 * i] = make_int4(jl[0] * ldhb, jl[1] * ldhb, jl[2] * ldhb, jl[3] * ldhb);
+#endif
                     REC[3 * i + 1] = make_int4(__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]), __float_as_int(c[3]));
                     REC[3 * i + 2] = make_int4(__float_as_int(di * di), r0.x, deg, __float_as_int(di));
                 }
@@ -452,6 +512,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #ifdef GNNB_PROBE
     unsigned long long pt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = clock64(), pw0 = wall_clock64(), pt_last = pt0;
     int nst = 0;
+    unsigned long long prows = 0, pgraphs = 0, punits = 0;
 #define ZF_PT(i) do { const unsigned long long _n = clock64(); pt[i] += _n - pt_last; pt_last = _n; } while (0)
 #else
 #define ZF_PT(i) do { } while (0)
@@ -502,15 +563,23 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         const int li = tv & 15, lg = (tv >> 4) & 3, wv = __builtin_amdgcn_readfirstlane(tv >> 6);
         const int rows = cur.rows, nb = cur.nb;
         const int units = (rows + 15) >> 4;
+#ifdef GNNB_PROBE
+        prows += rows;
+        pgraphs += cur.gb - cur.ga;
+        punits += units;
+#endif
         // ---- top: the next stage's inputs start their way to LDS (ROWS: P0 of `cur` was its last reader)
+#if !ZF_DMA_IN_M1
         issue_small(nxt, b ^ 1, tv & 63, wv);
         issue_rows(nxt, b ^ 1, tv & 63, wv);
+#endif
         ZF_PT(1);
 
         // ---- M0: H = act(A0 . W0^T + b0)   (wave: column slice x row group)
         if (ZF_ON(3)) {
             const int n0c = (wv & ((1 << cs0l) - 1)) * 16 + li;
             const int rg0 = wv >> cs0l;
+            const int nt0 = (ZF_K12 && KQ0 == 1 && f0 <= 12) ? 3 : 4;
             auto m0 = [&](auto nutag, int ubase) {
                 constexpr int NU = decltype(nutag)::value;
                 int row0[NU];
@@ -523,15 +592,16 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     row0[k] = (rg0 + (ubase + k) * nrg0) * 16;
                     acc[k] = (f32x4){bias0.x, bias0.y, bias0.z, bias0.w};
                 }
-                zf_mma<KQ0, NU>(A0, LD0, w0r, row0, li, lg, acc);
+                zf_mma<KQ0, NU>(A0, LD0, w0r, row0, li, lg, acc, nt0);
                 if (n0c < h0) { // (h0 is 32, 64 or 128: the lane's four columns are all inside when its slice is)
 #pragma unroll
                     for (int k = 0; k < NU; k++)
-                        *reinterpret_cast<float4 *>(H + (row0[k] + li) * ldh + (n0c - li) + 4 * lg) =
+                        *reinterpret_cast<float4 *>(H + (row0[k] + li) * ldh + (ZF_SWZ ? 4 * ((((n0c - li) >> 2) + lg) ^ (li & kmask)) : (n0c - li) + 4 * lg)) =
                             make_float4(act_t<ACT>(acc[k][0]), act_t<ACT>(acc[k][1]), act_t<ACT>(acc[k][2]), act_t<ACT>(acc[k][3]));
                 }
             };
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) >> lnrg0 : 0; // (nrg0 is a power of two)
+
             // (units in groups of three: register budget)
             if (nu >= 3)
                 m0(IntTag<3>{}, 0);
@@ -549,6 +619,14 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         ZF_PT(2);
         g2_barrier(); // H complete
         ZF_PT(3);
+#if ZF_DMA_IN_M1
+        // ---- the next stage's inputs start their way to LDS HERE (ROWS: P0 of `cur` was its last reader): at the stage top
+        // the ~40 scalar / vector instructions and two or three LDS-DMA issues per wave stood in front of M0 with nothing
+        // beside them (0.9-2.2 k cycles per stage); here they run beside the other waves' MFMA stream, and the data still
+        // has all of M1 to land
+        issue_small(nxt, b ^ 1, tv & 63, wv);
+        issue_rows(nxt, b ^ 1, tv & 63, wv);
+#endif
 
         // ---- M1: Z = H . W1^T for the wave's column slice and its units: stays in the accumulators across the barrier
         // (the ONLY phase at low priority: see the note on s_setprio at the top of the stage loop)
@@ -572,7 +650,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     row0[k] = (rg1 + (UB + k) * nrg1) * 16;
                     acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                zf_mma<KQ1, NU>(H, ldh, w1r, row0, li, lg, acc);
+                zf_mma<KQ1, NU>(H, ldh, w1r, row0, li, lg, acc, 4, kmask);
 #pragma unroll
                 for (int k = 0; k < NU; k++)
                     if (UB + k < ZMAX)
@@ -604,7 +682,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #pragma unroll
             for (int k = 0; k < ZMAX; k++)
                 if (k < nu1)
-                    *reinterpret_cast<float4 *>(H + ((rg1 + k * nrg1) * 16 + li) * ldh + (n1c - li) + 4 * lg) =
+                    *reinterpret_cast<float4 *>(H + ((rg1 + k * nrg1) * 16 + li) * ldh + (ZF_SWZ ? 4 * ((((n1c - li) >> 2) + lg) ^ (li & kmask)) : (n1c - li) + 4 * lg)) =
                         make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
         }
         g2_barrier(); // Z complete
@@ -627,6 +705,9 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             // SIMDs have to issue -- shared with the MFMA stream of the co-resident workgroup --, not by the longest wave,
             // and every task pays ~150 instructions of set-up, combine and stores: one part per graph for the four or
             // five graphs of a BASELINE config 2 stage, 42.4 instead of 43.3 us)
+            // (round 4, wide shape: letting the parts fill ALL sixteen waves -- eight graphs x two parts -- is 0.25 us SLOWER,
+            // 40.15 vs 39.9 us: the row walk of a task shortens from 4.1 k to 2.9 k cycles, but every task pays its ~1.9 k
+            // cycles of set-up, combine and stores, and the next stage's P0 loses its idle waves)
             while (pow2 && csl < 2 && (ngr << (csl + 1)) <= G2_NW / 2 && (nv >> (csl + 1)) >= 4)
                 csl++;
         }
@@ -663,7 +744,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                 r1g = min(__builtin_amdgcn_readfirstlane(r1g) - nb, rows);
                 const bool lane_on = gl * 4 < wpart;
                 const int col0 = lane_on ? cpart * wpart + gl * 4 : 0; // this lane's first column
-                const char *Hl = reinterpret_cast<const char *>(H) + col0 * 4; // its chunk of row 0
+                const char *Hl = reinterpret_cast<const char *>(H) + col0 * 4; // its chunk of row 0 (unswizzled layout)
+                [[maybe_unused]] const int cx = col0 * 4; // its chunk as a byte offset inside a row: XORed into a row's swizzled base
+                // (LDS byte address of this lane's chunk of row i)
+                auto hrow = [&](int i) { return ZF_SWZ ? smem + ((hoff + i * ldhb + hswz(i)) ^ cx) : Hl + i * ldhb; };
                 const float4 bias = *reinterpret_cast<const float4 *>(SB1 + col0);
                 V sum = V::splat(0.0f), mx = V::splat(-INFINITY);
 #ifdef GNNB_ZF_ABLATE
@@ -677,31 +761,63 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                 // waves of the SIMD cover the two LDS round trips), full passes without predication and one predicated
                 // tail pass, maxima through v_max_f32 directly (fmaxf adds a canonicalising v_max per operand).
                 const char *prec = reinterpret_cast<const char *>(REC) + (r0g + sr) * 48;
+#if ZF_SWZ
+                int pself = r0g + sr; // (the row index: its address is formed per pass, the key changes with the row)
+                const int dself = S;
+#else
                 const char *pself = Hl + (r0g + sr) * ldhb;
-                const int dself = ldhb << (6 - glog2), drec = 48 << (6 - glog2);
+                const int dself = ldhb << (6 - glog2);
+#endif
+                const int drec = 48 << (6 - glog2);
                 auto vmax_raw = [](float a, float b2) {
                     float r;
                     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b2));
                     return r;
                 };
-                auto one_row = [&](bool active) {
-                    const int4 ja = *reinterpret_cast<const int4 *>(prec);
-                    const int4 ca = *reinterpret_cast<const int4 *>(prec + 16);
-                    const int4 da = *reinterpret_cast<const int4 *>(prec + 32);
-                    const V n0 = V::load(reinterpret_cast<const float *>(Hl + ja.x)); // unused slots alias the row itself (coefficient 0)
-                    const V n1 = V::load(reinterpret_cast<const float *>(Hl + ja.y));
-                    const V n2 = V::load(reinterpret_cast<const float *>(Hl + ja.z));
-                    const V n3 = V::load(reinterpret_cast<const float *>(Hl + ja.w));
-                    const V self = V::load(reinterpret_cast<const float *>(pself));
+                // one pass = S rows (one per lane group), in three steps: the records, the rows, the arithmetic.  (Round 4:
+                // TWO passes in flight -- records of both, rows of both, then the arithmetic -- buy 0.1 us, 38.6 vs 38.7,
+                // for 118 instead of 95 VGPRs, which closes the 96-register wave slot of the other batches' kernels: not kept.)
+                struct RowRec { int4 ja, ca, da; };
+                struct RowDat { V n0, n1, n2, n3, self; };
+                auto load_rec = [&](const char *pr) {
+                    RowRec r;
+                    r.ja = *reinterpret_cast<const int4 *>(pr);
+                    r.ca = *reinterpret_cast<const int4 *>(pr + 16);
+                    r.da = *reinterpret_cast<const int4 *>(pr + 32);
+                    return r;
+                };
+#if ZF_SWZ
+                auto load_rows = [&](const RowRec &r, int ps) {
+                    RowDat d;
+                    d.n0 = V::load(reinterpret_cast<const float *>(smem + (r.ja.x ^ cx))); // unused slots alias the row itself (coefficient 0)
+                    d.n1 = V::load(reinterpret_cast<const float *>(smem + (r.ja.y ^ cx)));
+                    d.n2 = V::load(reinterpret_cast<const float *>(smem + (r.ja.z ^ cx)));
+                    d.n3 = V::load(reinterpret_cast<const float *>(smem + (r.ja.w ^ cx)));
+                    d.self = V::load(reinterpret_cast<const float *>(hrow(ps)));
+                    return d;
+                };
+#else
+                auto load_rows = [&](const RowRec &r, const char *ps) {
+                    RowDat d;
+                    d.n0 = V::load(reinterpret_cast<const float *>(Hl + r.ja.x)); // unused slots alias the row itself (coefficient 0)
+                    d.n1 = V::load(reinterpret_cast<const float *>(Hl + r.ja.y));
+                    d.n2 = V::load(reinterpret_cast<const float *>(Hl + r.ja.z));
+                    d.n3 = V::load(reinterpret_cast<const float *>(Hl + r.ja.w));
+                    d.self = V::load(reinterpret_cast<const float *>(ps));
+                    return d;
+                };
+#endif
+                auto finish_row = [&](const RowRec &r, const RowDat &d, bool active) {
+                    const int4 ca = r.ca, da = r.da;
                     V acc;
                     acc.v = bias;
-                    acc = vadd(acc, vmul(n0, V::splat(__int_as_float(ca.x))));
-                    acc = vadd(acc, vmul(n1, V::splat(__int_as_float(ca.y))));
-                    acc = vadd(acc, vmul(n2, V::splat(__int_as_float(ca.z))));
-                    acc = vadd(acc, vmul(n3, V::splat(__int_as_float(ca.w))));
+                    acc = vadd(acc, vmul(d.n0, V::splat(__int_as_float(ca.x))));
+                    acc = vadd(acc, vmul(d.n1, V::splat(__int_as_float(ca.y))));
+                    acc = vadd(acc, vmul(d.n2, V::splat(__int_as_float(ca.z))));
+                    acc = vadd(acc, vmul(d.n3, V::splat(__int_as_float(ca.w))));
                     if (da.z > 4) { // degree > 4: the rest of the CSR row (slice of `col` in LDS; two loops, see P0)
                         auto more = [&](int j) {
-                            acc = vadd(acc, vmul(V::load(reinterpret_cast<const float *>(Hl + j * ldhb)),
+                            acc = vadd(acc, vmul(V::load(reinterpret_cast<const float *>(hrow(j))),
                                                  V::splat(__int_as_float(da.w) * sdinv[j])));
                         };
                         if (col_lds) {
@@ -712,7 +828,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                                 more(col[k] - nb);
                         }
                     }
-                    acc = vadd(acc, vmul(self, V::splat(__int_as_float(da.x))));
+                    acc = vadd(acc, vmul(d.self, V::splat(__int_as_float(da.x))));
                     V o;
                     o.v = make_float4(act_t<ACT>(acc.v.x), act_t<ACT>(acc.v.y), act_t<ACT>(acc.v.z), act_t<ACT>(acc.v.w));
                     if (active) {
@@ -720,12 +836,18 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                         mx.v = make_float4(vmax_raw(mx.v.x, o.v.x), vmax_raw(mx.v.y, o.v.y), vmax_raw(mx.v.z, o.v.z), vmax_raw(mx.v.w, o.v.w));
                     }
                 };
+                auto one_row = [&](bool active) {
+                    const RowRec r = load_rec(prec);
+                    const RowDat d = load_rows(r, pself);
+                    finish_row(r, d, active);
+                };
 #ifdef GNNB_PROBE
                 const unsigned long long pl0 = clock64();
 #endif
                 const int nfull = n >> (6 - glog2), ntail = n & (S - 1);
+                int it = 0;
 #pragma unroll 1
-                for (int it = 0; it < nfull; it++) {
+                for (; it < nfull; it++) {
                     one_row(true);
                     prec += drec;
                     pself += dself;
@@ -734,7 +856,11 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     const bool active = sr < ntail;
                     if (!active) { // (inactive lane groups re-read the graph's first row)
                         prec = reinterpret_cast<const char *>(REC) + r0g * 48;
+#if ZF_SWZ
+                        pself = r0g;
+#else
                         pself = Hl + r0g * ldhb;
+#endif
                     }
                     one_row(active);
                 }
@@ -828,7 +954,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             o[2 + i] = pt[i];
         o[13] = clock64() - pt0;
         o[14] = (unsigned long long)nst;
-        o[15] = 0;
+        o[15] = prows | (pgraphs << 32) | (punits << 48);
     }
 #endif
 }
@@ -904,9 +1030,15 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
     const int gmax = cap <= 96 ? 64 : 128;
     const int xs_b = ((cap * f0 * 4) + 15) & ~15;
     const int rows_b = xs_b + cap * 32, small_b = cap * 4 + ((gmax + 1) * 4 + 15) / 16 * 16;
+#if ZF_SWZ
+    const int ldh = (h0 > 64 || h1 > 64) ? 128 : ((h0 > 32 || h1 > 32) ? 64 : 32); // (as the kernel's carve)
+    const size_t hoff = ((size_t)rows_b + 2 * (size_t)small_b + (size_t)cap * 16 * kq0 * 4 + 511) & ~(size_t)511;
+#else
     const int ldh = (h0 > h1 ? h0 : h1) + 4;
+    const size_t hoff = (size_t)rows_b + 2 * (size_t)small_b + (size_t)cap * 16 * kq0 * 4;
+#endif
     const int ecap = cap <= 96 ? 512 : 1024;
-    const size_t lds = (size_t)rows_b + 2 * (size_t)small_b + (size_t)cap * 16 * kq0 * 4 + (size_t)cap * ldh * 4 +
+    const size_t lds = hoff + (size_t)cap * ldh * 4 +
                        2 * (size_t)cap * 48 + 2 * (size_t)ecap * 4 + 512 + 32 + 512 + 768;
 
     if (lds > 160 * 1024)

@@ -382,9 +382,14 @@ class CompiledModel:
         import torch
         _require(x, "x", torch.float32, 2)
         w = int(x.shape[1])
+        # (raw pointers cross the C ABI: the kernel reads x[j * w] for every source j of the prepared batch)
+        if int(x.shape[0]) != self._N:
+            raise GnnbError(f"x has {int(x.shape[0])} rows, the prepared batch has {self._N} nodes")
         ow = 4 * w if kind == "pna" else w
         if self_term is not None:
             _require(self_term, "self_term", torch.float32, 2, w)
+            if int(self_term.shape[0]) != self._N or self_term.device != x.device:
+                raise GnnbError(f"self_term must be [{self._N}, {w}] on {x.device}")
         if out is None:
             out = torch.empty((x.shape[0], ow), dtype=torch.float32, device=x.device)
         else:

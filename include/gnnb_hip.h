@@ -42,7 +42,8 @@ typedef enum gnnb_status {
     GNNB_ERR_CAPACITY = -2,  /* batch exceeds the workspace (reference: silent overflow) */
     GNNB_ERR_HIP = -3,       /* a HIP runtime call failed */
     GNNB_ERR_NO_DEVICE = -4, /* no gfx950 device visible */
-    GNNB_ERR_GRAPH = -5      /* malformed batch: an edge leaves its graph, ptr not monotone */
+    GNNB_ERR_GRAPH = -5      /* malformed batch: an edge leaves its graph, ptr not monotone, a broken max_graph_nodes
+                              * promise, a large-segment triple that disagrees with the ptr arrays */
 } gnnb_status;
 
 /* gnnbuilder/models.py:453-459 (SUPPORTED_GNN_CONVS; GAT has no native path in the
@@ -129,7 +130,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
 void gnnb_workspace_destroy(gnnb_workspace *ws);
 size_t gnnb_workspace_bytes(const gnnb_workspace *ws);
 /* Promise that no graph of the batches run on this workspace has more than `n` nodes (0 = no
- * promise, the default).  Small molecules (n <= 61; 45 in the opt-in bf16x6 math mode; 169 for a 2-layer fp32 GCN) let whole graphs be staged in LDS, which enables
+ * promise, the default).  Small molecules (n <= 61; 45 in the opt-in bf16x6 math mode; for a 2-layer fp32 GCN 169 with in_dim <= 16 and 89 with in_dim 17..32) let whole graphs be staged in LDS, which enables
  * the fused conv-stack kernels.  The promise is VALIDATED on the device by every graph prep: a
  * larger graph makes gnnb_workspace_check() return GNNB_ERR_GRAPH (the reference's MAX_NODES, by
  * contrast, is never checked: model.cpp.jinja:5-22).  Callers that never call the check still find out: the NEXT
@@ -145,7 +146,7 @@ enum {
     GNNB_PATH_NONE = 0,      /* no forward yet */
     GNNB_PATH_LAYERWISE = 1, /* per layer: gather-aggregate + GEMM kernels */
     GNNB_PATH_STACK = 2,     /* whole conv stack + pooling in k_gcn2_fused (GCN / GIN, graphs <= 61 nodes) */
-    GNNB_PATH_STACK_ZF = 3,  /* 2-layer fp32 GCN in k_gcn2_zf (last layer transformed before aggregation, graphs <= 169 nodes) */
+    GNNB_PATH_STACK_ZF = 3,  /* 2-layer fp32 GCN in k_gcn2_zf (last layer transformed before aggregation, graphs <= 169 nodes for in_dim <= 16, <= 89 for in_dim 17..32) */
     GNNB_PATH_LARGE_LAYERWISE = 16 /* flag, or-ed to a STACK value: the batch had a large segment that ran layer by layer */
 };
 int gnnb_workspace_last_path(const gnnb_workspace *ws);
@@ -157,6 +158,10 @@ int gnnb_workspace_last_path(const gnnb_workspace *ws);
  * (still validated on the device) and run in the stack kernel; graphs [first_graph, num_graphs) are unrestricted and run
  * through the layer-by-layer kernels; both halves fill one pooled matrix and share the readout.  The setting applies to
  * every following gnnb_graph_prep / forward on the workspace until it is changed; first_graph < 0 removes it.  The
+ * triple must describe the batch it is used with: every graph prep checks ON THE DEVICE that first_node ==
+ * node_ptr[first_graph] and first_edge == edge_ptr[first_graph] and flags the batch otherwise (GNNB_ERR_GRAPH from
+ * gnnb_workspace_check, flag bit 16) -- a triple left over from the batch before would otherwise leave the rows between the
+ * two boundaries to neither half.  The
  * reference has no counterpart: its MAX_NODES is a compile-time array bound of the generated model
  * (templates/model.cpp.jinja:5-22), any graph up to it takes the same dataflow.
  * (gnnbuilder_amd.batching.order_large_last does the ordering and returns the three numbers and the permutation.) */

@@ -699,7 +699,10 @@ def test_fused_narrow_layer_equals_separate_kernels(dev, conv, fin):
 
 @pytest.mark.parametrize("fin,h0,h1,act,pools", [(11, 128, 128, "relu", ("add", "mean", "max")), (9, 64, 64, "tanh", ("max", "add")),
                                                  (11, 32, 128, "gelu", ("mean",)), (20, 128, 64, "sigmoid", ("add", "mean", "max")),
-                                                 (11, 64, 20, "relu", ("add",))])
+                                                 (11, 64, 20, "relu", ("add",)),
+                                                 # (either side of the three-k-step form of the narrow product: widths <= 12 / 13..16)
+                                                 (12, 64, 128, "relu", ("add", "max")), (13, 128, 64, "relu", ("mean", "max")),
+                                                 (16, 32, 32, "tanh", ("add",)), (4, 128, 128, "relu", ("max",))])
 @pytest.mark.parametrize("pad_to_tile", [False, True])
 @pytest.mark.parametrize("zf", [1, 2, 0])
 def test_fused_gcn_stack_equals_layerwise_and_oracle(dev, fin, h0, h1, act, pools, pad_to_tile, zf):
@@ -1347,6 +1350,33 @@ def test_large_segment_edge_cases(dev):
     cm2.forward(*to_dev(batch, dev))
     with pytest.raises(runtime.GnnbError):
         cm2.check()
+
+
+def test_stale_large_segment_triple_is_flagged(dev):
+    """The large-segment triple is sticky workspace state (advisor, round 3): a triple left over from ANOTHER batch stays in
+    range but names offsets that are not node_ptr / edge_ptr of its first graph -- the rows between the two boundaries
+    would belong to neither half.  Graph prep checks the triple on the device: the batch is flagged (GNNB_ERR_GRAPH), a
+    triple that matches passes, and so does the same workspace once the segment is re-stated for the new batch."""
+    from gnnbuilder_amd.batching import order_large_last
+    model = make_model("gin", in_dim=9, hidden=64, layers=2, out_dim=64, act="relu", pools=("add",), task_out=2)
+    a = synthetic.make_batch("molhiv_tail", 300, seed=5)
+    b = synthetic.make_batch("molhiv_tail", 300, seed=6)
+    oa, _, (ga, na, ea) = order_large_last(a, 40)
+    ob, permb, (gb, nb_, eb) = order_large_last(b, 40)
+    assert 0 < ga < a.num_graphs and 0 < gb < b.num_graphs and (na, ea) != (int(ob.node_ptr[ga]), int(ob.edge_ptr[ga]))
+    cap = max(oa.num_graphs, ob.num_graphs), max(oa.num_nodes, ob.num_nodes), max(oa.num_edges, ob.num_edges)
+    cm = runtime.CompiledModel.from_model(model, *cap, max_graph_nodes=40)
+    cm.set_large_segment(ga, na, ea)
+    cm.forward(*to_dev(oa, dev))
+    cm.check()  # the triple describes this batch
+    cm.forward(*to_dev(ob, dev))  # ... and is stale for this one (still inside the batch: the host check cannot see it)
+    with pytest.raises(runtime.GnnbError):
+        cm.check()
+    cm.set_large_segment(gb, nb_, eb)
+    out = cm.forward(*to_dev(ob, dev)).cpu().numpy()[np.argsort(permb)]
+    cm.check()
+    ref = O.forward_batched(model.spec(), canon(model), b.x, b.coo, b.node_ptr, b.edge_ptr)
+    assert np.abs(out - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
 
 
 def test_full_size_config3_with_the_heavy_tail(dev):

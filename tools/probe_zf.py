@@ -34,12 +34,19 @@ for i, nm in enumerate(names):
     per = p[:, 2 + i] / (1 if i == 0 else p[:, 14])
     print(f"  {nm:52s} {100 * (p[:, 2 + i] / p[:, 13]).mean():5.1f}%  {per.mean():8.0f} cycles" + ("" if i == 0 else "/stage"))
 rows = (p[:, 15].astype(np.uint64) & np.uint64(0xffffffff)).astype(np.float64)
-graphs = (p[:, 15].astype(np.uint64) >> np.uint64(32)).astype(np.float64)
+graphs = ((p[:, 15].astype(np.uint64) >> np.uint64(32)) & np.uint64(0xffff)).astype(np.float64)
+units = (p[:, 15].astype(np.uint64) >> np.uint64(48)).astype(np.float64)
 end = (p[:, 1] - p[:, 0].min()) / 100
 start = (p[:, 0] - p[:, 0].min()) / 100
 print("lifetime us percentiles 5/25/50/75/95/100:", np.percentile(life, [5, 25, 50, 75, 95, 100]).round(2).tolist())
 print("start us percentiles 50/95/100:", np.percentile(start, [50, 95, 100]).round(2).tolist(), " end us 50/95/100:", np.percentile(end, [50, 95, 100]).round(2).tolist())
 print(f"rows per workgroup {rows.min():.0f}..{rows.max():.0f} (mean {rows.mean():.1f}); corr(lifetime, rows) {np.corrcoef(life, rows)[0, 1]:.2f}, corr(lifetime, graphs) {np.corrcoef(life, graphs)[0, 1]:.2f}, corr(lifetime, start) {np.corrcoef(life, start)[0, 1]:.2f}")
+print(f"units per workgroup {units.min():.0f}..{units.max():.0f} (mean {units.mean():.2f}); corr(lifetime, units) {np.corrcoef(life, units)[0, 1]:.2f}")
+for u in np.unique(units):
+    m = units == u
+    print(f"  units {u:.0f}: {m.sum()} workgroups, lifetime mean {life[m].mean():.2f} us, 95% {np.percentile(life[m], 95):.2f}, max {life[m].max():.2f}; rows {rows[m].mean():.0f}")
+xcd = np.arange(len(life)) % 8
+print("lifetime mean per XCD (block id mod 8):", [round(float(life[xcd == k].mean()), 2) for k in range(8)])
 print("per-wave cycles/stage (mean over workgroups):")
 pa = pall[pall[:, 0, 14] > 0]
 for wv in range(NW):
