@@ -85,33 +85,44 @@ def build_model(w, seed=0):
 
 
 # --------------------------------------------------------------------------------------- roofline legs
+# aggregate kind each workload's layer-by-layer forward runs at its full width (GNNB_AGG_*), and how many [N, w] matrices it writes
+WORKLOAD_AGG = {"gcn": ("gcn", 1), "gin": ("sum", 1), "sage": ("mean", 1), "pna": ("pna", 4)}
+
+
 def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("hbm", "l3_resident"), kind="gcn"):
-    """GCN gather-aggregate at `width`, timed with HIP events on the launch stream.  Returns both
+    """Gather-aggregate of `kind` at `width`, timed with HIP events on the launch stream.  Returns both
     the HBM regime (inputs/outputs rotate over > 256 MiB of distinct buffers) and the regime the
-    kernel sees inside the pipeline (same buffers every launch: Infinity-Cache resident)."""
+    kernel sees inside the pipeline (same buffers every launch: Infinity-Cache resident).
+    Algorithmic bytes as SURVEY.md 8(d): every input row read once + every output row written once (PNA: four output
+    matrices -- max, min, mean, std) + CSR + graph ptr; PNA's per-destination term q [N, w] (the x_i half of the pre-NN,
+    which the kernel reads beside the gathered p rows) is reported separately as `extra_read_bytes`."""
     import torch
 
     x, coo, nptr, eptr = batch_dev
     N, E, B = int(x.shape[0]), int(coo.shape[0]), int(nptr.numel()) - 1
     cm.graph_prep(coo, nptr, eptr, N)
-    # SURVEY.md 8(d): read every input row once + write every output row once + CSR + graph ptr
-    alg_bytes = 4 * width * N + 4 * width * N + 4 * (N + 1) + 4 * E + 4 * (B + 1)
-    per_pair = 2 * 4 * width * N
+    k_out = 4 if kind == "pna" else 1
+    alg_bytes = 4 * width * N + 4 * width * N * k_out + 4 * (N + 1) + 4 * E + 4 * (B + 1)
+    per_pair = 4 * width * N * (1 + k_out)
     nbuf = max(2, int(np.ceil(320 * 2**20 / per_pair)) + 1)
     ins = [torch.rand(N, width, device=dev) * 2 - 1 for _ in range(nbuf)]
-    outs = [torch.empty(N, width, device=dev) for _ in range(nbuf)]
+    outs = [torch.empty(N, width * k_out, device=dev) for _ in range(nbuf)]
+    selfq = torch.rand(N, width, device=dev) * 2 - 1 if kind == "pna" else None
     res = {}
     for regime, n in (("hbm", nbuf), ("l3_resident", 1)):
         if regime not in regimes:
             continue
-        us = cm.aggregate_timed(kind, ins[:n], outs[:n], iters)  # launches issued from C
+        us = cm.aggregate_timed(kind, ins[:n], outs[:n], iters, self_term=selfq)  # launches issued from C
         res[regime] = dict(us=us, gbps=alg_bytes / (us * 1e-6) / 1e9)
+    if selfq is not None:
+        res["extra_read_bytes"] = 4 * width * N
     # calibration with the SAME launch shape and bytes: the library's own float4 row copy (no gather, no CSR)
-    try:
-        us = cm.aggregate_timed("copy", ins, outs, iters)
-        res["copy_same_launch_shape"] = dict(us=us, gbps=per_pair / (us * 1e-6) / 1e9)
-    except Exception:
-        pass
+    if kind != "pna":
+        try:
+            us = cm.aggregate_timed("copy", ins, outs, iters)
+            res["copy_same_launch_shape"] = dict(us=us, gbps=per_pair / (us * 1e-6) / 1e9)
+        except Exception:
+            pass
     del ins, outs
     return alg_bytes, res
 
@@ -519,10 +530,15 @@ def main():
             cm.set_large_segment(*seg)
         bd = tuple(torch.from_numpy(a).to(dev) for a in (batch.x, batch.coo, batch.node_ptr, batch.edge_ptr))
         alg_bytes, agg = measure_aggregate_roofline(cm, bd, w["hidden"], dev, regimes=("hbm",))
+        wkind = WORKLOAD_AGG[w["conv"]][0]
+        own = None
+        if wkind != "gcn":
+            ab, ag = measure_aggregate_roofline(cm, bd, w["hidden"], dev, regimes=("hbm",), kind=wkind)
+            own = {"kind": wkind, "algorithmic_bytes_per_launch": ab, **ag["hbm"]}
         fused = measure_fused_stack(cm, bd, (int(batch.x.shape[1]), w["hidden"], w["hidden"], len(w["pools"])),
                                     conv=w["conv"], layers=w["layers"], seg=seg) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
         print(json.dumps({"roofline_only": True, "workload": args.workload, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"],
-                          "copy_same_launch_shape": agg.get("copy_same_launch_shape"), "fused_stack": fused,
+                          "copy_same_launch_shape": agg.get("copy_same_launch_shape"), "workload_kind": own, "fused_stack": fused,
                           "stack_path": cm.last_path() if fused else None}))
         return
 
@@ -724,6 +740,19 @@ def main():
             "in_pipeline_l3_resident": agg["l3_resident"],
             "copy_ceiling_same_bytes": ceiling,
         }
+        wkind, k_out = WORKLOAD_AGG[w["conv"]]
+        if wkind != "gcn":
+            # the aggregate this workload's layer-by-layer forward actually runs at its full width (SUM / MEAN / PNA with four
+            # output matrices), beside the GCN kind the north star names: same batch, same protocol
+            ab, ag = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev, kind=wkind)
+            gather["workload_kind"] = {
+                "kernel": "k_aggregate_ring<%s> (width %d, %d output matri%s)" % (wkind.upper(), w["hidden"], k_out, "x" if k_out == 1 else "ces"),
+                "bound": "hbm", "achieved": ag["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ag["hbm"]["gbps"] / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": ab, "us_per_launch": ag["hbm"]["us"],
+                "traffic": pmc_traffic("aggregate_%s" % wkind, args.workload, ab),
+                "in_pipeline_l3_resident": ag.get("l3_resident"), "extra_read_bytes": ag.get("extra_read_bytes", 0),
+                "note": "algorithmic bytes per SURVEY 8(d): 4 w N (1 + k_out) + CSR + graph ptr; PNA's per-destination "
+                        "term q [N, w] is read on top (extra_read_bytes) and not counted"}
         fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w["hidden"], len(w["pools"])),
                                     conv=w["conv"], layers=w["layers"], seg=segs[0]) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
         upd = dict(kernel="k_linear_wlds (fp32 MFMA, weights in LDS), full-width layer update", bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS,

@@ -31,7 +31,7 @@ namespace gnnb {
 // the rows (rg + k nrg) * 16 + lg * 4 + r of its units k < NU (NU wave-uniform).  The units'
 // accumulators are interleaved so that dependent MFMAs are >= 2 issues apart (NU == 1: the k range
 // is split over two accumulators instead).
-template <int ACT, int KQ, int NU, bool SWZ>
+template <int ACT, int KQ, int NU, bool SWZ, bool PIN = false>
 __device__ __forceinline__ void g2_mma(const float *__restrict__ Asrc, int lda, int P, const float (&wr)[KQ * 4],
                                        float bias, int rg, int nrg, int li, int lg, float (&v)[NU][4])
 {
@@ -58,6 +58,8 @@ __device__ __forceinline__ void g2_mma(const float *__restrict__ Asrc, int lda, 
             for (int k = 0; k < NU; k++)
                 an[k] = frag(q + 1, k);
         }
+        if (PIN) // (no fragment load is hoisted further than one k block ahead: the register budget of the deep / GIN variants)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -66,6 +68,8 @@ __device__ __forceinline__ void g2_mma(const float *__restrict__ Asrc, int lda, 
                 const int ai = NU == 1 ? (t & 1) : k;
                 acc[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[q * 4 + t], acc[ai], 0, 0, 0);
             }
+        if (PIN)
+            __builtin_amdgcn_sched_barrier(0);
         if (q + 1 < KQ) {
 #pragma unroll
             for (int k = 0; k < NU; k++)
@@ -77,6 +81,33 @@ __device__ __forceinline__ void g2_mma(const float *__restrict__ Asrc, int lda, 
 #pragma unroll
         for (int r = 0; r < 4; r++)
             v[k][r] = act_t<ACT>((NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias);
+}
+
+// The same product with the units taken in groups of at most two (SPLIT): the 128-wide products of the deep / GIN
+// variants hold a 32-register weight slice, the accumulators kept across a barrier AND the next slice's loads at once --
+// four units in one go (32 fragment registers in flight) overflowed the 128-register budget into scratch (40-67 VGPRs
+// spilled per instantiation, 23 MB of scratch writes per launch at BASELINE config 3).  Two units keep the dependent
+// MFMAs of one accumulator 64 cycles apart (latency 40): the matrix pipe stays fed.
+template <int ACT, int KQ, int NU, bool SPLIT>
+__device__ __forceinline__ void g2_mma_s(const float *__restrict__ Asrc, int lda, const float (&wr)[KQ * 4], float bias, int rg,
+                                         int nrg, int li, int lg, float (&v)[NU][4])
+{
+    if constexpr (SPLIT && NU > 2) {
+        float va[2][4], vb[NU - 2][4];
+        g2_mma<ACT, KQ, 2, false, true>(Asrc, lda, 1, wr, bias, rg, nrg, li, lg, va);
+        __builtin_amdgcn_sched_barrier(0); // (the second group's fragment loads stay behind the first group's products)
+        g2_mma<ACT, KQ, NU - 2, false, true>(Asrc, lda, 1, wr, bias, rg + 2 * nrg, nrg, li, lg, vb);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v[0][r] = va[0][r];
+            v[1][r] = va[1][r];
+#pragma unroll
+            for (int k = 2; k < NU; k++)
+                v[k][r] = vb[k - 2][r];
+        }
+    } else {
+        g2_mma<ACT, KQ, NU, false, SPLIT>(Asrc, lda, 1, wr, bias, rg, nrg, li, lg, v);
+    }
 }
 
 // M1 of the fused stack with bf16x6: A1 lives in LDS as three bf16 planes [rows][h0] (16-B chunks of
@@ -152,8 +183,17 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ Wmid, const float *__restrict__ bmid, long mid_stride, long bmid_stride, int skip,
     float gin_eps)
 {
+    if (GIN) {
+        // (GIN stacks are hidden x hidden everywhere -- the launcher checks h1 == h0 == 16 KQ1 --, so the row strides of H and
+        // A1 are compile-time constants: the sixteen write-back addresses of a wide product are one register + immediates
+        // instead of sixteen hoisted registers, which is what pushed these variants over the 128-register budget)
+        h0 = 16 * KQ1;
+        h1 = 16 * KQ1;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G2_UNITS = g2_units(MATH), G2_CAP = 16 * G2_UNITS;
+    constexpr bool G2_SPLIT = (DEEP || GIN) && KQ1 >= 4; // wide products in groups of two units (register budget: g2_mma_s)
+    constexpr bool G2_W0_PER_STAGE = DEEP || GIN || (MATH && KQ0 == 2); // the narrow slice re-read per stage (see M0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     // ---- LDS carve (bytes, every region 16-B aligned):
@@ -269,7 +309,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     for (int q = 0; q < KQ0; q++) {
         const int k = 16 * q + 4 * lg;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0c < h0)
+        if (!G2_W0_PER_STAGE && n0c < h0) // (else: loaded per stage, in front of M0)
             v = load4_guard(W0 + (size_t)n0c * f0 + k, f0 - k, false);
         w0r[q * 4 + 0] = v.x;
         w0r[q * 4 + 1] = v.y;
@@ -287,7 +327,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         w1r[q * 4 + 2] = v.z;
         w1r[q * 4 + 3] = v.w;
     }
-    float bias0 = (n0c < h0 && b0) ? b0[n0c] : 0.0f;
+    float bias0 = (!G2_W0_PER_STAGE && n0c < h0 && b0) ? b0[n0c] : 0.0f;
     float bias1 = (n1c < h1 && b1) ? b1[n1c] : 0.0f;
     // MATH 1: the wave's W1 slice as three bf16 register sets, lane (li, lg) holding k = 32 kb + 8 lg .. + 7
     u32x4 wh[KB1], wm[KB1], wl[KB1];
@@ -319,9 +359,11 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     // alone it keeps them "possibly in flight" around the stage loop's back edge and guards their first
     // use in M0 / M1 with s_waitcnt vmcnt(0) -- which also waits for the next stage's DMA issued just
     // before, i.e. exposes the full memory latency in every stage.
+    if (!G2_W0_PER_STAGE) {
 #pragma unroll
-    for (int q = 0; q < KQ0 * 4; q++)
-        asm volatile("" : "+v"(w0r[q]));
+        for (int q = 0; q < KQ0 * 4; q++)
+            asm volatile("" : "+v"(w0r[q]));
+    }
     if (MATH) {
 #pragma unroll
         for (int kb = 0; kb < KB1; kb++)
@@ -333,7 +375,9 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         for (int q = 0; q < KQ1 * 4; q++)
             asm volatile("" : "+v"(w1r[q]));
     }
-    asm volatile("" : "+v"(bias0), "+v"(bias1));
+    if (!G2_W0_PER_STAGE)
+        asm volatile("" : "+v"(bias0));
+    asm volatile("" : "+v"(bias1));
     __syncthreads();
 
     const int nv1 = h0 >> 2;                         // float4 chunks per H row consumed by layer 1
@@ -471,6 +515,24 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 
         // ---- M0: H = act(A0 . W0^T + b0)   (wave: column slice x row group)
         {
+            if (G2_W0_PER_STAGE) {
+                // (deep / GIN variants, and the bf16x6 form with two narrow k blocks: the narrow slice and its bias are re-read from L2 per stage -- 16 + 4 bytes per lane,
+                // requested here and first used behind the fragment read -- instead of living in five registers through the
+                // wide phases, where the budget is 128: together with the two-unit products this took the variants from
+                // 40-67 spilled registers to none)
+#pragma unroll
+                for (int q = 0; q < KQ0; q++) {
+                    const int k = 16 * q + 4 * lg;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n0c < h0)
+                        v = load4_guard(W0 + (size_t)n0c * f0 + k, f0 - k, false);
+                    w0r[q * 4 + 0] = v.x;
+                    w0r[q * 4 + 1] = v.y;
+                    w0r[q * 4 + 2] = v.z;
+                    w0r[q * 4 + 3] = v.w;
+                }
+                bias0 = (n0c < h0 && b0) ? b0[n0c] : 0.0f;
+            }
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
             auto m0 = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
@@ -561,7 +623,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
             auto mm = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
                 float v[NU][4];
-                g2_mma<GNNB_ACT_NONE, KQ1, NU, false>(A1, lda1, 1, w1r, bias1, rg0, nrg0, li, lg, v);
+                g2_mma_s<GNNB_ACT_NONE, KQ1, NU, G2_SPLIT>(A1, lda1, w1r, bias1, rg0, nrg0, li, lg, v);
                 if (n0c < h0) {
 #pragma unroll
                     for (int k = 0; k < NU; k++)
@@ -589,7 +651,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
             auto comp = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
                 float t[NU][4];
-                g2_mma<A, KQ1, NU, false>(buf, ld, 1, w1r, bias1, rg0, nrg0, li, lg, t);
+                g2_mma_s<A, KQ1, NU, G2_SPLIT>(buf, ld, w1r, bias1, rg0, nrg0, li, lg, t);
 #pragma unroll
                 for (int k = 0; k < NU; k++)
 #pragma unroll
@@ -666,7 +728,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 if (MATH)
                     g2_mma_bf6<ACT, KB1, NU>(reinterpret_cast<const char *>(A1), plane_b, prow_b, wh, wm, wl, bias1, li, lg, v);
                 else
-                    g2_mma<ACT, KQ1, NU, false>(A1, lda1, 1, w1r, bias1, 0, 1, li, lg, v);
+                    g2_mma_s<ACT, KQ1, NU, G2_SPLIT>(A1, lda1, w1r, bias1, 0, 1, li, lg, v);
                 const int ngr = cur.gb - cur.ga;
                 // (one store instruction per graph and pool; none if the whole slice is past h1; the rare
                 // paths below that read global memory only make the count conservative -- see the wait)
@@ -843,9 +905,11 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
         else if (kq0 == 2 && kq1 == 4) go(atag, IntTag<2>{}, IntTag<4>{});
         else go(atag, IntTag<2>{}, IntTag<2>{});
     };
-#ifdef GNNB_DEV_FAST // development builds: only the BASELINE config 2 instantiation (seconds instead of minutes to compile)
+#ifdef GNNB_DEV_FAST // development builds: only the BASELINE config 2 / 3 instantiations (seconds instead of minutes to compile)
     if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && !deep.gin && !math && deep.nl == 2)
         go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<0>{});
+    else if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && deep.gin)
+        go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<2>{});
 #else
     GNNB_DISPATCH_ACT(act, go_q)
 #endif

@@ -17,7 +17,7 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
 def kernel_registers(tmp_path):
-    """{mangled kernel name: (vgprs, agprs)} over every device code object bundled into the library."""
+    """{mangled kernel name: (vgprs, agprs, scratch bytes per lane, spilled vgprs)} over every device code object bundled into the library."""
     fat = tmp_path / "fat.bin"
     subprocess.run([str(LLVM / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(LIB), str(tmp_path / "unused.so")],
                    check=True, capture_output=True)
@@ -37,8 +37,11 @@ def kernel_registers(tmp_path):
             name = re.search(r"\.name:\s+(\S+)", entry)
             vg = re.search(r"\.vgpr_count:\s+(\d+)", entry)
             ag = re.search(r"\.agpr_count:\s+(\d+)", entry)
+            sc = re.search(r"\.private_segment_fixed_size:\s+(\d+)", entry)
+            sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", entry)
             if name and vg:
-                out[name.group(1)] = (int(vg.group(1)), int(ag.group(1)) if ag else 0)
+                out[name.group(1)] = (int(vg.group(1)), int(ag.group(1)) if ag else 0, int(sc.group(1)) if sc else 0,
+                                      int(sp.group(1)) if sp else 0)
     return out
 
 
@@ -49,9 +52,24 @@ def test_kernels_that_share_a_cu_keep_their_register_budgets(tmp_path):
     # -- 110 registers --, GELU / sigmoid / tanh need 105 .. 107: no co-residency promised there)
     zf = {k: v for k, v in regs.items() if re.search(r"k_gcn2_zfILi0ELi1E", k)}
     assert len(zf) >= 6, f"k_gcn2_zf instantiations not found among {len(regs)} kernels"
-    for k, (v, a) in zf.items():
+    for k, (v, a, _, _) in zf.items():
         assert v + a <= 104, f"{k}: {v} VGPRs + {a} AGPRs > 104 -- closes the 96-register slot beside four waves per SIMD"
     guests = {k: v for k, v in regs.items() if "k_graph_prep" in k or "k_head_small" in k or "k_conv_rows" in k}
     assert guests
-    for k, (v, a) in guests.items():
+    for k, (v, a, _, _) in guests.items():
         assert v + a <= 96, f"{k}: {v} + {a} registers do not fit the slot the conv-stack kernel leaves"
+
+
+@pytest.mark.skipif(not LIB.exists() or shutil.which(str(LLVM / "llvm-readelf")) is None, reason="library or LLVM tools missing")
+def test_no_stack_kernel_spills_to_scratch(tmp_path):
+    """Every shipped instantiation of the LDS-resident conv-stack kernels (k_gcn2_zf, k_gcn2_fused incl. its deep, GIN and
+    bf16x6 variants) and of the kernels that run beside them: private_segment_fixed_size == 0 and no spilled VGPR.
+    (Round 3 shipped the GIN / deep variants with 40-67 spilled registers: 64-96 B of scratch per lane, 21 MB of scratch
+    writes per launch at BASELINE config 3 -- and scratch reloads are vector-memory operations that queue behind the
+    stage DMA.  Nothing asserted it.)"""
+    regs = kernel_registers(tmp_path)
+    stack = {k: v for k, v in regs.items() if "k_gcn2_zf" in k or "k_gcn2_fused" in k or "k_conv_rows" in k
+             or "k_graph_prep" in k or "k_head_small" in k}
+    assert sum("k_gcn2_fused" in k for k in stack) >= 100 and sum("k_gcn2_zf" in k for k in stack) >= 40, len(stack)
+    bad = {k: v for k, v in stack.items() if v[2] != 0 or v[3] != 0}
+    assert not bad, "kernels with scratch: " + "; ".join(f"{k[:60]}: {v[2]} B/lane, {v[3]} spilled" for k, v in bad.items())

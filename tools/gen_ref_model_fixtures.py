@@ -250,6 +250,17 @@ CASES = {
     "pna_l4_skip_tanh": C_("pna", 4, act="tanh", in_dim=8, hidden=12, out_dim=12, pools=("max", "mean"), pna_delta=2.5,
                            directed_extras=True, seed=15),
     "pna_l3_skip_sigmoid": C_("pna", 3, act="sigmoid", in_dim=11, hidden=16, out_dim=8, pools=("mean", "add", "max"), seed=16),
+    # the reference's one published benchmark model (experiments/build_base_benchmarks.py:61-81): SIX conv layers with skip
+    # connections, hidden != out (128 / 64 there; 32 / 16 here -- what these vectors pin is the composition: layer dimensions,
+    # skip placement over four middle layers, the last layer narrowing, a head of FOUR hidden layers), QM9-shaped inputs
+    "ref6_gcn": C_("gcn", 6, in_dim=11, hidden=32, out_dim=16, mlp_hidden=16, mlp_hidden_layers=4, mlp_out=19,
+                   sizes=(18, 21, 9, 29, 14), isolated=True, seed=21),
+    "ref6_gin": C_("gin", 6, in_dim=11, hidden=32, out_dim=16, mlp_hidden=16, mlp_hidden_layers=4, mlp_out=19,
+                   sizes=(18, 21, 9, 29, 14), seed=22),
+    "ref6_sage": C_("sage", 6, in_dim=11, hidden=32, out_dim=16, mlp_hidden=16, mlp_hidden_layers=4, mlp_out=19,
+                    sizes=(18, 21, 9, 29, 14), isolated=True, seed=23),
+    "ref6_pna": C_("pna", 6, in_dim=11, hidden=16, out_dim=8, mlp_hidden=16, mlp_hidden_layers=4, mlp_out=19,
+                   sizes=(18, 21, 9, 29, 14), seed=24),
 }
 
 
@@ -258,7 +269,10 @@ def main():
         sys.exit("needs the reference tree at /root/reference (build container only)")
     tmp = tempfile.mkdtemp(prefix="gnnb_ref_models_")
     try:
+        only = set(sys.argv[1:])  # (optional: regenerate only the named cases)
         for name, case in CASES.items():
+            if only and name not in only:
+                continue
             out = run_case(name, case, tmp)
             print(f"{name:28s} graphs {out.shape[0]:2d}  out {out.shape[1]:3d}  |out|max {np.abs(out).max():.4f}")
     finally:
