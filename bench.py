@@ -65,6 +65,17 @@ WORKLOADS = {
                hidden=128, layers=3, pools=("add", "mean", "max"), batch=8192),
     "c5": dict(desc="2-layer GraphSAGE d=256, ogbg-molhiv-shaped graphs, batch=8192 per GPU (65536 over 8)",
                conv="sage", shape="molhiv", hidden=256, layers=2, pools=("add", "mean", "max"), batch=8192),
+    # the reference's ONE published benchmark model (experiments/build_base_benchmarks.py:61-81: 6 conv layers, hidden 128, out 64,
+    # skip connections, add|mean|max pooling, MLP head of 4 hidden layers of 64; its figures/runtime_results_pivot.csv rows are
+    # this model on QM9 and friends) for the four convs, on QM9-shaped batches of 4096
+    "ref6_gcn": dict(desc="reference benchmark model: 6-layer GCN 128/64 + MLP 4x64, QM9-shaped graphs, batch=4096 per GPU", conv="gcn",
+                     shape="qm9", hidden=128, out_dim=64, layers=6, pools=("add", "mean", "max"), mlp_layers=4, batch=4096),
+    "ref6_gin": dict(desc="reference benchmark model: 6-layer GIN 128/64 + MLP 4x64, QM9-shaped graphs, batch=4096 per GPU", conv="gin",
+                     shape="qm9", hidden=128, out_dim=64, layers=6, pools=("add", "mean", "max"), mlp_layers=4, batch=4096),
+    "ref6_sage": dict(desc="reference benchmark model: 6-layer GraphSAGE 128/64 + MLP 4x64, QM9-shaped graphs, batch=4096 per GPU",
+                      conv="sage", shape="qm9", hidden=128, out_dim=64, layers=6, pools=("add", "mean", "max"), mlp_layers=4, batch=4096),
+    "ref6_pna": dict(desc="reference benchmark model: 6-layer PNA 128/64 + MLP 4x64, QM9-shaped graphs, batch=4096 per GPU", conv="pna",
+                     shape="qm9", hidden=128, out_dim=64, layers=6, pools=("add", "mean", "max"), mlp_layers=4, batch=4096),
     # plumbing-sized workload of the launcher test (--dry-launch); never a bench line
     "tiny": dict(desc="launcher test: 2-layer GCN d=16, 64 QM9-shaped graphs", conv="gcn", shape="qm9",
                  hidden=16, layers=2, pools=("add", "mean", "max"), batch=64),
@@ -79,9 +90,10 @@ def build_model(w, seed=0):
     torch.manual_seed(seed)
     convs = {"gcn": gnnb.GCNConv_GNNB, "gin": gnnb.GINConv_GNNB, "sage": gnnb.SAGEConv_GNNB, "pna": gnnb.PNAConv_GNNB}
     shp = synthetic.SHAPES[w["shape"]]
-    return gnnb.GNNModel(shp["f_in"], None, w["hidden"], w["layers"], w["hidden"], convs[w["conv"]], torch.nn.ReLU,
+    out_dim = w.get("out_dim", w["hidden"])
+    return gnnb.GNNModel(shp["f_in"], None, w["hidden"], w["layers"], out_dim, convs[w["conv"]], torch.nn.ReLU,
                          True, gnnb.GlobalPooling(list(w["pools"])),
-                         gnnb.MLP(len(w["pools"]) * w["hidden"], shp["out"], 64, 2), None).eval()
+                         gnnb.MLP(len(w["pools"]) * out_dim, shp["out"], 64, w.get("mlp_layers", 2)), None).eval()
 
 
 # --------------------------------------------------------------------------------------- roofline legs
@@ -216,7 +228,7 @@ def measure_fused_stack(cm, batch_dev, model_dims, iters=200, conv="gcn", layers
         B, N, E = seg
     # the dense updates (MFMA); aggregation flops not counted.  GCN: one linear per layer; GIN: two (hidden = out)
     if conv == "gin":
-        flops = 2.0 * N * (f0 * h0 + (2 * layers - 1) * h0 * h0)
+        flops = 2.0 * N * (f0 * h0 + h0 * h0 + (layers - 2) * 2 * h0 * h0 + h0 * h1 + h1 * h1)  # (= f0 h0 + (2L - 1) h0^2 when out = hidden)
     else:
         flops = 2.0 * N * (f0 * h0 + (layers - 2) * h0 * h0 + h0 * h1)
     # HBM bytes the kernel has to move: x + node records + dinv + tile/graph tables in, pooled out
@@ -535,7 +547,7 @@ def main():
         if wkind != "gcn":
             ab, ag = measure_aggregate_roofline(cm, bd, w["hidden"], dev, regimes=("hbm",), kind=wkind)
             own = {"kind": wkind, "algorithmic_bytes_per_launch": ab, **ag["hbm"]}
-        fused = measure_fused_stack(cm, bd, (int(batch.x.shape[1]), w["hidden"], w["hidden"], len(w["pools"])),
+        fused = measure_fused_stack(cm, bd, (int(batch.x.shape[1]), w["hidden"], w.get("out_dim", w["hidden"]), len(w["pools"])),
                                     conv=w["conv"], layers=w["layers"], seg=seg) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
         print(json.dumps({"roofline_only": True, "workload": args.workload, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"],
                           "copy_same_launch_shape": agg.get("copy_same_launch_shape"), "workload_kind": own, "fused_stack": fused,
@@ -753,7 +765,7 @@ def main():
                 "in_pipeline_l3_resident": ag.get("l3_resident"), "extra_read_bytes": ag.get("extra_read_bytes", 0),
                 "note": "algorithmic bytes per SURVEY 8(d): 4 w N (1 + k_out) + CSR + graph ptr; PNA's per-destination "
                         "term q [N, w] is read on top (extra_read_bytes) and not counted"}
-        fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w["hidden"], len(w["pools"])),
+        fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w.get("out_dim", w["hidden"]), len(w["pools"])),
                                     conv=w["conv"], layers=w["layers"], seg=segs[0]) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
         upd = dict(kernel="k_linear_wlds (fp32 MFMA, weights in LDS), full-width layer update", bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS,
                    unit="TFLOP/s", traffic=None, **measure_update_mfma(w, batches[0].num_nodes, dev))

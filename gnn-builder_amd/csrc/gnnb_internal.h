@@ -25,6 +25,12 @@ struct BatchTables {
     int32_t *tile_first; // [T+1] first node of node-tile t; tiles are cut at graph boundaries
     int32_t *tile_edge;  // [T+1] first CSR slot of the tile (= edge_ptr of its first graph, clamped)
     int32_t *tile_graph; // [T+1] index of the graph that starts at tile_first[t] (B past the end)
+    int32_t *node_graph; // [N] index of the graph every node row belongs to (written by graph prep when the model's last
+                         //     conv layer can pool in its GEMM epilogue: launch_linear(..., PoolEpilogue); nullptr otherwise)
+    int4 *agg_cut;       // [agg_cut_n + 1] row-balanced ranges of the gather-aggregate kernels' workgroups: {first row of range b
+                         //       = floor(b N / n), start row / first CSR slot / index of the graph that row belongs to}; written
+                         //       by graph prep when agg_cut_n > 0 (a power of two: the ring kernel's grid on this device)
+    int32_t agg_cut_n;
     int32_t max_graph_nodes_hint; // caller's promise (0 = unknown); validated on device by prep
     int32_t promise_graphs;       // ... for graphs [0, promise_graphs) (the rest: the caller's "large segment")
     int32_t large_n, large_e;     // node / edge offset the caller named for graph promise_graphs (-1: no large segment);
@@ -53,6 +59,9 @@ struct Options {
     int agg_ring_slots;   // LDS stages in the ring
     int agg_ring_wg_per_cu;
     int agg_nt_store;     // non-temporal output stores
+    int agg_balance;      // 1 = the ring kernel's workgroups take row-balanced ranges (boundary graphs staged by both neighbours);
+                          //     0 = whole-graph runs (default: measured faster, 15.2 vs 15.9 us at BASELINE config 2 -- the 3 % of extra
+                          //     reads cost the per-CU memory pipe more than the +-8 % row imbalance)
     int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
     int gemm_max_wg_per_cu;
     int gemm_dma;      // 1 = large-K GEMM through LDS-DMA when every segment is plain (default)
@@ -69,6 +78,8 @@ struct Options {
                        //     2 = shape 1 wherever it exists (input widths up to 16), else shape 0 (default)
     int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it (k_gcn2_fused), 0 = layer by layer
     int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
+    int fuse_pool;     // 1 = global pooling in the epilogue of the last conv layer's GEMM where that GEMM has one (GraphSAGE's
+                       //     large-K segmented GEMM; default), 0 = separate pooling pass
     int head_small;    // 1 = readout on a pooled matrix with the small-footprint kernel that co-resides with the
                        //     conv-stack kernel of the next batch in flight (default); 0 = weights-in-LDS kernel
     int head_split;    // 1 = layer-wise models: pooling pass + small readout instead of the one-launch pooling+MLP kernel
@@ -87,6 +98,9 @@ hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, cons
                             float *out, int width, float eps, hipStream_t s);
 // t.gcoef from t.node_rec / t.dinv: what launch_aggregate(GNNB_AGG_GCN) reads (call once per prepared batch)
 hipError_t launch_gcn_coef(const BatchTables &t, hipStream_t s);
+// workgroups the ring-form gather-aggregate kernel launches on the current device (CUs x agg_ring_wg_per_cu): what graph
+// prep cuts its row-balanced ranges for
+int aggregate_ring_grid();
 // GINE: out_i = (1 + eps) x_i + sum_j relu(x_j + eterm[edge]); eterm [E, width] in COO order
 hipError_t launch_aggregate_edges(const BatchTables &t, const float *x, const float *eterm, float *out, int width,
                                   float eps, hipStream_t s);
@@ -108,8 +122,23 @@ hipError_t launch_conv_gather(const BatchTables &t, int agg_kind, float eps, con
                               int K, const float *w, int ldw, const float *bias, const float *skip,
                               float *y, int N, int act, hipStream_t s, int cat = 0);
 
+// Global pooling folded into the LAST conv layer's GEMM epilogue (reference compute_global_graph_pooling,
+// templates/model.cpp.jinja:413-449, global_*_pool gnn_builder_lib.h:2709-2803): the [N, d] output of the layer is never
+// written.  Rows are pooled in 32-row blocks: a graph that lies inside one block is finished there (-> pooled), the pieces
+// of a graph that crosses block boundaries go to `part` and launch_pool_combine adds them up in row order (deterministic).
+struct PoolEpilogue {
+    const int32_t *node_graph = nullptr; // BatchTables::node_graph
+    const int32_t *graph_ptr = nullptr;  // [B + 1]
+    float *pooled = nullptr;             // [B, np, N]
+    float2 *part = nullptr;              // [ceil(M / 32), 2, N] {sum, max} of a block's first / last open piece
+    int32_t num_graphs = 0, np = 0, pools[3] = {0, 0, 0};
+};
+// pe != nullptr: y is not written; returns hipErrorNotSupported (nothing launched) when the GEMM shape has no pooling
+// epilogue -- the caller then runs the plain GEMM + a pooling pass
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
-                         const float *skip, float *y, int M, int N, int act, hipStream_t s);
+                         const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pe = nullptr);
+// the pieces of graphs that cross 32-row blocks -> pooled (and zeros for empty graphs); after launch_linear(..., pe)
+hipError_t launch_pool_combine(const PoolEpilogue &pe, int M, int N, hipStream_t s);
 
 // Fused readout: global pooling + the whole MLP head in one launch (16 graphs per workgroup).
 struct HeadArgs {

@@ -53,12 +53,12 @@ Options &options()
 {
     static Options o = {env_int("GNNB_TILE_ROWS", 8), env_int("GNNB_AGG_LDS_KB", 0),
                                                 env_int("GNNB_AGG_RING_WAVES", 0),    env_int("GNNB_AGG_RING_SLOTS", 2),
-                        env_int("GNNB_AGG_RING_WG_PER_CU", 1), env_int("GNNB_AGG_NT_STORE", 1),
+                        env_int("GNNB_AGG_RING_WG_PER_CU", 1), env_int("GNNB_AGG_NT_STORE", 1), env_int("GNNB_AGG_BALANCE", 0),
                         env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_GEMM_DMA", 1),
                         env_int("GNNB_GEMM_WLDS", 1),             env_int("GNNB_GEMM_WLDS_SLOTS", 2),
                         env_int("GNNB_FUSE_NARROW", 1),     env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
-                        env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1),
+                        env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
                         env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 1)};
     return o;
@@ -163,6 +163,7 @@ struct gnnb_workspace {
     float *pooled = nullptr;            // [max_graphs, np*d]
     float *mlp[2] = {nullptr, nullptr}; // [max_graphs, max(mlp_hidden, mlp_out)]
     bool prepared = false;
+    float2 *pool_part = nullptr; // pieces of graphs that cross the 32-row blocks of the pooling GEMM epilogue (PoolEpilogue::part)
     bool gcoef_ready = false; // t.gcoef holds the prepared batch's GCN coefficients (ensure_gcoef)
     int max_graph_nodes = 0; // caller's promise (0 = none)
     int last_path = GNNB_PATH_NONE; // which kernels the last forward on this workspace ran (gnnb_workspace_last_path)
@@ -216,6 +217,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_ring_wg_per_cu = value;
     else if (!strcmp(name, "agg_nt_store") && value >= 0 && value <= 1)
         o.agg_nt_store = value;
+    else if (!strcmp(name, "agg_balance") && value >= 0 && value <= 1)
+        o.agg_balance = value;
     else if (!strcmp(name, "fuse_narrow") && value >= 0 && value <= 1)
         o.fuse_narrow = value;
     else if (!strcmp(name, "fuse_gcn2") && value >= 0 && value <= 1)
@@ -228,6 +231,8 @@ int gnnb_set_option(const char *name, int value)
         o.large_fork = value;
     else if (!strcmp(name, "fuse_head") && value >= 0 && value <= 1)
         o.fuse_head = value;
+    else if (!strcmp(name, "fuse_pool") && value >= 0 && value <= 1)
+        o.fuse_pool = value;
     else if (!strcmp(name, "head_split") && value >= 0 && value <= 1)
         o.head_split = value;
     else if (!strcmp(name, "head_small") && value >= 0 && value <= 1)
@@ -444,9 +449,13 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
         return o;
     };
     const size_t N = max_nodes, E = std::max(max_edges, 1), B = max_graphs;
+    // (models whose last conv layer ends in the large-K segmented GEMM -- GraphSAGE -- pool in that GEMM's epilogue: a
+    // node -> graph table and the buffer for the pieces of graphs that cross 32-row blocks)
+    const bool pool_epi = d.conv_type == GNNB_CONV_SAGE && d.num_layers >= 1 && d.fpx_w <= 0;
     const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_eid = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
                  o_att = carve(N * 4), o_gcoef = carve(N * 16), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_gptr = carve((B + 1) * 4),
-                 o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4),
+                 o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4), o_cut = carve((4096 + 1) * 16),
+                 o_ngraph = carve(pool_epi ? N * 4 : 0), o_part = carve(pool_epi ? ((N + 31) / 32) * 2 * (size_t)gnn_out_width(d) * 8 : 0),
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
                  o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
                  o_pool = carve(B * pooledw * 4), o_m0 = carve(B * mlpw * 4),
@@ -472,6 +481,10 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->t.tile_edge = (int32_t *)(b + o_tedge);
     ws->t.tile_graph = (int32_t *)(b + o_tgraph);
     ws->t.err = (int32_t *)(b + o_err);
+    ws->t.agg_cut = (int4 *)(b + o_cut);
+    ws->t.agg_cut_n = 0;
+    ws->t.node_graph = pool_epi ? (int32_t *)(b + o_ngraph) : nullptr;
+    ws->pool_part = pool_epi ? (float2 *)(b + o_part) : nullptr;
     ws->act[0] = (float *)(b + o_a0);
     ws->act[1] = (float *)(b + o_a1);
     ws->agg = (float *)(b + o_agg);
@@ -597,6 +610,16 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
             t.tile_rows <<= 1;
     }
     t.num_tiles = (num_nodes + t.tile_rows - 1) / t.tile_rows;
+    // row-balanced ranges for the gather-aggregate kernels (one per workgroup of the ring kernel's grid on this device):
+    // not for a batch that is expected on the stack kernels entirely (their graph prep is on the pipeline's critical path
+    // and pays for every instruction), not with a large segment (its aggregates walk a tile sub-range)
+    {
+        const bool stack_expected = options().fuse_gcn2 && (ws->desc.conv_type == GNNB_CONV_GCN || ws->desc.conv_type == GNNB_CONV_GIN) &&
+                                    ws->desc.num_layers >= 2 && ws->max_graph_nodes > 0 && ws->desc.fpx_w <= 0;
+        const int rings = aggregate_ring_grid();
+        t.agg_cut_n = (options().agg_balance && !stack_expected && ws->large_g < 0 && rings <= 4096 && (rings & (rings - 1)) == 0 &&
+                       t.num_tiles >= rings) ? rings : 0;
+    }
     if (!(pna_delta > 0.0f))
         pna_delta = 1.0f;
     // the degree scalers (amp / att) are only read by PNA layers: a model-bound workspace of another conv type
@@ -871,8 +894,10 @@ static G2Deep gcn_stack_middle_layers(const gnnb_model *model)
 // from tile_lo; the GEMMs take the row range as a pointer offset.  *out_cur = the last layer's output matrix ([N, width],
 // rows below row_lo untouched).
 static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, int row_lo, int tile_lo,
-                           const float **out_cur, void *stream)
+                           const float **out_cur, void *stream, bool *pooled_in_epilogue = nullptr)
 {
+    if (pooled_in_epilogue)
+        *pooled_in_epilogue = false;
     const gnnb_model_desc &d = model->desc;
     const int N = ws->t.num_nodes, M = N - row_lo;
     int rc;
@@ -961,6 +986,32 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
             if ((rc = aggregate(GNNB_AGG_MEAN, cur, nullptr, ws->agg, fi, 0.f)))
                 return rc;
             gnnb_gemm_seg segs[2] = {{R(ws->agg, fi), nullptr, fi, fi}, {R(cur, fi), nullptr, fi, fi}};
+            // the LAST layer of a whole-batch run: global pooling in the GEMM's epilogue -- its [N, out] output is never
+            // written and the separate pooling pass (a full read of it) disappears (reference: compute_gnn_head's last
+            // layer + compute_global_graph_pooling, templates/model.cpp.jinja:151-449).  Falls back when the GEMM shape
+            // has no such epilogue.
+            if (pooled_in_epilogue && whole && l == d.num_layers - 1 && !fpx && options().fuse_pool && ws->t.node_graph && ws->pool_part) {
+                GemmArgs g;
+                if ((rc = build_gemm(g, segs, 2, p[0], 2 * fi)))
+                    return rc;
+                PoolEpilogue pe;
+                pe.node_graph = ws->t.node_graph;
+                pe.graph_ptr = ws->t.graph_ptr;
+                pe.pooled = ws->pooled;
+                pe.part = ws->pool_part;
+                pe.num_graphs = ws->t.num_graphs;
+                pe.np = d.num_pools;
+                for (int k = 0; k < 3; k++)
+                    pe.pools[k] = k < d.num_pools ? d.pools[k] : 0;
+                hipError_t he = launch_linear(g, p[0], 2 * fi, p[1], nullptr, nxt, M, fo, d.activation, (hipStream_t)stream, &pe);
+                if (he == hipSuccess) {
+                    GNNB_HIP_TRY(launch_pool_combine(pe, M, fo, (hipStream_t)stream));
+                    *pooled_in_epilogue = true;
+                    break;
+                }
+                if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "pooling GEMM launch failed: %s", hipGetErrorString(he));
+            }
             if ((rc = gnnb_linear(segs, 2, p[0], 2 * fi, p[1], R(skip, fi), Rw(nxt, fo), M, fo, d.activation, stream)))
                 return rc;
             break;
@@ -1221,12 +1272,33 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
 
     ws->last_path = GNNB_PATH_LAYERWISE;
     const float *cur = nullptr;
-    if ((rc = run_conv_layers(model, ws, x_dev, 0, 0, &cur, stream)))
+    bool pooled_done = false;
+    if ((rc = run_conv_layers(model, ws, x_dev, 0, 0, &cur, stream, &pooled_done)))
         return rc;
 
     const int gw = gnn_out_width(d);
-    bool pooled_done = false;
-    if (!fpx) {
+    if (pooled_done) {
+        // (the last layer's GEMM pooled in its epilogue: ws->pooled is complete, the readout takes it as the stack path does)
+        HeadArgs head;
+        memset(&head, 0, sizeof(head));
+        head.nlin = d.mlp_num_linear;
+        if (head.nlin <= 8) {
+            for (int i = 0; i < head.nlin; i++) {
+                int din, dout;
+                mlp_dims(d, i, &din, &dout);
+                head.w[i] = model->head_w[i];
+                head.b[i] = model->head_b[i];
+                head.dims[i] = din;
+                head.dims[i + 1] = dout;
+            }
+            hipError_t he = launch_pool_mlp(nullptr, ws->t.graph_ptr, B, gw, d.pools, d.num_pools, head, d.mlp_activation, out_dev,
+                                            (hipStream_t)stream, ws->pooled);
+            if (he == hipSuccess)
+                return GNNB_OK;
+            if (he != hipErrorNotSupported)
+                return fail(GNNB_ERR_HIP, "readout launch failed: %s", hipGetErrorString(he));
+        }
+    } else if (!fpx) {
         // fused readout (pooling + whole MLP head, one launch) when the head fits LDS
         HeadArgs head;
         memset(&head, 0, sizeof(head));

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
     const int4 *__restrict__ node_rec, const int32_t *__restrict__ col, const float *__restrict__ dinv,
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_edge, int num_tiles, int N, int E, int w,
     int glog2, int cap, int ecap, int nslots, int slot_bytes, int slack, float eps, int tile_lo,
-    const float4 *__restrict__ gcoef)
+    const float4 *__restrict__ gcoef, const int4 *__restrict__ cut, int tile_rows)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HASQ = MODE == GNNB_AGG_PNA, HASREC = MODE != GNNB_AGG_COPY, HASDINV = MODE == GNNB_AGG_GCN;
@@ -338,8 +338,27 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
     // the workgroup's waves share the ring: wave sw of sn issues 1/sn of a stage's DMA and reduces 1/sn of its rows
     const int sw = wave, sn = nw;
     // (tile_lo > 0: only the tiles of the caller's large segment, see gnnb_workspace_set_large_segment)
-    const int t0 = tile_lo + (int)(((long long)blockIdx.x * (num_tiles - tile_lo)) / gridDim.x),
-              t1 = tile_lo + (int)(((long long)(blockIdx.x + 1) * (num_tiles - tile_lo)) / gridDim.x);
+    // The workgroup's rows.  Without `cut`: a run of whole node tiles (= whole graphs), equal tile counts -- rows +- one graph,
+    // 288 +- 8 % at BASELINE config 2, and the kernel ends with its slowest workgroup.  With `cut` (graph prep's row-balanced
+    // ranges, round 4): rows [r_lo, r_hi) = an exact 1 / grid share; the graphs those rows belong to are staged WHOLE --
+    // the boundary graph by both neighbours (~3 % more reads) -- and every workgroup reduces and stores only its own rows.
+    int t0, t1, r_lo = 0, r_hi = N, gs_row = 0, gs_edge = 0;
+    const bool use_cut = cut != nullptr;
+    if (use_cut) {
+        const int4 c0 = cut[blockIdx.x], c1 = cut[blockIdx.x + 1];
+        // (clamped: the table of a malformed -- flagged -- batch may hold stale entries; it must still stay in range)
+        r_lo = min(max(c0.x, 0), N);
+        r_hi = min(max(c1.x, r_lo), N);
+        gs_row = min(max(c0.y, 0), r_lo); // first row of the graph that owns r_lo
+        gs_edge = min(max(c0.z, 0), E);
+        t0 = min(gs_row / tile_rows, num_tiles);                          // (tile_first[t0] <= gs_row: never read as a stage start)
+        t1 = min((r_hi + tile_rows - 1) / tile_rows, num_tiles);          // tile_first[t1] = a graph start >= r_hi
+        if (r_hi <= r_lo)
+            return;
+    } else {
+        t0 = tile_lo + (int)(((long long)blockIdx.x * (num_tiles - tile_lo)) / gridDim.x);
+        t1 = tile_lo + (int)(((long long)(blockIdx.x + 1) * (num_tiles - tile_lo)) / gridDim.x);
+    }
     if (t0 >= t1)
         return; // (workgroup-uniform)
 #ifdef GNNB_PROBE
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
     int tev = HASREC ? min(tile_edge[min(wb + lane, num_tiles)], E) : 0;
     const int tf_end = min(tile_first[t1], N); // end of this ring's node range
     int ts = t0; // next tile to plan
+    bool first_cut = use_cut; // (row-balanced ranges: the first stage starts at the cut's graph, not at tile_first[t0])
 
     int f_nb[RING_MAX_SLOTS], f_rows[RING_MAX_SLOTS], f_mark[RING_MAX_SLOTS], f_e0[RING_MAX_SLOTS];
     int nfifo = 0, vm = 0, issue_slot = 0, head_slot = 0;
@@ -428,6 +448,8 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
 
     // reduce one landed stage; returns the number of store instructions the wave issued
     auto compute = [&](int slot, int nb_, int rows_, int e0_) -> int {
+        // (this workgroup's rows of the stage: all of them, or -- row-balanced ranges -- the part inside [r_lo, r_hi))
+        const int clo = max(r_lo - nb_, 0), chi = min(r_hi - nb_, rows_);
         const char *sb = wbase + (size_t)slot * slot_bytes;
         const float *sx = reinterpret_cast<const float *>(sb);
         const float *sq = reinterpret_cast<const float *>(sb + off_q);
@@ -446,12 +468,12 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
             const float4 *sgc = reinterpret_cast<const float4 *>(sb + off_gc);
             char *obase = reinterpret_cast<char *>(out + (size_t)nb_ * w) + gl * 16;
             const bool lane_on = gl < nvec;
-            for (int rb = sw * 2 * groups; rb < rows_; rb += sn * 2 * groups) {
-                const bool has_b = rb + groups < rows_;
+            for (int rb = clo + sw * 2 * groups; rb < chi; rb += sn * 2 * groups) {
+                const bool has_b = rb + groups < chi;
                 LdsRowF<MODE == GNNB_AGG_PNA || MODE == GNNB_AGG_LG || MODE == GNNB_AGG_COPY ? GNNB_AGG_SUM : MODE, NT> A, B;
-                A.begin(lane_on && rb + grp < rows_, rb + grp, srec, sxo, sx_lane, sdinv, sgc, w4);
+                A.begin(lane_on && rb + grp < chi, rb + grp, srec, sxo, sx_lane, sdinv, sgc, w4);
                 if (has_b)
-                    B.begin(lane_on && rb + groups + grp < rows_, rb + groups + grp, srec, sxo, sx_lane, sdinv, sgc, w4);
+                    B.begin(lane_on && rb + groups + grp < chi, rb + groups + grp, srec, sxo, sx_lane, sdinv, sgc, w4);
                 A.finish(sxo, sdo, scol_o, w4, obase, eps);
                 if (has_b)
                     B.finish(sxo, sdo, scol_o, w4, obase, eps);
@@ -459,14 +481,14 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
             }
             return nst;
         }
-        for (int rb = sw * 2 * groups; rb < rows_; rb += sn * 2 * groups) {
-            const bool has_b = rb + groups < rows_; // wave-uniform: the second row's store exists or not for the whole wave
+        for (int rb = clo + sw * 2 * groups; rb < chi; rb += sn * 2 * groups) {
+            const bool has_b = rb + groups < chi; // wave-uniform: the second row's store exists or not for the whole wave
             for (int f = gl; f < nvec; f += G) {
                 const int fo = f * VEC;
                 LdsRow<MODE, VEC, true, NT> A, B;
-                A.begin(rb + grp < rows_, nb_, rb + grp, sx, sq, srec, sdinv, selfq, w, fo);
+                A.begin(rb + grp < chi, nb_, rb + grp, sx, sq, srec, sdinv, selfq, w, fo);
                 if (has_b)
-                    B.begin(rb + groups + grp < rows_, nb_, rb + groups + grp, sx, sq, srec, sdinv, selfq, w, fo);
+                    B.begin(rb + groups + grp < chi, nb_, rb + groups + grp, sx, sq, srec, sdinv, selfq, w, fo);
                 A.finish(nb_, sx, srec, sdinv, scol, out, w, fo, eps);
                 if (has_b)
                     B.finish(nb_, sx, srec, sdinv, scol, out, w, fo, eps);
@@ -487,8 +509,9 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
                 tev = HASREC ? min(tile_edge[min(wb + lane, num_tiles)], E) : 0;
                 rel = 0;
             }
-            const int nb_ = __builtin_amdgcn_readlane(tfv, rel);
-            const int e0_ = __builtin_amdgcn_readlane(tev, rel);
+            const int nb_ = first_cut ? gs_row : __builtin_amdgcn_readlane(tfv, rel);
+            const int e0_ = first_cut ? gs_edge : __builtin_amdgcn_readlane(tev, rel);
+            first_cut = false;
             // a stage = a run of whole tiles whose rows AND CSR slice fit a slot.  The remaining rows are cut into
             // EQUAL stages (a greedy cut leaves a tiny last stage, and every stage costs a memory latency when the
             // ring is shallower than the range): aim at remaining / ceil(remaining / cap) rows, + half a tile
@@ -513,7 +536,7 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
             if (rows_ <= 0)
                 continue;
             if (big) {
-                for (int r = sw * groups + grp; r < rows_; r += sn * groups)
+                for (int r = max(r_lo - nb_, 0) + sw * groups + grp; r < min(r_hi - nb_, rows_); r += sn * groups)
                     for (int f = gl; f < nvec; f += G)
                         agg_row_direct<MODE, VEC, NT>(nb_ + r, x, selfq, out, node_rec, col, dinv, w, f * VEC, eps);
                 continue;
@@ -589,6 +612,8 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
     grid = std::min(grid, t.num_tiles - tile_lo);
     if (grid < 1)
         grid = 1;
+    // graph prep's row-balanced ranges, when they were made for exactly this grid
+    const int4 *cut = (o.agg_balance && tile_lo == 0 && t.agg_cut && t.agg_cut_n == grid) ? t.agg_cut : nullptr;
     auto launch = [&](auto kern) -> hipError_t {
         {
             hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
@@ -597,7 +622,8 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, x, selfq, out, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_edge, t.num_tiles, t.num_nodes, t.num_edges, w, glog2, cap,
-                           cap * ECAP_PER_ROW, ns, slot_bytes, std::max(t.tile_rows / 2, 1) + 2, eps, tile_lo, t.gcoef);
+                           cap * ECAP_PER_ROW, ns, slot_bytes, std::max(t.tile_rows / 2, 1) + 2, eps, tile_lo, t.gcoef, cut,
+                           std::max(t.tile_rows, 1));
         return hipGetLastError();
     };
     if (o.agg_nt_store)
@@ -684,6 +710,8 @@ hipError_t launch_gcn_coef(const BatchTables &t, hipStream_t s)
     hipLaunchKernelGGL(k_gcn_coef, dim3((t.num_nodes + WG - 1) / WG), dim3(WG), 0, s, t.node_rec, t.dinv, t.num_nodes, t.gcoef);
     return hipGetLastError();
 }
+
+int aggregate_ring_grid() { return device_cu_count() * std::max(options().agg_ring_wg_per_cu, 1); }
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s)

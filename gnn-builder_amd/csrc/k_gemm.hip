@@ -197,7 +197,8 @@ template <int MATH>
 __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__restrict__ W, int ldw,
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ skip, float *__restrict__ Y, int M,
-                                                    int N, int act, int tiles_m, int tiles_n, int split_from, int split)
+                                                    int N, int act, int tiles_m, int tiles_n, int split_from, int split,
+                                                    PoolEpilogue pe)
 {
     constexpr int NT = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -467,6 +468,95 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         }
         if (MC == 0)
             return;
+
+        // ---- pooling epilogue (the model's LAST conv layer): act(acc + bias) is pooled per graph instead of stored.
+        // Per 32-row block of the wave: the block goes through an 8-KB scratch in the chunk buffer that was consumed last
+        // (free until the next item's first barrier; 16-B chunks XOR-swizzled by the row: conflict-free both ways), then
+        // lane c walks column c down the rows IN ORDER with a running sum / max and the rows' graph ids (lane r + 1 of
+        // `gid`, read with v_readlane; lanes 0 / 33 hold the rows just outside the block).  A graph that lies inside the
+        // block is finished here; a piece of a graph that continues outside goes to part[block][0 = reaches the block's
+        // first row, 1 = only its last][column] for launch_pool_combine.  Rows past M carry id -1 and are dropped.
+        if (pe.pooled != nullptr) {
+            auto pool_epi = [&](auto tag) {
+                constexpr int ACT = decltype(tag)::value;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // every wave has read its last fragments
+                char *scr = smem + (size_t)((buf + DNBUF - 1) % DNBUF) * DBUF_B + (size_t)wave * 8192;
+                const int colg = n0 + wn * 32 * NT + lane; // this lane's column in the row walk
+                const bool col_ok = colg < N;
+#pragma unroll
+                for (int mi = 0; mi < MC; mi++) {
+                    const int blk0 = m0 + rbase + mi * 32;
+                    int gid = -1;
+                    {
+                        const int r = blk0 - 1 + lane;
+                        if (lane < 34 && r >= 0 && r < M)
+                            gid = pe.node_graph[r];
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int cw = ni * 32 + 8 * q + 4 * lh; // column inside the wave's 64
+                            const int cg = n0 + wn * 32 * NT + cw;
+                            float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+                            if (bias) {
+                                v.x += cg + 0 < N ? bias[cg + 0] : 0.0f;
+                                v.y += cg + 1 < N ? bias[cg + 1] : 0.0f;
+                                v.z += cg + 2 < N ? bias[cg + 2] : 0.0f;
+                                v.w += cg + 3 < N ? bias[cg + 3] : 0.0f;
+                            }
+                            v.x = act_t<ACT>(v.x), v.y = act_t<ACT>(v.y), v.z = act_t<ACT>(v.z), v.w = act_t<ACT>(v.w);
+                            *reinterpret_cast<float4 *>(scr + li * 256 + ((((cw >> 2)) ^ (li & 15)) << 4)) = v;
+                        }
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // own scratch writes + the ids (wave-private region: no barrier)
+                    const int blk = blk0 >> 5;
+                    float sum = 0.0f, mx = -INFINITY;
+                    int cur = __builtin_amdgcn_readlane(gid, 1), nrows = 0;
+                    bool open_start = cur >= 0 && __builtin_amdgcn_readlane(gid, 0) == cur;
+                    auto flush = [&](int g, int n, bool os, bool oe) { // (g, n, os, oe: wave-uniform)
+                        if (g < 0 || g >= pe.num_graphs || !col_ok)
+                            return;
+                        if (!os && !oe) {
+#pragma unroll
+                            for (int kk = 0; kk < 3; kk++) {
+                                if (kk >= pe.np)
+                                    break;
+                                float rr = sum;
+                                if (pe.pools[kk] == GNNB_POOL_MEAN)
+                                    rr = sum / (float)n;
+                                else if (pe.pools[kk] == GNNB_POOL_MAX)
+                                    rr = mx;
+                                pe.pooled[((size_t)g * pe.np + kk) * N + colg] = rr;
+                            }
+                        } else {
+                            pe.part[((size_t)blk * 2 + (os ? 0 : 1)) * N + colg] = make_float2(sum, mx);
+                        }
+                    };
+                    const char *col_p = scr + ((lane & 3) << 2);
+                    const int cch = lane >> 2;
+#pragma unroll 1
+                    for (int r = 0; r < 32; r++) {
+                        const int id = __builtin_amdgcn_readlane(gid, r + 1);
+                        if (id != cur) { // (wave-uniform)
+                            flush(cur, nrows, open_start, false);
+                            cur = id;
+                            sum = 0.0f;
+                            mx = -INFINITY;
+                            nrows = 0;
+                            open_start = false;
+                        }
+                        const float v = *reinterpret_cast<const float *>(col_p + r * 256 + ((cch ^ (r & 15)) << 4));
+                        sum += v;
+                        mx = fmaxf(mx, v);
+                        nrows++;
+                    }
+                    flush(cur, nrows, open_start, cur >= 0 && __builtin_amdgcn_readlane(gid, 33) == cur);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the walk's reads are done before the next block's writes
+                }
+            };
+            GNNB_DISPATCH_ACT(act, pool_epi)
+            return; // (the stores above are not counted in `vm`: the next waits are merely stricter)
+        }
 
         // D = W_tile . A_tile^T: lane (li, lh) holds Y[row = m_base + li][col = n_base + 8 (reg >> 2) + 4 lh + (reg & 3)]
         auto epilogue = [&](auto tag) {
@@ -1309,15 +1399,57 @@ hipError_t launch_conv_gather(const BatchTables &t, int agg_kind, float eps, con
     return launch_linear_reg_t<2, false>(x, lda, K, w, ldw, bias, skip, y, t.num_nodes, N, act, s, gd);
 }
 
+// the pieces of graphs that cross 32-row blocks, added up in block (= row) order; zeros for empty graphs.  Graphs inside
+// one block were finished by the GEMM's epilogue and are left alone.
+__global__ __launch_bounds__(WG) void k_pool_combine(PoolEpilogue pe, int M, int N)
+{
+    const int g = blockIdx.x;
+    const int g0 = min(max(pe.graph_ptr[g], 0), M), g1 = min(max(pe.graph_ptr[g + 1], g0), M);
+    const int n = g1 - g0;
+    const int b0 = g0 >> 5, b1 = (g1 - 1) >> 5;
+    if (n > 0 && b0 == b1)
+        return;
+    for (int c = threadIdx.x; c < N; c += WG) {
+        float sum = 0.0f, mx = n > 0 ? -INFINITY : 0.0f;
+        for (int b = b0; n > 0 && b <= b1; b++) {
+            const int slot = (b == b0 && g0 > (b0 << 5)) ? 1 : 0;
+            const float2 p = pe.part[((size_t)b * 2 + slot) * N + c];
+            sum += p.x;
+            mx = fmaxf(mx, p.y);
+        }
+        for (int kk = 0; kk < pe.np; kk++) {
+            float rr = sum;
+            if (pe.pools[kk] == GNNB_POOL_MEAN)
+                rr = n > 0 ? sum / (float)n : 0.0f;
+            else if (pe.pools[kk] == GNNB_POOL_MAX)
+                rr = mx;
+            pe.pooled[((size_t)g * pe.np + kk) * N + c] = rr;
+        }
+    }
+}
+
+hipError_t launch_pool_combine(const PoolEpilogue &pe, int M, int N, hipStream_t s)
+{
+    if (pe.num_graphs <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_pool_combine, dim3(pe.num_graphs), dim3(WG), 0, s, pe, M, N);
+    return hipGetLastError();
+}
+
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
-                         const float *skip, float *y, int M, int N, int act, hipStream_t s)
+                         const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pep)
 {
     if (M <= 0 || N <= 0)
-        return hipSuccess;
-    if (linear_wlds_eligible(g, w, ldw, bias, skip, y, N))
-        return launch_linear_wlds(g, w, ldw, bias, skip, y, M, N, act, s);
-    if (linear_reg_eligible(g))
-        return launch_linear_reg(g, w, ldw, bias, skip, y, M, N, act, s);
+        return pep ? hipErrorNotSupported : hipSuccess;
+    const PoolEpilogue pe = pep ? *pep : PoolEpilogue{};
+    if (!pep) {
+        if (linear_wlds_eligible(g, w, ldw, bias, skip, y, N))
+            return launch_linear_wlds(g, w, ldw, bias, skip, y, M, N, act, s);
+        if (linear_reg_eligible(g))
+            return launch_linear_reg(g, w, ldw, bias, skip, y, M, N, act, s);
+    } else if (skip != nullptr || linear_wlds_eligible(g, w, ldw, bias, skip, y, N) || linear_reg_eligible(g)) {
+        return hipErrorNotSupported; // (the pooling epilogue exists in k_linear_dma: the large-K segmented GEMM)
+    }
     const int gm = (M + BM - 1) / BM;
     if (N > 64 && options().gemm_dma) {
         bool plain = (ldw % 4 == 0) && (((uintptr_t)w & 15) == 0);
@@ -1337,19 +1469,21 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             // in 2 or 4 row slices per tile when those still fit one round (see the kernel)
             const int rem = tiles % num_cus;
             int split = 1;
-            if (options().gemm_tail_split && rem > 0)
+            if (options().gemm_tail_split && rem > 0 && !pep) // (pooling epilogue: whole tiles only -- its blocks are 32-row aligned, every wave joins its barrier)
                 split = 4 * rem <= DWGPC * num_cus ? 4 : (2 * rem <= DWGPC * num_cus ? 2 : 1);
             const int split_from = split > 1 ? tiles - rem : tiles;
             const int grid = std::min(split_from + split * (tiles - split_from), DWGPC * num_cus);
             if (options().math)
                 hipLaunchKernelGGL(k_linear_dma<1>, dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, tn,
-                                   split_from, split);
+                                   split_from, split, pe);
             else
                 hipLaunchKernelGGL(k_linear_dma<0>, dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, tn,
-                                   split_from, split);
+                                   split_from, split, pe);
             return hipGetLastError();
         }
     }
+    if (pep)
+        return hipErrorNotSupported;
     if (N > 64) {
         constexpr int NT = 2;
         const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * 64 * NT * LDS_LD) * 4;

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     float *__restrict__ amp, float *__restrict__ att, float delta,
     int32_t *__restrict__ tile_first, int32_t *__restrict__ tile_edge, int32_t *__restrict__ tile_graph,
     int32_t *__restrict__ graph_ptr, int tile_rows, int num_tiles, int max_graph_nodes_hint, int promise_graphs, int large_n,
-    int large_e, int drop_self, int32_t *__restrict__ err, int32_t *__restrict__ err_host)
+    int large_e, int drop_self, int32_t *__restrict__ err, int32_t *__restrict__ err_host, int4 *__restrict__ agg_cut, int cut_log2,
+    int32_t *__restrict__ node_graph)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_first[WG / 64][PREP_FAST_NODES * 4]; // first four sources of every node (read / written 16 B at a time)
     // Highest wave priority: with batches in flight on several streams this kernel runs BESIDE the conv-stack kernel of
@@ -326,6 +327,8 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     auto empty_rows = [&](int r0, int r1) {
         for (int v = r0 + lane; v < r1; v += 64) {
             row_ptr[v] = 0;
+            if (node_graph)
+                node_graph[v] = -1;
             node_rec[2 * (size_t)v] = make_int4(0, 0, v, v);
             node_rec[2 * (size_t)v + 1] = make_int4(v, v, 0, 0);
             dinv[v] = 1.0f;
@@ -338,6 +341,8 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
     if (g == B) {
         const int first = node_ptr[0], last = node_ptr[B];
         if (lane == 0) {
+            if (agg_cut)
+                agg_cut[1 << cut_log2] = make_int4(N, N, E, B); // (the end of the last range)
             row_ptr[N] = E;
             if (last != N || edge_ptr[B] != E || first != 0 || edge_ptr[0] != 0)
                 flag_batch(err, err_host, 1);
@@ -365,6 +370,25 @@ __global__ __launch_bounds__(WG) void k_graph_prep(
             e1 = e0; // no usable edge range: the rows get empty records
     }
     const int n = n1 - n0, ne = e1 - e0;
+    if (node_graph) // (the pooling epilogue of the last layer's GEMM walks rows by graph id: launch_linear, PoolEpilogue)
+        for (int v = n0 + lane; v < n1; v += 64)
+            node_graph[v] = g;
+    // Row-balanced ranges of the gather-aggregate workgroups (k_aggregate_ring): range b of 2^cut_log2 starts at row
+    // floor(b N / 2^cut_log2), usually in the middle of a graph -- the wave of the graph that owns that row records the
+    // graph's first row / CSR slot beside it (both neighbours stage the boundary graph, each reduces its own rows).  No
+    // search: lane l tests candidate b_est - 1 + l around a float estimate, exactly.
+    if (agg_cut) {
+        int bb = (int)((float)n0 * (float)(1 << cut_log2) / (float)max(N, 1)) - 2; // (wave-uniform)
+        do { // (one pass for any graph of less than ~60 ranges' worth of rows)
+            const int b = bb + lane;
+            if (b >= 0 && b < (1 << cut_log2)) {
+                const int r = (int)(((long long)b * N) >> cut_log2);
+                if (r >= n0 && r < n1)
+                    agg_cut[b] = make_int4(r, n0, e0, g);
+            }
+            bb += 64;
+        } while (bb < (1 << cut_log2) && (int)(((long long)max(bb, 0) * N) >> cut_log2) < n1);
+    }
     if (max_graph_nodes_hint > 0 && n > max_graph_nodes_hint && g < promise_graphs && lane == 0)
         flag_batch(err, err_host, 8); // the caller's max_graph_nodes promise does not hold for this batch
     if (n > PREP_FAST_NODES || ne > PREP_FAST_EDGES) { // wave-uniform
@@ -518,16 +542,22 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
     // (gnnb_workspace_check), so no per-batch memset node sits in front of this launch
     const int waves = t.num_graphs + 1;
     const int grid = (waves + (WG / 64) - 1) / (WG / 64);
+    int cut_log2 = -1; // (row-balanced aggregate ranges: only for a power-of-two range count)
+    if (t.agg_cut && t.agg_cut_n > 0 && (t.agg_cut_n & (t.agg_cut_n - 1)) == 0 && t.num_nodes > 0)
+        for (cut_log2 = 0; (1 << cut_log2) < t.agg_cut_n; cut_log2++) {
+        }
     if (t.max_graph_nodes_hint > 0 && t.max_graph_nodes_hint <= 64)
         hipLaunchKernelGGL(k_graph_prep<64>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, t.large_n, t.large_e, drop_self_loops, t.err, t.err_host_dev);
+                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, t.large_n, t.large_e, drop_self_loops, t.err, t.err_host_dev,
+                           cut_log2 >= 0 ? t.agg_cut : nullptr, cut_log2, t.node_graph);
     else
         hipLaunchKernelGGL(k_graph_prep<256>, dim3(grid), dim3(WG), 0, s, (const int2 *)coo, node_ptr,
                            edge_ptr, t.num_graphs, t.num_nodes, t.num_edges, t.row_ptr, t.col, t.eid, t.node_rec,
                            t.dinv, t.amp, t.att, pna_delta, t.tile_first, t.tile_edge, t.tile_graph, t.graph_ptr, t.tile_rows,
-                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, t.large_n, t.large_e, drop_self_loops, t.err, t.err_host_dev);
+                           t.num_tiles, t.max_graph_nodes_hint, t.promise_graphs, t.large_n, t.large_e, drop_self_loops, t.err, t.err_host_dev,
+                           cut_log2 >= 0 ? t.agg_cut : nullptr, cut_log2, t.node_graph);
     return hipGetLastError();
 }
 

@@ -303,7 +303,7 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
 /* tuning knobs (also read from the environment at load as GNNB_<NAME>): they select between parity-tested forms of the
  * same computation and never change results beyond fp32 rounding.
  *   tile_rows (>= 4, default 8)  node-tile size of graph prep         agg_lds_kb, agg_ring_waves / _slots / _wg_per_cu,
- *   agg_nt_store                 launch shape of the gather-aggregate  gemm_variant, gemm_dma, gemm_tail_split,
+ *   agg_nt_store, agg_balance    launch shape of the gather-aggregate  gemm_variant, gemm_dma, gemm_tail_split,
  *   gemm_wlds, gemm_wlds_slots, gemm_max_wg_per_cu  which GEMM kernel   fuse_narrow, fuse_gcn2, fuse_head, head_small,
  *   head_split                   which launches are fused (0 = layer by layer / separate readout)
  *   fuse_zf (default 1)          2-layer fp32 GCN stacks through k_gcn2_zf (last layer transformed before it is aggregated);

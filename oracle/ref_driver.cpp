@@ -60,6 +60,7 @@ typedef float W_TYPE;
     X(9, 128)             \
     X(11, 128)            \
     X(128, 128)           \
+    X(128, 64)            \
     X(9, 256)             \
     X(256, 256)
 

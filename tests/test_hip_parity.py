@@ -279,6 +279,47 @@ def test_weight_free_convs_on_degenerate_and_large_graphs(dev):
     assert torch.equal(cm.aggregate("copy", xd), xd)
 
 
+@pytest.mark.parametrize("shape,graphs,width", [("molhiv_tail", 2500, 128), ("qm9", 4096, 128), ("molhiv", 1500, 20), ("qm9", 3000, 256)])
+def test_row_balanced_aggregate_ranges_change_nothing(dev, shape, graphs, width):
+    """Round 4 (opt-in, `agg_balance`): the ring kernel's workgroups take an exact 1 / grid share of the ROWS (graph prep's
+    cut table; the boundary graph is staged by both neighbours, each reduces its own rows) instead of whole-graph runs.
+    Every aggregate kind, on batches large enough to have a range per workgroup (incl. graphs larger than an LDS stage: the
+    direct path is clipped too), float4 and scalar rows: identical to the whole-graph ranges -- bit for bit where a row's
+    arithmetic does not depend on whether its graph was staged in LDS or read from L2 (every kind but the two with
+    coefficients, GCN and LG: there the staged path multiplies by a precomputed coefficient) --, and SUM / MEAN equal to a
+    plain scatter formulation in fp64 to fp32 rounding."""
+    batch = synthetic.make_batch(shape, graphs, seed=13)
+    rng = np.random.default_rng(width)
+    x = rng.uniform(-1, 1, (batch.num_nodes, width)).astype(np.float32)
+    q = rng.uniform(-1, 1, (batch.num_nodes, width)).astype(np.float32)
+    outs = {}
+    try:
+        for bal in (1, 0):
+            runtime.set_option("agg_balance", bal)
+            cm = runtime.CompiledModel.from_model(plain_model("pna", 8, 8), batch.num_graphs, batch.num_nodes, batch.num_edges)
+            _, cood, nptr, eptr = to_dev(batch, dev)
+            cm.graph_prep(cood, nptr, eptr, batch.num_nodes)
+            xd, qd = torch.from_numpy(x).to(dev), torch.from_numpy(q).to(dev)
+            for kind in ("gcn", "sum", "mean", "pna", "lg", "simple", "copy"):
+                outs[(kind, bal)] = cm.aggregate(kind, xd, self_term=qd if kind == "pna" else None, eps=0.25).cpu().numpy()
+            cm.check()
+    finally:
+        runtime.set_option("agg_balance", 0)
+    for kind in ("sum", "mean", "pna", "simple", "copy"):
+        assert np.array_equal(outs[(kind, 1)], outs[(kind, 0)]), kind
+    for kind in ("gcn", "lg"):
+        assert np.abs(outs[(kind, 1)] - outs[(kind, 0)]).max() < 1e-6, kind
+    assert np.array_equal(outs[("copy", 1)], x)
+    # independent check of two kinds in float64 (scatter form)
+    src, dst = batch.coo[:, 0], batch.coo[:, 1]
+    deg = np.bincount(dst, minlength=batch.num_nodes).astype(np.float64)
+    mean = np.zeros((batch.num_nodes, width))
+    np.add.at(mean, dst, x[src].astype(np.float64))
+    ssum = mean + 1.25 * x
+    mean = np.where(deg[:, None] > 0, mean / np.maximum(deg, 1)[:, None], 0.0)
+    assert np.abs(outs[("mean", 1)] - mean).max() < 1e-5 and np.abs(outs[("sum", 1)] - ssum).max() < 2e-5
+
+
 def test_malformed_batch_is_reported(dev):
     batch = synthetic.make_batch("qm9", 8, 0)
     bad = batch.coo.copy()
