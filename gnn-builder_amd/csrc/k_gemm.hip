@@ -499,7 +499,10 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             const int cw = ni * 32 + 8 * q + 4 * lh; // column inside the wave's 64
                             const int cg = n0 + wn * 32 * NT + cw;
                             float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
-                            if (bias) {
+                            if (bias && vec && cg + 3 < N) {
+                                const float4 bv = *reinterpret_cast<const float4 *>(bias + cg);
+                                v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                            } else if (bias) {
                                 v.x += cg + 0 < N ? bias[cg + 0] : 0.0f;
                                 v.y += cg + 1 < N ? bias[cg + 1] : 0.0f;
                                 v.z += cg + 2 < N ? bias[cg + 2] : 0.0f;
@@ -535,20 +538,26 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                     const char *col_p = scr + ((lane & 3) << 2);
                     const int cch = lane >> 2;
 #pragma unroll 1
-                    for (int r = 0; r < 32; r++) {
-                        const int id = __builtin_amdgcn_readlane(gid, r + 1);
-                        if (id != cur) { // (wave-uniform)
-                            flush(cur, nrows, open_start, false);
-                            cur = id;
-                            sum = 0.0f;
-                            mx = -INFINITY;
-                            nrows = 0;
-                            open_start = false;
+                    for (int r8 = 0; r8 < 32; r8 += 8) { // eight rows per step: their LDS reads go out together
+                        float v8[8];
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                            v8[i] = *reinterpret_cast<const float *>(col_p + (r8 + i) * 256 + ((cch ^ ((r8 + i) & 15)) << 4));
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const int id = __builtin_amdgcn_readlane(gid, r8 + i + 1);
+                            if (id != cur) { // (wave-uniform)
+                                flush(cur, nrows, open_start, false);
+                                cur = id;
+                                sum = 0.0f;
+                                mx = -INFINITY;
+                                nrows = 0;
+                                open_start = false;
+                            }
+                            sum += v8[i];
+                            mx = fmaxf(mx, v8[i]);
+                            nrows++;
                         }
-                        const float v = *reinterpret_cast<const float *>(col_p + r * 256 + ((cch ^ (r & 15)) << 4));
-                        sum += v;
-                        mx = fmaxf(mx, v);
-                        nrows++;
                     }
                     flush(cur, nrows, open_start, cur >= 0 && __builtin_amdgcn_readlane(gid, 33) == cur);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the walk's reads are done before the next block's writes
@@ -1412,7 +1421,7 @@ __global__ __launch_bounds__(WG) void k_pool_combine(PoolEpilogue pe, int M, int
     for (int c = threadIdx.x; c < N; c += WG) {
         float sum = 0.0f, mx = n > 0 ? -INFINITY : 0.0f;
         for (int b = b0; n > 0 && b <= b1; b++) {
-            const int slot = (b == b0 && g0 > (b0 << 5)) ? 1 : 0;
+            const int slot = b == b0 ? 1 : 0; // (the graph's first block holds its head -- open at the end only --, every later block a piece that reaches the block's first row)
             const float2 p = pe.part[((size_t)b * 2 + slot) * N + c];
             sum += p.x;
             mx = fmaxf(mx, p.y);

@@ -320,6 +320,47 @@ def test_row_balanced_aggregate_ranges_change_nothing(dev, shape, graphs, width)
     assert np.abs(outs[("mean", 1)] - mean).max() < 1e-5 and np.abs(outs[("sum", 1)] - ssum).max() < 2e-5
 
 
+@pytest.mark.parametrize("hidden,layers,pools,act", [(256, 2, ("add", "mean", "max"), "relu"), (128, 3, ("max", "add"), "tanh"),
+                                                     (256, 1, ("mean",), "sigmoid"), (128, 2, ("add", "mean", "max"), "gelu")])
+def test_pooling_in_the_last_gemm_epilogue(dev, hidden, layers, pools, act):
+    """GraphSAGE: the last layer's large-K GEMM pools in its epilogue (32-row blocks, graphs crossing blocks combined in
+    row order by k_pool_combine) and never writes its [N, d] output -- against the separate pooling pass (fuse_pool = 0)
+    and the oracle, EVERY graph.  Batch: heavy-tailed sizes (graphs of 100+ rows span several blocks and tiles), runs of
+    one- and two-node graphs (many graphs inside one block), graphs that start exactly on a block boundary, empty graphs at
+    both ends and in the middle, a row count that is no multiple of the 128-row tile; and the same graphs in reverse order."""
+    model = make_model("sage", in_dim=9, hidden=hidden, layers=layers, act=act, pools=pools, task_out=3, seed=hidden + layers)
+    rng = np.random.default_rng(layers)
+    base = synthetic.make_batch("molhiv_tail", 700, seed=17)
+    empty = (np.zeros((0, 9), np.float32), np.zeros((0, 2), np.int32))
+
+    def chain(k):  # a path graph of k nodes
+        e = np.array([[i, i + 1] for i in range(k - 1)] + [[i + 1, i] for i in range(k - 1)], np.int32).reshape(-1, 2)
+        return rng.uniform(-1, 1, (k, 9)).astype(np.float32), e
+
+    tiny = [chain(k) for k in (1, 2, 1, 1, 3, 2, 1, 1, 1, 2) * 4]
+    aligned = [chain(32), chain(64), chain(40), chain(24), chain(96), chain(33)]  # (the first starts on row 0: block-aligned heads)
+    graphs = aligned + [empty, empty] + [base.graph(g) for g in range(350)] + tiny + [empty] + [base.graph(g) for g in range(350, 700)] + [empty]
+    for order in (1, -1):
+        batch = pack_graphs(graphs[::order])
+        assert batch.num_nodes % 128 != 0 and int(np.diff(batch.node_ptr).max()) >= 96
+        ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+        outs = {}
+        try:
+            for fuse in (1, 0):
+                runtime.set_option("fuse_pool", fuse)
+                cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+                outs[fuse] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+                cm.check()
+                outs[(fuse, 2)] = cm.forward(*to_dev(batch, dev)).cpu().numpy()  # (a second forward on the same workspace)
+        finally:
+            runtime.set_option("fuse_pool", 1)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.isfinite(outs[1]).all()
+        assert np.abs(outs[1] - ref).max() < TOL * scale and np.abs(outs[0] - ref).max() < TOL * scale
+        assert np.abs(outs[1] - outs[0]).max() < 2e-5 * scale
+        assert np.array_equal(outs[1], outs[(1, 2)])  # deterministic: the same batch gives the same bits
+
+
 def test_malformed_batch_is_reported(dev):
     batch = synthetic.make_batch("qm9", 8, 0)
     bad = batch.coo.copy()
