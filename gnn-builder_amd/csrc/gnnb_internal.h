@@ -68,6 +68,8 @@ struct Options {
     int gemm_wlds;     // 1 = K, N in {64,128}, no skip operand: weights-in-LDS, barrier-free kernel (default); 0 = register-resident weights
     int gemm_wlds_slots; // ... its ring depth per wave (capped by what fits beside W in LDS)
     int fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
+    int first_ring;    // ... 1 = in ring form (k_conv_first: graphs staged in LDS, all columns from one stage; default), 0 = inside
+                       //     k_linear_reg's A stage (round 3)
     int fuse_zf;       // 1 = a 2-layer fp32 GCN stack takes k_gcn2_zf (last layer transformed before it is aggregated, 96-row
                        //     stages) instead of k_gcn2_fused (default); needs fuse_gcn2
     int large_fork;    // a batch's large segment: 2 = through k_conv_rows on the caller's stream behind the stack kernel (default:
@@ -137,6 +139,10 @@ struct PoolEpilogue {
 // epilogue -- the caller then runs the plain GEMM + a pooling pass
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
                          const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pe = nullptr);
+// the same narrow-input layer in ring form (k_first.hip): whole graphs staged in LDS once for ALL N <= 256 output columns;
+// F = width of x, K = F or (cat = F) 2 F.  hipErrorNotSupported -> launch_conv_gather's k_linear_reg form
+hipError_t launch_conv_first(const BatchTables &t, int agg_kind, float eps, const float *x, int F, int K, const float *w,
+                             int ldw, const float *bias, float *y, int Nout, int act, hipStream_t s, int cat);
 // the pieces of graphs that cross 32-row blocks -> pooled (and zeros for empty graphs); after launch_linear(..., pe)
 hipError_t launch_pool_combine(const PoolEpilogue &pe, int M, int N, hipStream_t s);
 

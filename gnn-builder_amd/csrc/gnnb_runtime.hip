@@ -57,7 +57,7 @@ Options &options()
                         env_int("GNNB_GEMM_VARIANT", 0),
                         env_int("GNNB_GEMM_MAX_WG_PER_CU", 2), env_int("GNNB_GEMM_DMA", 1),
                         env_int("GNNB_GEMM_WLDS", 1),             env_int("GNNB_GEMM_WLDS_SLOTS", 2),
-                        env_int("GNNB_FUSE_NARROW", 1),     env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
+                        env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
                         env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 1)};
@@ -221,6 +221,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_balance = value;
     else if (!strcmp(name, "fuse_narrow") && value >= 0 && value <= 1)
         o.fuse_narrow = value;
+    else if (!strcmp(name, "first_ring") && value >= 0 && value <= 1)
+        o.first_ring = value;
     else if (!strcmp(name, "fuse_gcn2") && value >= 0 && value <= 1)
         o.fuse_gcn2 = value;
     else if (!strcmp(name, "fuse_zf") && value >= 0 && value <= 1)

@@ -1396,6 +1396,12 @@ hipError_t launch_conv_gather(const BatchTables &t, int agg_kind, float eps, con
     // K = width of the stage row the GEMM contracts over: F_in, or 2 F_in in the [aggregate | own row] form
     if (K > 32 || agg_kind == GNNB_AGG_PNA || t.num_nodes <= 0 || (cat > 0 && K != 2 * cat))
         return hipErrorNotSupported;
+    // the ring form (k_first.hip): whole graphs staged once for all output columns
+    if (options().first_ring && skip == nullptr && lda == (cat > 0 ? cat : K)) {
+        hipError_t he = launch_conv_first(t, agg_kind, eps, x, lda, K, w, ldw, bias, y, N, act, s, cat);
+        if (he != hipErrorNotSupported)
+            return he;
+    }
     GatherDesc gd;
     gd.rec = t.node_rec;
     gd.col = t.col;

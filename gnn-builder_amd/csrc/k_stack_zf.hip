@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 )
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ZF_CAP = 16 * ZF_UNITS, G2_NW = NW, G2_WG = NW * 64;
+    constexpr int ZF_CAP = 16 * ZF_UNITS, G2_NW = NW;
     constexpr int GMAX = ZF_CAP <= 96 ? 64 : 128; // graph boundaries of a stage kept in LDS (more: empty graphs piling up)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- LDS carve (bytes, every region 16-B aligned; LDS pointers are always derived arithmetically from `smem`:

@@ -361,6 +361,48 @@ def test_pooling_in_the_last_gemm_epilogue(dev, hidden, layers, pools, act):
         assert np.array_equal(outs[1], outs[(1, 2)])  # deterministic: the same batch gives the same bits
 
 
+@pytest.mark.parametrize("conv,fin,hidden,act", [("sage", 9, 256, "relu"), ("sage", 16, 100, "tanh"), ("gcn", 11, 128, "relu"),
+                                                 ("gcn", 20, 64, "gelu"), ("gin", 9, 128, "relu"), ("gin", 32, 256, "sigmoid"),
+                                                 ("sage", 4, 16, "relu")])
+def test_narrow_first_layer_in_ring_form(dev, conv, fin, hidden, act):
+    """k_conv_first (round 4): the narrow first layer with whole graphs staged in LDS and all output columns from one stage,
+    against the round-3 form (inside k_linear_reg's A stage, `first_ring` = 0), the unfused form and the oracle.  Batch:
+    molecules, graphs of 130-300 nodes (beyond a stage: taken in pieces from L2) incl. a hub of degree 200, isolated nodes,
+    one-node and empty graphs at both ends, duplicate edges and self loops."""
+    model = make_model(conv, in_dim=fin, hidden=hidden, layers=2, act=act, pools=("add", "max"), task_out=3, seed=fin + hidden)
+    rng = np.random.default_rng(fin)
+    base = synthetic.make_batch("molhiv_tail", 260, seed=fin)
+    empty = (np.zeros((0, fin), np.float32), np.zeros((0, 2), np.int32))
+
+    def rnd(n, e, hub=False):
+        coo = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int32)
+        if hub:
+            coo = np.concatenate([coo, np.stack([np.arange(1, 201), np.zeros(200, np.int64)], 1).astype(np.int32)])
+        return rng.uniform(-1, 1, (n, fin)).astype(np.float32), coo
+
+    graphs = [empty, rnd(1, 0)] + [(rng.uniform(-1, 1, (base.graph(g)[0].shape[0], fin)).astype(np.float32), base.graph(g)[1]) for g in range(130)]
+    graphs += [rnd(300, 900, hub=True), rnd(131, 260), empty, rnd(129, 10)]
+    graphs += [(rng.uniform(-1, 1, (base.graph(g)[0].shape[0], fin)).astype(np.float32), base.graph(g)[1]) for g in range(130, 260)] + [rnd(2, 5), empty]
+    batch = pack_graphs(graphs)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    outs = {}
+    try:
+        for ring, narrow in ((1, 1), (0, 1), (0, 0)):
+            runtime.set_option("first_ring", ring)
+            runtime.set_option("fuse_narrow", narrow)
+            cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+            outs[(ring, narrow)] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            cm.check()
+            assert cm.last_path() == "layerwise"
+    finally:
+        runtime.set_option("first_ring", 1)
+        runtime.set_option("fuse_narrow", 1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for k, v in outs.items():
+        assert np.isfinite(v).all() and np.abs(v - ref).max() < TOL * scale, k
+    assert np.abs(outs[(1, 1)] - outs[(0, 0)]).max() < 2e-5 * scale
+
+
 def test_malformed_batch_is_reported(dev):
     batch = synthetic.make_batch("qm9", 8, 0)
     bad = batch.coo.copy()
