@@ -25,7 +25,16 @@ namespace gnnb {
 // Graphs larger than a stage (no max_graph_nodes promise on this path) are taken in pieces whose sources are read from
 // global memory (L2) instead of LDS -- same arithmetic, same order.
 // Sums run in CSR order with the self term last, as k_aggregate_ring and the reference do.
-static constexpr int F1_NW = 8, F1_WG = F1_NW * 64, F1_CAP = 128, F1_ECAP = 1024; // rows / CSR entries per stage
+#ifndef F1_CAP_ROWS
+#define F1_CAP_ROWS 128
+#endif
+#ifndef F1_ABLATE   // development: 1 no stores, 2 no MFMA, 4 no P0, 8 no DMA (timing only: WRONG results)
+#define F1_ABLATE 0
+#endif
+#ifndef F1_NT_STORE
+#define F1_NT_STORE 1
+#endif
+static constexpr int F1_NW = 8, F1_WG = F1_NW * 64, F1_CAP = F1_CAP_ROWS, F1_ECAP = 8 * F1_CAP_ROWS; // rows / CSR entries per stage
 
 struct F1Stage {
     int ok, nb, rows, e0, ne, direct, next_t, next_row; // direct: the piece's sources are read from global memory
@@ -46,6 +55,8 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
     const int xs_b = ((F1_CAP * F * 4) + 15) & ~15;
     const int rec_o = xs_b, dinv_o = rec_o + F1_CAP * 32, col_o = dinv_o + F1_CAP * 4, in_b = col_o + F1_ECAP * 4;
     float *A0 = reinterpret_cast<float *>(smem + 2 * (size_t)in_b);
+    // per-wave scratch for the output transpose: 16 rows x 32 columns (+ 4 floats of padding per row)
+    float *ST = A0 + F1_CAP * LD0 + wave * (16 * 36);
 
     const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
     const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
     };
     int vm = 0; // vector-memory instructions this wave has issued (DMA + stores): counted waits (VM operations retire in order)
     auto issue = [&](const F1Stage &st, int bb) {
-        if (!st.ok || st.direct || st.rows <= 0)
+        if (!st.ok || st.direct || st.rows <= 0 || (F1_ABLATE & 8))
             return;
         char *base = smem + (size_t)bb * in_b;
         const int nx = st.rows * F;
@@ -130,10 +141,10 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
     issue(nxt, 1);
     int mark_nxt = vm;
 
-    // ---- wave roles: NS = slices of 16 output columns; a wave owns SPW adjacent slices (32 columns when N > 128) for the
-    // units rg, rg + RGN, ...
+    // ---- wave roles: NS = slices of 16 output columns; a wave owns SPW adjacent slices (32 columns) for the units rg,
+    // rg + RGN, ...
     const int NS = (Nout + 15) >> 4;
-    const int SPW = NS > 8 ? 2 : 1;
+    const int SPW = NS >= 2 ? 2 : 1; // (two ADJACENT slices per wave wherever there are two: whole 128-B lines per stored row)
     int cwl = 0;
     while ((1 << cwl) * SPW < NS && cwl < 3)
         cwl++;
@@ -183,7 +194,11 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
             vmcnt_wait_n(min(vm - mark_cur, 63));
         g2_barrier();
         // ---- P0: A0[i][pos(fk)] for the stage column fk < K: eight lanes per row, lane l8 takes columns l8, l8 + 8, ...
-        {
+        // TWO copies of the loop, staged and direct, chosen per stage: inside one loop the compiler joins the two sources of
+        // a value behind an unconditional s_waitcnt vmcnt(0) -- the direct path's global loads -- which in EVERY row pass
+        // also waited for the DMA of the stages ahead and the output stores of the stage before (77 us instead of 4x)
+        auto p0 = [&](auto dtag) {
+            constexpr bool DIRECT = decltype(dtag)::value != 0;
             constexpr int T0 = 2 * KQ; // columns per lane (16 KQ / 8)
             const char *base = smem + (size_t)b * in_b;
             const float *xs = reinterpret_cast<const float *>(base);
@@ -191,10 +206,9 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
             const float *sdinv = reinterpret_cast<const float *>(base + dinv_o);
             const int32_t *scol = reinterpret_cast<const int32_t *>(base + col_o);
             const int l8 = tid & 7;
-            const bool direct = cur.direct != 0;
             for (int i = tid >> 3; i < rows; i += F1_WG / 8) {
                 int4 r0, r1;
-                if (direct) { // (two loops, not a select between an LDS and a global pointer: that becomes a flat load)
+                if (DIRECT) {
                     r0 = node_rec[2 * (size_t)(nb + i)];
                     r1 = node_rec[2 * (size_t)(nb + i) + 1];
                 } else {
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
                     acc[t] = 0.0f;
                 }
                 float di = 1.0f;
-                if (direct) {
+                if (DIRECT) {
                     if (MODE == GNNB_AGG_GCN)
                         di = dinv[nb + i];
 #pragma unroll
@@ -273,7 +287,12 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
                     A0[i * LD0 + fp] = fk < K ? v : 0.0f;
                 }
             }
-        }
+        };
+        if (F1_ABLATE & 4) {
+        } else if (cur.direct)
+            p0(IntTag<1>{});
+        else
+            p0(IntTag<0>{});
         g2_barrier(); // A0 complete; the input buffer is free
         // ---- the stage after next starts its way to LDS (into the buffer P0 just consumed)
         const F1Stage nn = plan(nxt.next_t, nxt.next_row);
@@ -283,6 +302,10 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
         // ---- M + ST
         {
             const int units = (rows + 15) >> 4;
+            // 16-B store instructions this wave issues per unit: one per slice it owns that holds a column (wave-uniform;
+            // such an instruction always has an active lane -- row u * 16 of the unit, columns 4 lg = 0 of the slice)
+            const int st_per_unit = vec_out ? min(max(NS - cw * SPW, 0), SPW) : 0;
+            const bool wide_rows = vec_out && SPW == 2 && cw * 32 + 32 <= Nout; // (wave-uniform)
             for (int u = rg; u < units; u += RGN) {
                 const float *ap = A0 + (u * 16 + li) * LD0 + 4 * lg;
                 float4 a4[KQ];
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
                 for (int q = 0; q < KQ; q++)
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
-                        if (q * 4 + t >= nsteps) // (wave-uniform: this k step holds no feature)
+                        if (q * 4 + t >= nsteps || (F1_ABLATE & 2)) // (wave-uniform: this k step holds no feature)
                             break;
                         const float av = t == 0 ? a4[q].x : (t == 1 ? a4[q].y : (t == 2 ? a4[q].z : a4[q].w));
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][q * 4 + t], av, acc[0], 0, 0, 0);
@@ -305,6 +328,34 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
                             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][q * 4 + t], av, acc[1], 0, 0, 0);
                     }
                 const int row = u * 16 + li;
+                if (wide_rows) {
+                    // two adjacent slices = 32 columns = one 128-B line per row: through the wave's LDS scratch, so that a
+                    // store instruction writes EIGHT WHOLE lines (8 lanes x 16 B per row) instead of sixteen 64-B halves --
+                    // straight from the accumulators the kernel was store-bound at 2.9 TB/s (77 us at BASELINE config 5,
+                    // 18 us with the stores compiled out)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        *reinterpret_cast<float4 *>(ST + li * 36 + j * 16 + 4 * lg) =
+                            make_float4(act_t<ACT>(acc[j][0]), act_t<ACT>(acc[j][1]), act_t<ACT>(acc[j][2]), act_t<ACT>(acc[j][3]));
+                    // (same wave writes and reads: the LDS executes a wave's operations in order)
+                    vm += u * 16 + 8 < rows ? 2 : 1; // (a store instruction per half of the unit that holds a row)
+#pragma unroll
+                    for (int ps = 0; ps < 2; ps++) {
+                        const int rr = ps * 8 + (lane >> 3), cc = (lane & 7) * 4;
+                        const float4 v = *reinterpret_cast<const float4 *>(ST + rr * 36 + cc);
+                        if (u * 16 + rr < rows && !(F1_ABLATE & 1)) {
+                            float *yp = Y + (size_t)(nb + u * 16 + rr) * Nout + cw * 32 + cc;
+#if F1_NT_STORE
+                            agg_f32x4 tv = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(tv, reinterpret_cast<agg_f32x4 *>(yp));
+#else
+                            *reinterpret_cast<float4 *>(yp) = v;
+#endif
+                        }
+                    }
+                    continue;
+                }
+                vm += st_per_unit;
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     if (j >= SPW)
@@ -312,10 +363,14 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
                     const int c0 = (cw * SPW + j) * 16 + 4 * lg;
                     float4 v = make_float4(act_t<ACT>(acc[j][0]), act_t<ACT>(acc[j][1]), act_t<ACT>(acc[j][2]), act_t<ACT>(acc[j][3]));
                     float *yp = Y + (size_t)(nb + row) * Nout + c0;
-                    if (row < rows && c0 < Nout) {
+                    if (row < rows && c0 < Nout && !(F1_ABLATE & 1)) {
                         if (vec_out && c0 + 3 < Nout) {
+#if F1_NT_STORE
                             agg_f32x4 tv = {v.x, v.y, v.z, v.w};
                             __builtin_nontemporal_store(tv, reinterpret_cast<agg_f32x4 *>(yp));
+#else
+                            *reinterpret_cast<float4 *>(yp) = v;
+#endif
                         } else {
                             yp[0] = v.x;
                             if (c0 + 1 < Nout) yp[1] = v.y;
@@ -326,8 +381,9 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
                 }
             }
         }
-        // (the stores are tracked by the compiler, the DMA is not: nothing is counted for them -- the next waits are merely
-        // stricter, see vmcnt_wait_n)
+        // (the 16-B stores are COUNTED in `vm` like the DMA: the wait at the top of the next stage must leave them -- and the
+        // DMA of the stage after next, issued in front of them -- in flight; uncounted, every stage waited for a memory round
+        // trip: 77 us instead of 4x us at BASELINE config 5.  The scalar-store path is not counted: its waits are stricter.)
         cur = nxt;
         mark_cur = mark_nxt;
         nxt = nn;
@@ -350,7 +406,7 @@ hipError_t launch_conv_first(const BatchTables &t, int agg_kind, float eps, cons
     const int kq = K <= 16 ? 1 : 2;
     const int xs_b = ((F1_CAP * F * 4) + 15) & ~15;
     const size_t in_b = (size_t)xs_b + F1_CAP * 32 + F1_CAP * 4 + F1_ECAP * 4;
-    const size_t lds = 2 * in_b + (size_t)F1_CAP * (16 * kq + 4) * 4;
+    const size_t lds = 2 * in_b + (size_t)F1_CAP * (16 * kq + 4) * 4 + (size_t)F1_NW * 16 * 36 * 4;
     const int cus = device_cu_count();
     long long grid = std::min<long long>(2LL * cus, t.num_tiles);
     if (grid < 1)
