@@ -1219,9 +1219,14 @@ __global__ __launch_bounds__(WG, 1) void k_linear_wlds(const float *__restrict__
     int pm = M;              // ... their row (>= M: nothing to store)
     bool have_prev = false;  // wave-uniform
     int head_slot = 0, fill_slot = ahead == 0 ? 0 : (ahead % nslots);
-    auto store_prev = [&](int t) { // tile t of the previous unit
+    // tile t of the previous unit: sixteen 64-B pieces per instruction (rows li, columns 16 t + 4 lg).  (Round 4: the tiles
+    // paired through a DPP rotation so that an instruction writes eight WHOLE 128-B lines -- what took k_conv_first from 2.9 to
+    // 4.2 TB/s -- is SLOWER here, 35.5 vs 34.4 us at M = 73 763: this kernel writes at ~1 TB/s beside its MFMA stream, the
+    // half lines cost nothing and the eight extra VALU operations per pair do.)
+    auto store_prev = [&](int t) -> int {
         if (pm < M)
             *reinterpret_cast<float4 *>(Y + (size_t)pm * N + 16 * t + 4 * lg) = pv[t];
+        return 1;
     };
     for (int u = u0; u < u1; u++) {
         vmcnt_wait_n(min(vm - f_mark[0], 63));
@@ -1261,10 +1266,8 @@ __global__ __launch_bounds__(WG, 1) void k_linear_wlds(const float *__restrict__
             if (have_prev) {
 #pragma unroll
                 for (int i = 0; i < TPB; i++)
-                    if (q * TPB + i < NT) {
-                        store_prev(q * TPB + i);
-                        vm++;
-                    }
+                    if (q * TPB + i < NT)
+                        vm += store_prev(q * TPB + i);
             }
             if (more)
                 vm += issue_piece(un, fill_slot, q);
