@@ -148,6 +148,11 @@ struct gnnb_model {
     std::vector<std::vector<const float *>> conv;
     std::vector<const float *> head_w, head_b;
     const float *zf_w1f = nullptr; // 2-layer GCN: layer 1's weight once more, in MFMA-fragment order (see k_gcn2_zf)
+    // GIN stacks (k_gcn2_fused<GIN>): every wide matrix once more in EXECUTION order, each hidden x hidden at one stride --
+    // Wb0 | Wa1 Wb1 | ... | Wa(L-1) Wb(L-1) -- and the biases likewise.  A last layer narrower than hidden (the reference's
+    // benchmark model: 128 -> 64, models.py:530-545) is zero-padded to hidden x hidden: its extra output columns are
+    // act(0 + 0) and never leave the kernel.  nullptr when the model is no GIN stack the kernel takes.
+    const float *gin_w = nullptr, *gin_b = nullptr;
     int device = 0;
 };
 
@@ -360,6 +365,28 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
         w1f_off = push(frag.data(), frag.size());
         have_w1f = true;
     }
+    size_t gin_w_off = 0, gin_b_off = 0;
+    bool have_gin = false;
+    if (d.conv_type == GNNB_CONV_GIN && d.num_layers >= 2 && (d.hidden_dim == 32 || d.hidden_dim == 64 || d.hidden_dim == 128) &&
+        d.out_dim <= d.hidden_dim && d.out_dim % 4 == 0) {
+        const size_t h = d.hidden_dim, ho = d.out_dim;
+        const int L = d.num_layers, nm = 2 * L - 1;
+        std::vector<float> gw((size_t)nm * h * h, 0.0f), gb((size_t)nm * h, 0.0f);
+        auto put = [&](int idx, size_t off_w, size_t off_b, size_t rows, size_t cols) { // [rows, cols] -> top-left of slot idx
+            for (size_t r = 0; r < rows; r++)
+                memcpy(&gw[(size_t)idx * h * h + r * h], &img[off_w + r * cols], cols * sizeof(float));
+            memcpy(&gb[(size_t)idx * h], &img[off_b], rows * sizeof(float));
+        };
+        put(0, conv_off[0][2], conv_off[0][3], L == 1 ? ho : h, L == 1 ? ho : h); // (layer 0's second linear)
+        for (int l = 1; l < L; l++) {
+            const size_t fo = l == L - 1 ? ho : h;
+            put(2 * l - 1, conv_off[l][0], conv_off[l][1], fo, h); // Wa [fo, h]
+            put(2 * l, conv_off[l][2], conv_off[l][3], fo, fo);     // Wb [fo, fo]
+        }
+        gin_w_off = push(gw.data(), gw.size());
+        gin_b_off = push(gb.data(), gb.size());
+        have_gin = true;
+    }
     for (int i = 0; i < d.mlp_num_linear; i++) {
         int din, dout;
         mlp_dims(d, i, &din, &dout);
@@ -387,6 +414,10 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
             m->conv[l].push_back(m->blob + off);
     if (have_w1f)
         m->zf_w1f = m->blob + w1f_off;
+    if (have_gin) {
+        m->gin_w = m->blob + gin_w_off;
+        m->gin_b = m->blob + gin_b_off;
+    }
     for (int i = 0; i < d.mlp_num_linear; i++) {
         m->head_w.push_back(m->blob + hw[i]);
         m->head_b.push_back(m->blob + hb[i]);
@@ -848,24 +879,12 @@ static G2Deep gcn_stack_middle_layers(const gnnb_model *model)
     G2Deep g;
     g.nl = 0;
     const int L = d.num_layers;
-    if (d.conv_type == GNNB_CONV_GIN && L >= 2 && L <= GNNB_MAX_LAYERS && d.hidden_dim == d.out_dim) {
-        // wide matrices in execution order: Wb0 | Wa1 Wb1 | Wa2 Wb2 ...  (conv[l] = {Wa, ba, Wb, bb})
-        std::vector<const float *> w, b;
-        w.push_back(model->conv[0][2]);
-        b.push_back(model->conv[0][3]);
-        for (int l = 1; l < L; l++) {
-            w.push_back(model->conv[l][0]);
-            b.push_back(model->conv[l][1]);
-            w.push_back(model->conv[l][2]);
-            b.push_back(model->conv[l][3]);
-        }
-        g.wmid = w[0];
-        g.bmid = b[0];
-        g.mid_stride = (long)(w[1] - w[0]);
-        g.bmid_stride = (long)(b[1] - b[0]);
-        for (size_t j = 0; j < w.size(); j++)
-            if (w[j] != g.wmid + (long)j * g.mid_stride || b[j] != g.bmid + (long)j * g.bmid_stride)
-                return g;
+    if (d.conv_type == GNNB_CONV_GIN && L >= 2 && L <= GNNB_MAX_LAYERS && model->gin_w && model->gin_b) {
+        // (the execution-order copy made at upload: one stride by construction, the last layer padded to hidden x hidden)
+        g.wmid = model->gin_w;
+        g.bmid = model->gin_b;
+        g.mid_stride = (long)d.hidden_dim * d.hidden_dim;
+        g.bmid_stride = (long)d.hidden_dim;
         g.gin = 1;
         g.eps = d.gin_eps;
         g.skip = d.skip ? 1 : 0;

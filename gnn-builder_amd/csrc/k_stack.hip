@@ -183,8 +183,9 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ Wmid, const float *__restrict__ bmid, long mid_stride, long bmid_stride, int skip,
     float gin_eps)
 {
+    const int h1out = h1; // the width of the pooled rows (GIN: the model's out_dim <= hidden; the products run hidden-wide)
     if (GIN) {
-        // (GIN stacks are hidden x hidden everywhere -- the launcher checks h1 == h0 == 16 KQ1 --, so the row strides of H and
+        // (GIN stacks are hidden x hidden everywhere -- the wide matrices come zero-padded, gnnb_model_create --, so the row strides of H and
         // A1 are compile-time constants: the sixteen write-back addresses of a wide product are one register + immediates
         // instead of sixteen hoisted registers, which is what pushed these variants over the 128-register budget)
         h0 = 16 * KQ1;
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 const int ngr = cur.gb - cur.ga;
                 // (one store instruction per graph and pool; none if the whole slice is past h1; the rare
                 // paths below that read global memory only make the count conservative -- see the wait)
-                stores_behind_dma = wv * 16 < h1 ? ngr * np : 0;
+                stores_behind_dma = wv * 16 < h1out ? ngr * np : 0;
                 auto pool_graph = [&](int gi, int r0g, int r1g) { // wave-uniform row range of graph ga + gi
                     r0g = __builtin_amdgcn_readfirstlane(r0g) - nb;
                     r1g = min(__builtin_amdgcn_readfirstlane(r1g) - nb, G2_CAP);
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                     sum = rows4_sum(sum);
                     mx = rows4_max(mx);
                     const int n = r1g - r0g;
-                    if (lg == 0 && n1c < h1) {
+                    if (lg == 0 && n1c < h1out) {
 #pragma unroll
                         for (int kk = 0; kk < 3; kk++) {
                             if (kk >= np)
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                                 rr = n > 0 ? sum / (float)n : 0.0f;
                             else if (pools[kk] == GNNB_POOL_MAX)
                                 rr = n > 0 ? mx : 0.0f;
-                            pooled[((size_t)(cur.ga + gi) * np + kk) * h1 + n1c] = rr;
+                            pooled[((size_t)(cur.ga + gi) * np + kk) * h1out + n1c] = rr;
                         }
                     }
                 };
@@ -785,8 +786,8 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         } else if (units == 0 && wv == 0) {
             // a stage without rows (empty graphs behind the last node of a tile): zeros
             stores_behind_dma = 1 << 20; // (full drain)
-            for (int e = tv; e < (cur.gb - cur.ga) * np * h1; e += 64)
-                pooled[(size_t)cur.ga * np * h1 + e] = 0.0f;
+            for (int e = tv; e < (cur.gb - cur.ga) * np * h1out; e += 64)
+                pooled[(size_t)cur.ga * np * h1out + e] = 0.0f;
         }
         G2_PT(10);
 #ifdef GNNB_PROBE
@@ -831,8 +832,8 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     // fp32 kernel in either mode -- the mode may never make a model slower by sending it down the layer-by-layer path)
     if (deep.nl < 2 || (deep.nl > 2 && (!deep.wmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3))))
         return hipErrorNotSupported;
-    // GIN stacks: fp32 mode, hidden == out (every wide matrix h0 x h0), biases present
-    if (deep.gin && (h1 != h0 || !deep.wmid || !deep.bmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3)))
+    // GIN stacks: fp32 mode, out <= hidden (the wide matrices come hidden x hidden, zero-padded: gnnb_model_create), biases present
+    if (deep.gin && (h1 > h0 || !deep.wmid || !deep.bmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3)))
         return hipErrorNotSupported;
     const int math = (o.math && deep.nl == 2 && !deep.gin) ? 1 : 0;
     const int cap = 16 * g2_units(math);

@@ -1278,6 +1278,33 @@ def test_fused_gin_stack(dev, layers, hidden, act, skip, shape, eps):
             runtime.set_option("fuse_gcn2", 1)
 
 
+@pytest.mark.parametrize("layers,hidden,out_dim,act,skip,pools", [(6, 128, 64, "relu", True, ("add", "mean", "max")), (2, 64, 32, "tanh", True, ("add",)),
+                                                                  (3, 128, 20, "sigmoid", False, ("max", "mean")), (4, 32, 4, "gelu", True, ("mean",)),
+                                                                  (6, 128, 64, "relu", True, ("add", "mean", "max"))])
+def test_fused_stacks_with_a_last_layer_narrower_than_hidden(dev, layers, hidden, out_dim, act, skip, pools):
+    """The reference's one published benchmark model has out != hidden (6 layers, 128 / 64: experiments/
+    build_base_benchmarks.py:61-81).  GIN stacks take it in the LDS-resident kernel through hidden x hidden zero-padded
+    copies of the last layer's matrices (gnnb_model_create), GCN stacks through the kernel's own last-layer slice; the
+    pooled rows are out_dim wide.  Sigmoid / tanh / GELU make the padded columns act(0) != 0 -- they must not leak.  Against
+    the oracle and the layer-by-layer path."""
+    for conv in ("gin", "gcn"):
+        model = make_model(conv, in_dim=11, hidden=hidden, layers=layers, out_dim=out_dim, act=act, skip=skip, pools=pools,
+                           mlp_hidden=64, mlp_layers=4, task_out=19, seed=layers + out_dim)
+        batch = synthetic.make_batch("qm9", 400, seed=out_dim)
+        promise = int(np.diff(batch.node_ptr).max())
+        ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+        scale = max(1.0, float(np.abs(ref).max()))
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise)
+        args = to_dev(batch, dev)
+        got = cm.forward(*args).cpu().numpy()
+        cm.check()
+        assert cm.last_path().startswith("stack"), (conv, cm.last_path())
+        assert np.abs(got - ref).max() < TOL * scale, (conv, np.abs(got - ref).max(), scale)
+        lw = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+        out_lw = lw.forward(*args).cpu().numpy()
+        assert lw.last_path() == "layerwise" and np.abs(out_lw - got).max() < 5e-5 * scale, conv
+
+
 @pytest.mark.parametrize("conv,layers,hidden", [("gcn", 3, 64), ("gin", 3, 128), ("gin", 2, 32), ("gcn", 4, 32)])
 def test_fused_stacks_with_wide_input_features(dev, conv, layers, hidden):
     """F_in = 20 (two 16-wide k blocks in the first layer's product) and 30 on the deep GCN / GIN fused stacks, random
