@@ -65,6 +65,9 @@ namespace gnnb {
 #ifndef ZF_DMA_IN_M1   // the next stage's DMA issued behind the H barrier instead of at the stage top: +-0 (wide), -0.25 us (96-row shape)
 #define ZF_DMA_IN_M1 1
 #endif
+#ifndef ZF_PIN         // scheduler barriers pin "request block q + 1's fragments, THEN issue block q's MFMAs" in zf_mma (left alone the
+#define ZF_PIN 1       // compiler sinks every ds_read to just above its first use): 38.73 -> 38.55 us, 99 VGPRs
+#endif
 #ifndef ZF_SWZ         // H / Z rows unpadded, 16-B chunks XOR-swizzled by the row index: LDS bank conflicts 28 % -> 0 and the
 #define ZF_SWZ 0       // kernel 1.7 us SLOWER (38.8 -> 40.5 us, 117 VGPRs): the conflicts sit in M1's fragment reads, where the
 #endif                 // LDS array is < 25 % busy -- they cost nothing; the swizzle's address arithmetic does
@@ -97,6 +100,9 @@ __device__ __forceinline__ void zf_mma(const float *__restrict__ A, int lda, con
             for (int k = 0; k < NU; k++)
                 an[k] = *reinterpret_cast<const float4 *>(ap[k] + 16 * ((q + 1) ^ kq));
         }
+#if ZF_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             if (t >= nt) // (wave-uniform; nt = 3: the block's fourth k step holds zeros on both sides -- narrow inputs, ZF_K12)
@@ -107,6 +113,9 @@ __device__ __forceinline__ void zf_mma(const float *__restrict__ A, int lda, con
                 acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + t], av, acc[k], 0, 0, 0);
             }
         }
+#if ZF_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (q + 1 < KQ) {
 #pragma unroll
             for (int k = 0; k < NU; k++)

@@ -16,7 +16,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "prof"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 dst = ROOT / "profiles"
 dst.mkdir(exist_ok=True)
 
@@ -73,6 +73,7 @@ for wdir in sorted(src.glob("bench_*")):
         (dst / f"{tag}_{w}_bench.json").write_text(json.dumps(json.loads(lines[-1]), indent=1) + "\n")
     rl = src / f"roofline_{w}.log"
     if not rl.exists():
+        print(w, "done (line + kernel table)")
         continue
     rstats = list((src / f"roofline_{w}").rglob("roofline_kernel_stats.csv"))
     if rstats:
@@ -95,6 +96,20 @@ for wdir in sorted(src.glob("bench_*")):
             h, m = pmc["TCC_HIT_sum"]["mean"], pmc["TCC_MISS_sum"]["mean"]
             summary["l2_hit_rate"] = h / (h + m)
         (dst / f"{tag}_{w}_aggregate_pmc.json").write_text(json.dumps(summary, indent=2) + "\n")
+    # the aggregate kind this workload's own layers run (SUM / MEAN / PNA with four output matrices)
+    own = meas.get("workload_kind")
+    if own:
+        mode = {"sum": 1, "mean": 2, "pna": 3}[own["kind"]]
+        pk = collect(w, f"k_aggregate_ring<{mode},")
+        if pk:
+            so = {"command": f"rocprofv3 --pmc <counter> -- python3 bench.py --workload {w} --roofline-only (one pass per counter group)",
+                  "workload": w, "kernel": f"gnnb::k_aggregate_ring<{own['kind'].upper()}, float4, nt stores>, this workload's batch and width",
+                  "raw_counters_per_launch": pk, "algorithmic_bytes_per_launch": own["algorithmic_bytes_per_launch"],
+                  "events_us_per_launch": own["us"]}
+            t = traffic(pk, own["algorithmic_bytes_per_launch"])
+            if t:
+                so["hbm_traffic_bytes_per_launch"] = t
+            (dst / f"{tag}_{w}_aggregate_{own['kind']}_pmc.json").write_text(json.dumps(so, indent=2) + "\n")
     fs = meas.get("fused_stack")
     g2 = collect(w, "k_gcn2_")
     if fs and g2:
@@ -110,5 +125,30 @@ for wdir in sorted(src.glob("bench_*")):
                                                 "mfma": g2["SQ_INSTS_MFMA"]["mean"],
                                                 "salu": g2.get("SQ_INSTS_SALU", {}).get("mean"),
                                                 "lds": g2.get("SQ_INSTS_LDS", {}).get("mean")}
+        if "SQ_LDS_BANK_CONFLICT" in g2 and "SQ_LDS_IDX_ACTIVE" in g2:
+            s2["lds_bank_conflict_share_of_lds_cycles"] = g2["SQ_LDS_BANK_CONFLICT"]["mean"] / g2["SQ_LDS_IDX_ACTIVE"]["mean"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in g2 and "SQ_BUSY_CYCLES" in g2:
+            s2["note_busy"] = "SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs: / 1024 = matrix-pipe cycles per SIMD"
         (dst / f"{tag}_{w}_gcn2_pmc.json").write_text(json.dumps(s2, indent=2) + "\n")
     print(w, "done")
+
+# the swizzled build of k_gcn2_zf (profile_r.sh): conflicts and time beside the shipped kernel's
+swz = src / "swz_roofline.log"
+if swz.exists():
+    meas = [l for l in swz.read_text().splitlines() if l.startswith("{")]
+    pm = {}
+    for sub in ("pmc_swz_lds", "pmc_swz_inst"):
+        for p in (src / sub).rglob("*counter_collection.csv"):
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(p)):
+                if "k_gcn2_zf" in r["Kernel_Name"]:
+                    acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for k, v in acc.items():
+                pm[k] = {"launches": len(v), "mean": sum(v) / len(v)}
+    if meas and pm:
+        m = json.loads(meas[-1])
+        out = {"what": "k_gcn2_zf built with -DZF_SWZ=1 (H / Z rows unpadded, 16-B chunks XOR-swizzled by the row index): NOT the shipped kernel",
+               "events_us_per_launch": (m.get("fused_stack") or {}).get("us"), "raw_counters_per_launch": pm}
+        if "SQ_LDS_BANK_CONFLICT" in pm and "SQ_LDS_IDX_ACTIVE" in pm:
+            out["lds_bank_conflict_share_of_lds_cycles"] = pm["SQ_LDS_BANK_CONFLICT"]["mean"] / pm["SQ_LDS_IDX_ACTIVE"]["mean"]
+        (dst / f"{tag}_c2_gcn2_swizzled_build_pmc.json").write_text(json.dumps(out, indent=2) + "\n")
