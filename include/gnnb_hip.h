@@ -287,7 +287,7 @@ int gnnb_linear_timed(const float *a_dev, int lda, int k, const float *w_dev, in
                       void *stream, float *out_us_per_launch);
 
 /* Same for the fused GCN stack + pooling kernel on the workspace's prepared batch (the kernel
- * gnnb_forward_prepared runs when the model is a GCN (or a GIN with hidden = out) of two or more layers and a
+ * gnnb_forward_prepared runs when the model is a GCN or a GIN (hidden 32 / 64 / 128, out <= hidden) of two or more layers and a
  * max_graph_nodes promise is set;
  * replaces compute_gnn_head + compute_global_graph_pooling, templates/model.cpp.jinja:151-359,
  * :413-449).  GNNB_ERR_INVALID when that path is not eligible. */
@@ -306,6 +306,12 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *   agg_nt_store, agg_balance    launch shape of the gather-aggregate  gemm_variant, gemm_dma, gemm_tail_split,
  *   gemm_wlds, gemm_wlds_slots, gemm_max_wg_per_cu  which GEMM kernel   fuse_narrow, fuse_gcn2, fuse_head, head_small,
  *   head_split                   which launches are fused (0 = layer by layer / separate readout)
+ *   first_ring (default 1)       a narrow-input first layer (F_in <= 32) in ring form: whole graphs staged in LDS, all N <= 256
+ *                                output columns from one stage (k_conv_first); 0 = inside the GEMM's A stage (k_linear_reg)
+ *   fuse_pool (default 1)        global pooling in the epilogue of the last conv layer's GEMM where that GEMM has one
+ *                                (GraphSAGE's large-K segmented GEMM): its [N, d] output is never written; 0 = pooling pass
+ *   agg_balance (default 0)      gather-aggregate workgroups take row-balanced ranges (boundary graphs staged twice) instead
+ *                                of whole-graph runs: measured slower (15.9 vs 15.2 us at BASELINE config 2), kept opt-in
  *   fuse_zf (default 1)          2-layer fp32 GCN stacks through k_gcn2_zf (last layer transformed before it is aggregated);
  *                                0 = k_gcn2_fused.  zf_shape: 0 = two 8-wave workgroups per CU, 96-row stages; 1 = one 16-wave
  *                                workgroup, 176-row stages; 2 (default) = 1 wherever it exists (input widths <= 16)
