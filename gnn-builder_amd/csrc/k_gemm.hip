@@ -193,7 +193,9 @@ static constexpr int DBUF_B = (DM + DN) * BK * 4; // 32 KB: A chunk | W chunk
 // MATH 1 (opt-in, gnnb_set_option("math", 1)): the same chunks, but each 16-wide k block is multiplied as six
 // v_mfma_f32_32x32x16_bf16 products of an exact 3-way bf16 split of BOTH operands (see split3), the fragments split in
 // the wave after the LDS read -- 24 MFMA of 8 passes instead of 32 of 16 per k block and accumulator quartet.
-template <int MATH>
+// POOL: the pooling epilogue as its own instantiation (as a run-time branch of the one kernel it cost the plain GEMM 6-8 %:
+// 109 -> 101 TFLOP/s at the C4 shape, round 4)
+template <int MATH, bool POOL>
 __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__restrict__ W, int ldw,
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ skip, float *__restrict__ Y, int M,
@@ -333,6 +335,19 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                 for (int i = 0; i < 16; i++)
                     acc[mi][ni][i] = 0.0f;
 
+        // (pooling epilogue: the graph ids of the rows of this wave's 32-row blocks -- lane r + 1 holds row r, lanes 0 / 33 the
+        // rows just outside --, fetched HERE and consumed below like the scalers: inside the epilogue every block paid a
+        // memory round trip for them)
+        int gidv[MC > 0 ? MC : 1];
+#pragma unroll
+        for (int mi = 0; mi < (MC > 0 ? MC : 1); mi++) {
+            gidv[mi] = -1;
+            if (MC > 0 && POOL) {
+                const int r = m0 + rbase + mi * 32 - 1 + lane;
+                if (lane < 34 && r >= 0 && r < M)
+                    gidv[mi] = pe.node_graph[r];
+            }
+        }
         // per-row scalers of the scaled segments (PNA: amp . A, att . A), fetched once per item for the lane's A rows
         float sc[4][MC > 0 ? MC : 1];
         if (MC > 0) {
@@ -352,6 +367,9 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                 for (int mi = 0; mi < MC; mi++)
                     asm volatile("" : "+v"(sc[sgm][mi]));
+#pragma unroll
+            for (int mi = 0; mi < MC; mi++)
+                asm volatile("" : "+v"(gidv[mi]));
         }
 
         for (int c = 0; c < total; c++) {
@@ -476,7 +494,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         // `gid`, read with v_readlane; lanes 0 / 33 hold the rows just outside the block).  A graph that lies inside the
         // block is finished here; a piece of a graph that continues outside goes to part[block][0 = reaches the block's
         // first row, 1 = only its last][column] for launch_pool_combine.  Rows past M carry id -1 and are dropped.
-        if (pe.pooled != nullptr) {
+        if constexpr (POOL) {
             auto pool_epi = [&](auto tag) {
                 constexpr int ACT = decltype(tag)::value;
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // every wave has read its last fragments
@@ -486,12 +504,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                 for (int mi = 0; mi < MC; mi++) {
                     const int blk0 = m0 + rbase + mi * 32;
-                    int gid = -1;
-                    {
-                        const int r = blk0 - 1 + lane;
-                        if (lane < 34 && r >= 0 && r < M)
-                            gid = pe.node_graph[r];
-                    }
+                    const int gid = gidv[mi];
 #pragma unroll
                     for (int ni = 0; ni < NT; ni++)
 #pragma unroll
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             v.x = act_t<ACT>(v.x), v.y = act_t<ACT>(v.y), v.z = act_t<ACT>(v.z), v.w = act_t<ACT>(v.w);
                             *reinterpret_cast<float4 *>(scr + li * 256 + ((((cw >> 2)) ^ (li & 15)) << 4)) = v;
                         }
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // own scratch writes + the ids (wave-private region: no barrier)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own scratch writes (wave-private region: no barrier)
                     const int blk = blk0 >> 5;
                     float sum = 0.0f, mx = -INFINITY;
                     int cur = __builtin_amdgcn_readlane(gid, 1), nrows = 0;
@@ -1476,7 +1489,9 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
         if (plain) {
             const size_t lds = (size_t)DNBUF * DBUF_B;
             {
-                hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(options().math ? k_linear_dma<1> : k_linear_dma<0>), lds);
+                const void *fn = pep ? (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, true>) : reinterpret_cast<const void *>(k_linear_dma<0, true>))
+                                     : (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, false>) : reinterpret_cast<const void *>(k_linear_dma<0, false>));
+                hipError_t e = ensure_dynamic_lds(fn, lds);
                 if (e != hipSuccess)
                     return e;
             }
@@ -1491,12 +1506,21 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
                 split = 4 * rem <= DWGPC * num_cus ? 4 : (2 * rem <= DWGPC * num_cus ? 2 : 1);
             const int split_from = split > 1 ? tiles - rem : tiles;
             const int grid = std::min(split_from + split * (tiles - split_from), DWGPC * num_cus);
-            if (options().math)
-                hipLaunchKernelGGL(k_linear_dma<1>, dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, tn,
-                                   split_from, split, pe);
-            else
-                hipLaunchKernelGGL(k_linear_dma<0>, dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, tn,
-                                   split_from, split, pe);
+#define GNNB_DMA_LAUNCH(MATHV, POOLV)                                                                                    \
+    hipLaunchKernelGGL((k_linear_dma<MATHV, POOLV>), dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, \
+                       tn, split_from, split, pe)
+            if (options().math) {
+                if (pep)
+                    GNNB_DMA_LAUNCH(1, true);
+                else
+                    GNNB_DMA_LAUNCH(1, false);
+            } else {
+                if (pep)
+                    GNNB_DMA_LAUNCH(0, true);
+                else
+                    GNNB_DMA_LAUNCH(0, false);
+            }
+#undef GNNB_DMA_LAUNCH
             return hipGetLastError();
         }
     }
