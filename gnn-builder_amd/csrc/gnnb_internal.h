@@ -88,7 +88,9 @@ struct Options {
     int math;          // 0 = fp32 MFMA everywhere (default); 1 = the wide update of the fused GCN stack and the
                        //     K <= 128 GEMMs as six bf16 MFMA products of an exact 3-way split of both operands
                        //     (fp32-equivalent, opt-in)
-    int gemm_tail_split; // 1 = k_linear_dma hands the last, partial round of tiles out as row slices (default)
+    int gemm_tail_split; // k_linear_dma's last, partial round of tiles: 2 = cut along K into equal runs over all resident
+                         // workgroups, parts added up by the last one at each tile (stream-K; default), 1 = handed out as
+                         // row slices (bit-identical to 0), 0 = whole tiles
 };
 Options &options();
 
@@ -134,6 +136,13 @@ struct PoolEpilogue {
     float *pooled = nullptr;             // [B, np, N]
     float2 *part = nullptr;              // [ceil(M / 32), 2, N] {sum, max} of a block's first / last open piece
     int32_t num_graphs = 0, np = 0, pools[3] = {0, 0, 0};
+};
+// Stream-K tail of k_linear_dma (k_gemm.hip): q chunks per run; part[2 * workgroup + segment][4 waves][64 x 64 lanes]
+// accumulators, cnt[tail tile] arrival counters (zero between launches).  q = 0: off.
+struct StreamK {
+    int q = 0;
+    float *part = nullptr;
+    int *cnt = nullptr;
 };
 // pe != nullptr: y is not written; returns hipErrorNotSupported (nothing launched) when the GEMM shape has no pooling
 // epilogue -- the caller then runs the plain GEMM + a pooling pass

@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 1)};
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2)};
     return o;
 }
 
@@ -250,7 +250,7 @@ int gnnb_set_option(const char *name, int value)
         o.gemm_variant = value;
     else if (!strcmp(name, "gemm_dma") && value >= 0 && value <= 1)
         o.gemm_dma = value;
-    else if (!strcmp(name, "gemm_tail_split") && value >= 0 && value <= 1)
+    else if (!strcmp(name, "gemm_tail_split") && value >= 0 && value <= 2)
         o.gemm_tail_split = value;
     else if (!strcmp(name, "gemm_wlds") && value >= 0 && value <= 1)
         o.gemm_wlds = value;

@@ -200,12 +200,11 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ skip, float *__restrict__ Y, int M,
                                                     int N, int act, int tiles_m, int tiles_n, int split_from, int split,
-                                                    PoolEpilogue pe)
+                                                    PoolEpilogue pe, StreamK sk)
 {
-    constexpr int NT = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1; // 2 x 2 waves: 64 rows x 64 columns each
+    const int wm = wave >> 1, wn = wave & 1; // 2 x 2 waves: 64 rows x 64 columns each (a 32-row slice: 1 x 4 waves, 32 columns each)
     const int total = g.cpre[g.nseg];
     const int li = lane & 31, lh = lane >> 5;
     const uint32_t smem_a = (uint32_t)(uintptr_t)(lds_vptr)smem;
@@ -217,25 +216,55 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     // across item boundaries.  TAIL SPLIT: tiles / CUs is rarely whole (PNA at C4: 1153 tiles on 256 CUs = 4.5 per CU,
     // paid as 5).  Tiles from `split_from` on -- the last, partial round -- are handed out as `split` (2 or 4) row
     // slices each, so that the round costs a half or a quarter tile.  A slice keeps the tile's MFMA order per output
-    // element: 64 rows = one 32-row accumulator block per wave instead of two, 32 rows = the same on half of the waves.
+    // element: 64 rows = one 32-row accumulator block per wave instead of two, 32 rows = 1 x 4 waves of 32 x 32.
+    // STREAM-K TAIL (round 4, sk.q > 0): the tiles from `split_from` on are not sliced by rows -- a 32-row slice keeps the
+    // whole K loop, whose chunks are then too small to cover the DMA round trip: at the C4 shape the quarter-tile round
+    // cost 80 us where a quarter of a round is 57, and 153 us when 4 x 129 slices just missed the 512 resident workgroups.
+    // Instead their (tile, chunk) space is cut into equal runs of q chunks, one run per workgroup (a run spans at most two
+    // tiles: q <= chunks per tile).  A workgroup multiplies its run at full tile width, parks the accumulators in
+    // sk.part[2 * workgroup + segment], and the LAST workgroup to arrive at a tile (sk.cnt, one counter per tile, reset by
+    // that workgroup) adds the parts up IN RUN ORDER and runs the epilogue: deterministic, one summation order per shape.
     const int num_tiles = tiles_m * tiles_n;
-    const int num_items = split_from + split * (num_tiles - split_from);
-    if ((int)blockIdx.x >= num_items)
+    const bool skm = sk.q > 0;
+    const int num_items = skm ? split_from : split_from + split * (num_tiles - split_from); // handed out round-robin
+    const int sk_total = skm ? (num_tiles - split_from) * total : 0;
+    const int sk_g0 = min((int)blockIdx.x * sk.q, sk_total), sk_g1 = min(sk_g0 + sk.q, sk_total);
+    const int sk_t0 = sk_g0 / total;
+    const int sk_nseg = sk_g1 > sk_g0 ? (sk_g1 - 1) / total - sk_t0 + 1 : 0;
+    const int n_rr = (int)blockIdx.x < num_items ? (num_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_work = n_rr + sk_nseg;
+    if (n_work == 0)
         return;
-    auto decode = [&](int it, int &m0, int &n0, int &mrows) {
-        const bool part = it >= split_from;
-        const int j = it - split_from;
-        const int t = part ? split_from + j / split : it;
-        mrows = part ? DM / split : DM;
-        m0 = (t / tiles_n) * DM + (part ? (j % split) * mrows : 0);
-        n0 = (t % tiles_n) * DN;
+    // work item v of this workgroup: rows [m0, m0 + mrows) x columns from n0, chunks [c0, c1); skt = the tail tile of a
+    // stream-K run (-1: the item owns its whole K and stores from its accumulators)
+    auto decode = [&](int v, int &m0, int &n0, int &mrows, int &c0, int &c1, int &skt) {
+        if (v < n_rr) {
+            const int it = (int)blockIdx.x + v * (int)gridDim.x;
+            const bool part = it >= split_from;
+            const int j = it - split_from;
+            const int t = part ? split_from + j / split : it;
+            mrows = part ? DM / split : DM;
+            m0 = (t / tiles_n) * DM + (part ? (j % split) * mrows : 0);
+            n0 = (t % tiles_n) * DN;
+            c0 = 0, c1 = total, skt = -1;
+        } else {
+            const int tr = sk_t0 + (v - n_rr), t = split_from + tr;
+            mrows = DM;
+            m0 = (t / tiles_n) * DM;
+            n0 = (t % tiles_n) * DN;
+            c0 = max(sk_g0 - tr * total, 0), c1 = min(sk_g1 - tr * total, total);
+            skt = (c0 == 0 && c1 == total) ? -1 : tr;
+        }
     };
 
     // issue cursor: runs ahead of the multiply cursor, across item boundaries (its item's origin is decoded once per item:
     // the integer divisions are scalar instructions in front of every wave's next MFMA)
-    int iss_item = blockIdx.x, iss_c = 0, iss_buf = 0;
+    int iss_v = 0, iss_c = 0, iss_c1 = 0, iss_buf = 0;
     int iss_m0 = 0, iss_n0 = 0, iss_mrows = 0;
-    decode(iss_item, iss_m0, iss_n0, iss_mrows);
+    {
+        int skt_;
+        decode(0, iss_m0, iss_n0, iss_mrows, iss_c, iss_c1, skt_);
+    }
     int vm = 0; // vector-memory instructions this wave has issued (DMA + epilogue stores): for the counted waits
     // The next chunk's DMA goes out in FOUR parts, one per k step of the chunk being multiplied (a burst of eight
     // instructions behind the barrier kept every wave of the workgroup off the matrix pipe at the same moment):
@@ -248,7 +277,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     };
     auto issue_begin = [&]() -> IssueCtx {
         IssueCtx ic;
-        ic.valid = iss_item < num_items;
+        ic.valid = iss_v < n_work;
         if (!ic.valid)
             return ic;
         const int m0 = iss_m0, n0 = iss_n0;
@@ -299,11 +328,11 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         if (!ic.valid)
             return -1;
         iss_buf = iss_buf + 1 == DNBUF ? 0 : iss_buf + 1;
-        if (++iss_c == total) {
-            iss_c = 0;
-            iss_item += gridDim.x;
-            if (iss_item < num_items)
-                decode(iss_item, iss_m0, iss_n0, iss_mrows);
+        if (++iss_c == iss_c1) {
+            if (++iss_v < n_work) {
+                int skt_;
+                decode(iss_v, iss_m0, iss_n0, iss_mrows, iss_c, iss_c1, skt_);
+            }
         }
         return vm;
     };
@@ -324,8 +353,9 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     // one work item with MC 32-row accumulator blocks per wave (2 = whole tile, 1 = a slice, 0 = a wave that only
     // keeps the chunk pipeline going).  A compile-time MC: with a run-time block count the accumulators of the
     // conditional block leave the AGPRs at every loop header.
-    auto run_item = [&](auto mtag, int m0, int n0, int rbase) {
-        constexpr int MC = decltype(mtag)::value;
+    auto run_item = [&](auto mtag, auto ntag, int m0, int n0, int rbase, int wcol, int c0, int c1, int skt, int skseg) {
+        constexpr int MC = decltype(mtag)::value; // 32-row blocks of the wave
+        constexpr int NT = decltype(ntag)::value; // 32-column blocks of the wave, from column `wcol` of the tile
         f32x16 acc[MC > 0 ? MC : 1][NT];
 #pragma unroll
         for (int mi = 0; mi < (MC > 0 ? MC : 1); mi++)
@@ -372,7 +402,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                 asm volatile("" : "+v"(gidv[mi]));
         }
 
-        for (int c = 0; c < total; c++) {
+        for (int c = c0; c < c1; c++) {
             // this chunk has landed for this wave when at most the operations issued after it are outstanding (VM
             // operations retire in order; loads the compiler tracks itself only make the wait stricter) ...
             vmcnt_wait_n(min(vm - mk0, 63));
@@ -420,7 +450,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                         }
 #pragma unroll
                         for (int ni = 0; ni < NT; ni++) {
-                            const int r = wn * 32 * NT + ni * 32 + li;
+                            const int r = wcol + ni * 32 + li;
                             const float4 f0 = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
                             const float4 f1 = *reinterpret_cast<const float4 *>(b + r * BK + (((piece + 1) ^ (r & 7)) << 2));
                             split3x8(f0, f1, wh[ni], wm[ni], wl[ni]);
@@ -458,7 +488,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                     }
 #pragma unroll
                     for (int ni = 0; ni < NT; ni++) {
-                        const int r = wn * 32 * NT + ni * 32 + li;
+                        const int r = wcol + ni * 32 + li;
                         fb[ni] = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
                     }
                     issue_part(ic, kb / 8); // (behind this step's fragment reads, in front of its MFMAs)
@@ -499,7 +529,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                 constexpr int ACT = decltype(tag)::value;
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // every wave has read its last fragments
                 char *scr = smem + (size_t)((buf + DNBUF - 1) % DNBUF) * DBUF_B + (size_t)wave * 8192;
-                const int colg = n0 + wn * 32 * NT + lane; // this lane's column in the row walk
+                const int colg = n0 + wcol + lane; // this lane's column in the row walk
                 const bool col_ok = colg < N;
 #pragma unroll
                 for (int mi = 0; mi < MC; mi++) {
@@ -510,7 +540,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             const int cw = ni * 32 + 8 * q + 4 * lh; // column inside the wave's 64
-                            const int cg = n0 + wn * 32 * NT + cw;
+                            const int cg = n0 + wcol + cw;
                             float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
                             if (bias && vec && cg + 3 < N) {
                                 const float4 bv = *reinterpret_cast<const float4 *>(bias + cg);
@@ -580,6 +610,53 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
             return; // (the stores above are not counted in `vm`: the next waits are merely stricter)
         }
 
+        // ---- stream-K run: park the accumulators; the last workgroup at the tile adds the runs up and goes on to the epilogue.
+        // The parts are exchanged between workgroups on DIFFERENT XCDs (one L2 each): stores and loads at agent scope (sc1:
+        // write-through / read from the coherent level) and a wait for the stores, instead of a release fence -- which
+        // writes back the whole L2 (buffer_wbl2) per wave: measured 655 us against 540 for the row slices at the C4 shape.
+        if (MC == 2 && NT == 2 && !POOL && skt >= 0) {
+            // part layout: [accumulator register 0..63][lane] (256-B rows: every store / load instruction is one contiguous piece)
+            float *mine = sk.part + ((size_t)(2 * blockIdx.x + skseg) * 4 + wave) * 4096 + lane;
+#pragma unroll
+            for (int mi = 0; mi < MC; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        __hip_atomic_store(mine + ((mi * NT + ni) * 16 + i) * 64, acc[mi][ni][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the parts are at the coherent level before the arrival is counted
+            __syncthreads();
+            int *flag = reinterpret_cast<int *>(smem + (size_t)DNBUF * DBUF_B);
+            const int w_first = (skt * total) / sk.q, w_last = ((skt + 1) * total - 1) / sk.q;
+            if (tid == 0)
+                *flag = __hip_atomic_fetch_add(sk.cnt + skt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *flag == w_last - w_first;
+            if (!last)
+                return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (buffer_inv: the loads below see the other XCDs' parts)
+#pragma unroll
+            for (int mi = 0; mi < MC; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        acc[mi][ni][i] = 0.0f;
+            for (int wq = w_first; wq <= w_last; wq++) { // run order = k order
+                const int sg = wq * sk.q < skt * total ? 1 : 0; // the tile is that workgroup's second segment when its run began in the tile before
+                const float *theirs = sk.part + ((size_t)(2 * wq + sg) * 4 + wave) * 4096 + lane;
+#pragma unroll
+                for (int mi = 0; mi < MC; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++)
+                            acc[mi][ni][i] += theirs[((mi * NT + ni) * 16 + i) * 64];
+            }
+            if (tid == 0)
+                sk.cnt[skt] = 0; // (nobody else comes to this tile in this launch; the next launch finds it cleared)
+        }
+
         // D = W_tile . A_tile^T: lane (li, lh) holds Y[row = m_base + li][col = n_base + 8 (reg >> 2) + 4 lh + (reg & 3)]
         auto epilogue = [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
@@ -592,7 +669,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                 for (int ni = 0; ni < NT; ni++)
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const int colg = n0 + wn * 32 * NT + ni * 32 + 8 * q + 4 * lh;
+                        const int colg = n0 + wcol + ni * 32 + 8 * q + 4 * lh;
                         if (vec && colg + 3 < N) {
                             float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2],
                                                    acc[mi][ni][4 * q + 3]);
@@ -623,25 +700,25 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         // the stores just issued sit between the prefetched chunk and the next waits: count them, or the first wait
         // of the next item would drain them.  Only blocks that certainly issued all eight 16-B stores are counted (an
         // under-count merely makes the next waits stricter; an over-count would let a wait return early).
-        if (vec && n0 + wn * 64 + 64 <= N) {
+        if (vec && n0 + wcol + 32 * NT <= N) {
 #pragma unroll
             for (int mi = 0; mi < MC; mi++)
                 if (m0 + rbase + mi * 32 + 32 <= M)
-                    vm += 8;
+                    vm += 4 * NT;
         }
     };
 
-    for (int item = blockIdx.x; item < num_items; item += gridDim.x) {
-        int m0, n0, mrows;
-        decode(item, m0, n0, mrows);
-        const int rpw = max(mrows / (DM / 64), 32); // rows per wave: 64, or 32 in a slice
-        const int rbase = wm * rpw;                 // the wave's first row inside the item
-        if (rbase >= mrows)                         // (a 32-row slice keeps half of the waves busy)
-            run_item(IntTag<0>{}, m0, n0, rbase);
-        else if (rpw == 64)
-            run_item(IntTag<2>{}, m0, n0, rbase);
+    for (int v = 0; v < n_work; v++) {
+        int m0, n0, mrows, c0, c1, skt;
+        decode(v, m0, n0, mrows, c0, c1, skt);
+        // whole tile: 2 x 2 waves of 64 x 64; 64-row slice: 2 x 2 waves of 32 x 64; 32-row slice: 1 x 4 waves of 32 x 32 (round
+        // 4 -- it had been 32 x 64 on two of the four waves)
+        if (mrows == DM)
+            run_item(IntTag<2>{}, IntTag<2>{}, m0, n0, wm * 64, wn * 64, c0, c1, skt, v - n_rr);
+        else if (mrows == DM / 2)
+            run_item(IntTag<1>{}, IntTag<2>{}, m0, n0, wm * 32, wn * 64, c0, c1, -1, 0);
         else
-            run_item(IntTag<1>{}, m0, n0, rbase);
+            run_item(IntTag<1>{}, IntTag<1>{}, m0, n0, 0, wave * 32, c0, c1, -1, 0);
     }
 }
 
@@ -1467,6 +1544,48 @@ hipError_t launch_pool_combine(const PoolEpilogue &pe, int M, int N, hipStream_t
     return hipGetLastError();
 }
 
+// Stream-K scratch: one per (device, stream) -- launches on one stream run in order and may share it, launches on different
+// streams may not --, allocated at the first GEMM that wants it (never while the stream is being captured into a graph:
+// that launch takes the row slices) and kept for the life of the process.  64 MB of parts + the tile counters.
+// Used for K >= 1024 (32 chunks): measured at C4's 13F GEMM (52 chunks, 1153 tiles) 112.5 against 106 TFLOP/s with row slices,
+// at C5's K = 512 (16 chunks: runs of 7) 105 against 108 -- short runs are all pipeline prologue and fix-up.
+static constexpr int SK_MIN_Q = 6, SK_MIN_TOTAL = 32, SK_MAX_WG = 512, SK_MAX_STREAMS = 16;
+static bool stream_k_scratch(hipStream_t s, StreamK &out)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, StreamK> have;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = have.find(std::make_pair(dev, s));
+    if (it == have.end()) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if ((int)have.size() >= SK_MAX_STREAMS)
+            return false;
+        StreamK k;
+        const size_t part_b = (size_t)2 * SK_MAX_WG * DM * DN * sizeof(float), cnt_b = 4096;
+        char *p = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&p), part_b + cnt_b) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (hipMemsetAsync(p + part_b, 0, cnt_b, s) != hipSuccess) { // (in stream order, in front of the first launch that counts)
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return false;
+        }
+        k.part = reinterpret_cast<float *>(p);
+        k.cnt = reinterpret_cast<int *>(p + part_b);
+        it = have.emplace(std::make_pair(dev, s), k).first;
+    }
+    out = it->second;
+    return true;
+}
+
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
                          const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pep)
 {
@@ -1487,7 +1606,7 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
         for (int sg = 0; sg < g.nseg && plain; sg++)
             plain = g.avec[sg] && g.wvec[sg] && (g.k[sg] % BK == 0) && (g.koff[sg] % 4 == 0);
         if (plain) {
-            const size_t lds = (size_t)DNBUF * DBUF_B;
+            const size_t lds = (size_t)DNBUF * DBUF_B + 16; // (+ the stream-K arrival flag)
             {
                 const void *fn = pep ? (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, true>) : reinterpret_cast<const void *>(k_linear_dma<0, true>))
                                      : (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, false>) : reinterpret_cast<const void *>(k_linear_dma<0, false>));
@@ -1502,13 +1621,22 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             // in 2 or 4 row slices per tile when those still fit one round (see the kernel)
             const int rem = tiles % num_cus;
             int split = 1;
-            if (options().gemm_tail_split && rem > 0 && !pep) // (pooling epilogue: whole tiles only -- its blocks are 32-row aligned, every wave joins its barrier)
-                split = 4 * rem <= DWGPC * num_cus ? 4 : (2 * rem <= DWGPC * num_cus ? 2 : 1);
-            const int split_from = split > 1 ? tiles - rem : tiles;
-            const int grid = std::min(split_from + split * (tiles - split_from), DWGPC * num_cus);
+            StreamK sk;
+            const int total = g.cpre[g.nseg], resident = DWGPC * num_cus;
+            if (options().gemm_tail_split == 2 && rem > 0 && !pep && total >= SK_MIN_TOTAL && resident <= SK_MAX_WG &&
+                stream_k_scratch(s, sk)) {
+                // equal runs over all resident workgroups, at least SK_MIN_Q chunks long (shorter ones are all pipeline
+                // prologue), at most one tile's K (a run spans two tiles at most)
+                sk.q = std::min(std::max((rem * total + resident - 1) / resident, SK_MIN_Q), total);
+            } else if (options().gemm_tail_split && rem > 0 && !pep) { // (pooling epilogue: whole tiles only -- its blocks are 32-row aligned, every wave joins its barrier)
+                split = 4 * rem <= resident ? 4 : (2 * rem <= resident ? 2 : 1);
+            }
+            const int split_from = (split > 1 || sk.q > 0) ? tiles - rem : tiles;
+            const int grid = sk.q > 0 ? std::min(std::max(split_from, (rem * total + sk.q - 1) / sk.q), resident)
+                                      : std::min(split_from + split * (tiles - split_from), resident);
 #define GNNB_DMA_LAUNCH(MATHV, POOLV)                                                                                    \
     hipLaunchKernelGGL((k_linear_dma<MATHV, POOLV>), dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, \
-                       tn, split_from, split, pe)
+                       tn, split_from, split, pe, sk)
             if (options().math) {
                 if (pep)
                     GNNB_DMA_LAUNCH(1, true);

@@ -315,6 +315,12 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *   fuse_zf (default 1)          2-layer fp32 GCN stacks through k_gcn2_zf (last layer transformed before it is aggregated);
  *                                0 = k_gcn2_fused.  zf_shape: 0 = two 8-wave workgroups per CU, 96-row stages; 1 = one 16-wave
  *                                workgroup, 176-row stages; 2 (default) = 1 wherever it exists (input widths <= 16)
+ *   gemm_tail_split (default 2)  the last, partial round of tiles of the large-K GEMM (k_linear_dma): 2 = for K >= 1024 cut
+ *                                along K into equal runs over all resident workgroups, parts added up in run order by the last
+ *                                workgroup at each tile (stream-K: one summation order per shape, not the unsplit one; 64 MB
+ *                                of scratch per (device, stream), allocated at the first such launch on a stream that is not
+ *                                being captured -- warm up before capturing a graph), row slices otherwise; 1 = row slices
+ *                                (bit-identical to 0); 0 = whole tiles
  *   large_fork (default 2)       how a batch's large segment (gnnb_workspace_set_large_segment) runs: 2 = small per-layer
  *                                kernels behind the stack kernel, 1 = the same on a side stream, 0 = the big layer-wise kernels
  * "math": 0 (default) = native fp32 MFMA everywhere; 1 = every wide update (the fused GCN stack's A1.W1^T, the

@@ -1103,11 +1103,13 @@ def test_linear_dma_path_segments_rowscale_and_ragged_edges(dev, M, N, F):
     segs = [(x.to(dev), None), (Ad, None), (Ad, amp.to(dev)), (Ad, att.to(dev))]
     outs = []
     try:
+        runtime.set_option("gemm_tail_split", 1)  # (row slices keep the summation order; the default stream-K tail has its own test)
         for dma in (1, 0):
             runtime.set_option("gemm_dma", dma)
             outs.append(runtime.linear(segs, w.to(dev), b.to(dev), skip=skip.to(dev), act="tanh").cpu())
     finally:
         runtime.set_option("gemm_dma", 1)
+        runtime.set_option("gemm_tail_split", 2)
     assert (outs[0].double() - ref).abs().max().item() < 2e-5
     assert torch.equal(outs[0], outs[1])
 
@@ -1130,11 +1132,48 @@ def test_linear_dma_tail_split_is_bit_identical(dev, M, N, K):
             runtime.set_option("gemm_tail_split", split)
             outs.append(runtime.linear([(ad, None)], wd, bd, skip=sd, act="relu").cpu())
     finally:
-        runtime.set_option("gemm_tail_split", 1)
+        runtime.set_option("gemm_tail_split", 2)
     rows = torch.cat([torch.arange(0, min(4096, M)), torch.arange(max(M - 70000, 0), M)])     # head + the whole tail round
     ref = torch.relu(a[rows].double() @ w.double().T + b.double() + skip[rows].double())
     assert (outs[0][rows].double() - ref).abs().max().item() < 2e-5
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N,K,segs", [(147494, 128, 1664, 4), (128 * 1153, 128, 1664, 1), (128 * 300 - 5, 256, 1024, 2),
+                                        (128 * 40 + 3, 128, 1280, 1), (5000, 130, 1600, 1), (77, 255, 1024, 2),
+                                        (128 * 255, 128, 1152, 3), (128 * 257, 128, 1152, 1), (128 * 513 + 1, 192, 1056, 1),
+                                        (128 * 300 - 5, 256, 512, 2)])
+def test_linear_dma_stream_k_tail(dev, M, N, K, segs):
+    """The default tail of k_linear_dma (gemm_tail_split 2): the last, partial round of tiles cut along K into equal runs over
+    all resident workgroups, parts added up in run order by the last workgroup at each tile.  Another summation order than
+    the unsplit launch -- compared with a float64 product at the same tolerance, and with the unsplit launch --, one order
+    per shape: two launches give the same bits; counters are left cleared (a third launch is right again).  Shapes: C4's
+    13F GEMM (1153 tiles, 4 segments with row scalers), fewer tiles than CUs, runs that span two tiles, ragged M and N; the
+    last one (K = 512 < 1024) takes row slices under the same option."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.rand(M, K, generator=g) - 0.5
+    w = (torch.rand(N, K, generator=g) - 0.5) / K ** 0.5
+    b, skip = torch.rand(N, generator=g), torch.rand(M, N, generator=g) - 0.5
+    sc = [None] + [torch.rand(M, generator=g) + 0.5 for _ in range(segs - 1)]
+    ks = K // segs // 32 * 32
+    cuts = [i * ks for i in range(segs)] + [K]
+    ad, wd, bd, sd = a.to(dev), w.to(dev), b.to(dev), skip.to(dev)
+    seg_list = [(ad[:, cuts[i]:cuts[i + 1]], sc[i].to(dev) if sc[i] is not None else None) for i in range(segs)]
+    outs = []
+    try:
+        for split in (2, 2, 0, 2):
+            runtime.set_option("gemm_tail_split", split)
+            outs.append(runtime.linear(seg_list, wd, bd, skip=sd, act="relu").cpu())
+    finally:
+        runtime.set_option("gemm_tail_split", 2)
+    rows = torch.cat([torch.arange(0, min(4096, M)), torch.arange(max(M - 40000, 0), M)])
+    a64 = a[rows].double().clone()
+    for i in range(1, segs):
+        a64[:, cuts[i]:cuts[i + 1]] *= sc[i][rows].double()[:, None]
+    ref = torch.relu(a64 @ w.double().T + b.double() + skip[rows].double())
+    assert (outs[0][rows].double() - ref).abs().max().item() < 3e-5
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[3])
+    assert (outs[0] - outs[2]).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize("promise,math,zf", [(34, 0, 0), (50, 0, 0), (55, 0, 0), (57, 0, 0), (58, 0, 0), (61, 0, 0), (62, 0, 0),
