@@ -936,6 +936,27 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         }
         ZF_PT(7);
 
+#ifdef GNNB_ZF_ABLATE
+        // development: the waves WITHOUT a graph (8 .. 15 at BASELINE config 2) run a whole M1's worth of MFMAs beside P1 (one
+        // column slice x ALL units each; results dropped) -- does the row walk overlap with a matrix stream on the same SIMDs?
+        if ((dbg & (1 << 21)) && wv >= G2_NW / 2) {
+            __builtin_amdgcn_s_setprio(0);
+            for (int u = 0; u < units; u += 3) {
+                int row0[3];
+                f32x4 acc[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    row0[k] = min(u + k, units - 1) * 16;
+                    acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                zf_mma<KQ1, 3>(H, ldh, w1r, row0, li, lg, acc, 4, kmask);
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    asm volatile("" ::"v"(acc[k]));
+            }
+            __builtin_amdgcn_s_setprio(ZF_PRIO);
+        }
+#endif
         // ---- P0 of the NEXT stage (its rows landed before the last barrier but one), starting on the first wave that
         // had no graph to reduce
         if (nxt.ok && ZF_ON(1))
