@@ -91,6 +91,7 @@ struct Options {
     int gemm_tail_split; // k_linear_dma's last, partial round of tiles: 2 = cut along K into equal runs over all resident
                          // workgroups, parts added up by the last one at each tile (stream-K; default), 1 = handed out as
                          // row slices (bit-identical to 0), 0 = whole tiles
+    int pna_fold_lin;    // 1 = PNA's `lin` folded into its post-NN at upload: one 13F-wide GEMM per layer (default); 0 = two GEMMs
 };
 Options &options();
 

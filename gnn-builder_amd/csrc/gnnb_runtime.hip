@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2)};
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1)};
     return o;
 }
 
@@ -252,6 +252,8 @@ int gnnb_set_option(const char *name, int value)
         o.gemm_dma = value;
     else if (!strcmp(name, "gemm_tail_split") && value >= 0 && value <= 2)
         o.gemm_tail_split = value;
+    else if (!strcmp(name, "pna_fold_lin") && value >= 0 && value <= 1)
+        o.pna_fold_lin = value;
     else if (!strcmp(name, "gemm_wlds") && value >= 0 && value <= 1)
         o.gemm_wlds = value;
     else if (!strcmp(name, "gemm_wlds_slots") && value >= 1 && value <= 4)
@@ -334,6 +336,33 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
         case GNNB_CONV_PNA:
             conv_off[l] = {push(p[0], fi * 2 * fi), push(p[1], fi), push(p[2], fo * 13 * fi),
                            push(p[3], fo),          push(p[4], fo * fo), push(p[5], fo)};
+            // slots 6, 7: `lin` folded into the post-NN.  PNAConv applies them back to back with nothing in between
+            // (out = W_lin (W_post [x | S] + b_post) + b_lin, gnn_builder_lib.h:2081-2157), so
+            // W' = W_lin W_post [out, 13 F] and b' = W_lin b_post + b_lin (formed in double, rounded once) give the layer
+            // in ONE 13F-wide GEMM whose epilogue carries the skip operand and the activation: the out x out GEMM and the
+            // [N, out] hand-over between the two are gone (3 x ~55 us of a BASELINE config 4 step).  Not under the
+            // fixed-point emulation: the folded matrix is not on the weight grid.
+            if (!fpx) {
+                const size_t K13 = 13 * fi;
+                std::vector<double> acc(K13);
+                std::vector<float> wm(fo * K13), bm(fo);
+                for (size_t o = 0; o < fo; o++) {
+                    std::fill(acc.begin(), acc.end(), 0.0);
+                    double ab = (double)p[5][o];
+                    for (size_t h = 0; h < fo; h++) {
+                        const double wl = (double)p[4][o * fo + h];
+                        const float *wp = p[2] + h * K13;
+                        for (size_t k = 0; k < K13; k++)
+                            acc[k] += wl * (double)wp[k];
+                        ab += wl * (double)p[3][h];
+                    }
+                    for (size_t k = 0; k < K13; k++)
+                        wm[o * K13 + k] = (float)acc[k];
+                    bm[o] = (float)ab;
+                }
+                conv_off[l].push_back(push(wm.data(), wm.size()));
+                conv_off[l].push_back(push(bm.data(), bm.size()));
+            }
             break;
         }
         pi += slots;
@@ -484,7 +513,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     const size_t N = max_nodes, E = std::max(max_edges, 1), B = max_graphs;
     // (models whose last conv layer ends in the large-K segmented GEMM -- GraphSAGE -- pool in that GEMM's epilogue: a
     // node -> graph table and the buffer for the pieces of graphs that cross 32-row blocks)
-    const bool pool_epi = d.conv_type == GNNB_CONV_SAGE && d.num_layers >= 1 && d.fpx_w <= 0;
+    const bool pool_epi = (d.conv_type == GNNB_CONV_SAGE || d.conv_type == GNNB_CONV_PNA) && d.num_layers >= 1 && d.fpx_w <= 0;
     const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_eid = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
                  o_att = carve(N * 4), o_gcoef = carve(N * 16), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_gptr = carve((B + 1) * 4),
                  o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4), o_cut = carve((4096 + 1) * 16),
@@ -1051,6 +1080,35 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
                                      {R(ws->agg, 4 * fi), nullptr, 4 * fi, 4 * fi},
                                      {R(ws->agg, 4 * fi), ws->t.amp + row_lo, 4 * fi, 4 * fi},
                                      {R(ws->agg, 4 * fi), ws->t.att + row_lo, 4 * fi, 4 * fi}};
+            if (p.size() >= 8 && options().pna_fold_lin) {
+                // `lin` folded into the post-NN at upload (gnnb_model_create): one GEMM, skip + activation in its epilogue;
+                // the last layer of a whole-batch run pools there too (as GraphSAGE's)
+                if (pooled_in_epilogue && whole && l == d.num_layers - 1 && !fpx && options().fuse_pool && ws->t.node_graph && ws->pool_part && skip == nullptr) {
+                    GemmArgs g;
+                    if ((rc = build_gemm(g, segs, 4, p[6], 13 * fi)))
+                        return rc;
+                    PoolEpilogue pe;
+                    pe.node_graph = ws->t.node_graph;
+                    pe.graph_ptr = ws->t.graph_ptr;
+                    pe.pooled = ws->pooled;
+                    pe.part = ws->pool_part;
+                    pe.num_graphs = ws->t.num_graphs;
+                    pe.np = d.num_pools;
+                    for (int k = 0; k < 3; k++)
+                        pe.pools[k] = k < d.num_pools ? d.pools[k] : 0;
+                    hipError_t he = launch_linear(g, p[6], 13 * fi, p[7], nullptr, nxt, M, fo, d.activation, (hipStream_t)stream, &pe);
+                    if (he == hipSuccess) {
+                        GNNB_HIP_TRY(launch_pool_combine(pe, M, fo, (hipStream_t)stream));
+                        *pooled_in_epilogue = true;
+                        break;
+                    }
+                    if (he != hipErrorNotSupported)
+                        return fail(GNNB_ERR_HIP, "pooling GEMM launch failed: %s", hipGetErrorString(he));
+                }
+                if ((rc = gnnb_linear(segs, 4, p[6], 13 * fi, p[7], R(skip, fo), Rw(nxt, fo), M, fo, d.activation, stream)))
+                    return rc;
+                break;
+            }
             float *hid = ws->tmp0; // q is dead after the aggregate
             if ((rc = gnnb_linear(segs, 4, p[2], 13 * fi, p[3], nullptr, Rw(hid, fo), M, fo, GNNB_ACT_NONE, stream)))
                 return rc;

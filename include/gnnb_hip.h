@@ -321,6 +321,9 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *                                of scratch per (device, stream), allocated at the first such launch on a stream that is not
  *                                being captured -- warm up before capturing a graph), row slices otherwise; 1 = row slices
  *                                (bit-identical to 0); 0 = whole tiles
+ *   pna_fold_lin (default 1)     PNA: `lin` folded into the post-NN at upload (W' = W_lin W_post, formed in double): one 13F-wide
+ *                                GEMM per layer with skip + activation (+ the last layer's pooling) in its epilogue; 0 = the
+ *                                reference's two products.  Off under the fixed-point emulation
  *   large_fork (default 2)       how a batch's large segment (gnnb_workspace_set_large_segment) runs: 2 = small per-layer
  *                                kernels behind the stack kernel, 1 = the same on a side stream, 0 = the big layer-wise kernels
  * "math": 0 (default) = native fp32 MFMA everywhere; 1 = every wide update (the fused GCN stack's A1.W1^T, the

@@ -361,6 +361,44 @@ def test_pooling_in_the_last_gemm_epilogue(dev, hidden, layers, pools, act):
         assert np.array_equal(outs[1], outs[(1, 2)])  # deterministic: the same batch gives the same bits
 
 
+@pytest.mark.parametrize("hidden,out,layers,pools,act,skip", [(128, 128, 3, ("add", "mean", "max"), "relu", True), (128, 64, 2, ("max", "add"), "tanh", False),
+                                                              (32, 32, 3, ("mean",), "gelu", True), (128, 128, 1, ("add",), "sigmoid", False),
+                                                              (64, 128, 4, ("add", "mean", "max"), "relu", True)])
+def test_pna_lin_folded_into_the_post_nn(dev, hidden, out, layers, pools, act, skip):
+    """PNA (round 4): `lin` folded into the post-NN at upload -- one 13F-wide GEMM per layer, skip + activation in its
+    epilogue, the last layer of 128-wide models pooling there too -- against the reference's two products (pna_fold_lin = 0),
+    against the separate pooling pass, and the oracle, every graph.  Heavy-tailed batch with empty graphs, graphs crossing the
+    32-row pooling blocks, isolated nodes (degree 0: amplification 0, attenuation on the clamped degree)."""
+    model = make_model("pna", in_dim=11, hidden=hidden, out_dim=out, layers=layers, act=act, pools=pools, task_out=2, skip=skip, seed=hidden + layers)
+    base = synthetic.make_batch("molhiv_tail", 300, seed=5)
+    empty = (np.zeros((0, 11), np.float32), np.zeros((0, 2), np.int32))
+    rng = np.random.default_rng(layers)
+
+    def regraph(g):  # the same topology with 11 features
+        x, e = base.graph(g)
+        return rng.uniform(-1, 1, (x.shape[0], 11)).astype(np.float32), e
+
+    lone = (rng.uniform(-1, 1, (3, 11)).astype(np.float32), np.zeros((0, 2), np.int32))  # three isolated nodes
+    graphs = [empty] + [regraph(g) for g in range(150)] + [lone, empty] + [regraph(g) for g in range(150, 300)] + [empty]
+    batch = pack_graphs(graphs)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    outs = {}
+    try:
+        for fold, fuse in ((1, 1), (0, 1), (1, 0)):
+            runtime.set_option("pna_fold_lin", fold)
+            runtime.set_option("fuse_pool", fuse)
+            cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+            outs[(fold, fuse)] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            cm.check()
+    finally:
+        runtime.set_option("pna_fold_lin", 1)
+        runtime.set_option("fuse_pool", 1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for k, v in outs.items():
+        assert np.isfinite(v).all() and np.abs(v - ref).max() < TOL * scale, k
+    assert np.abs(outs[(1, 1)] - outs[(0, 1)]).max() < 3e-5 * scale and np.abs(outs[(1, 1)] - outs[(1, 0)]).max() < 3e-5 * scale
+
+
 @pytest.mark.parametrize("conv,fin,hidden,act", [("sage", 9, 256, "relu"), ("sage", 16, 100, "tanh"), ("gcn", 11, 128, "relu"),
                                                  ("gcn", 20, 64, "gelu"), ("gin", 9, 128, "relu"), ("gin", 32, 256, "sigmoid"),
                                                  ("sage", 4, 16, "relu")])
