@@ -217,13 +217,15 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     // paid as 5).  Tiles from `split_from` on -- the last, partial round -- are handed out as `split` (2 or 4) row
     // slices each, so that the round costs a half or a quarter tile.  A slice keeps the tile's MFMA order per output
     // element: 64 rows = one 32-row accumulator block per wave instead of two, 32 rows = 1 x 4 waves of 32 x 32.
-    // STREAM-K TAIL (round 4, sk.q > 0): the tiles from `split_from` on are not sliced by rows -- a 32-row slice keeps the
-    // whole K loop, whose chunks are then too small to cover the DMA round trip: at the C4 shape the quarter-tile round
-    // cost 80 us where a quarter of a round is 57, and 153 us when 4 x 129 slices just missed the 512 resident workgroups.
-    // Instead their (tile, chunk) space is cut into equal runs of q chunks, one run per workgroup (a run spans at most two
-    // tiles: q <= chunks per tile).  A workgroup multiplies its run at full tile width, parks the accumulators in
-    // sk.part[2 * workgroup + segment], and the LAST workgroup to arrive at a tile (sk.cnt, one counter per tile, reset by
-    // that workgroup) adds the parts up IN RUN ORDER and runs the epilogue: deterministic, one summation order per shape.
+    // STREAM-K (round 4, sk.q > 0): the tiles from `split_from` on are not sliced by rows -- a 32-row slice keeps the whole K
+    // loop, whose chunks are then too small to cover the DMA round trip: at the C4 shape the quarter-tile round cost 80 us
+    // where a quarter of a round is 57, and 153 us when 4 x 129 slices just missed the 512 resident workgroups.  Instead
+    // their (tile, chunk) space is cut into equal runs of q chunks, one run per workgroup: a partial tile, whole tiles, a
+    // partial tile.  A workgroup multiplies its run at full tile width; where it holds only a part of a tile's K it parks the
+    // accumulators in sk.part[2 * workgroup + (0: the run's first tile, 1: its last)], and the LAST workgroup to arrive at a
+    // tile (sk.cnt, one counter per tile, reset by that workgroup) adds the parts up IN RUN ORDER and runs the epilogue:
+    // deterministic, one summation order per shape.  The launcher puts ALL tiles into that space when there is at least one
+    // whole round of them (split_from = 0: no last round is left), else the tiles of the partial round.
     const int num_tiles = tiles_m * tiles_n;
     const bool skm = sk.q > 0;
     const int num_items = skm ? split_from : split_from + split * (num_tiles - split_from); // handed out round-robin
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         // The parts are exchanged between workgroups on DIFFERENT XCDs (one L2 each): stores and loads at agent scope (sc1:
         // write-through / read from the coherent level) and a wait for the stores, instead of a release fence -- which
         // writes back the whole L2 (buffer_wbl2) per wave: measured 655 us against 540 for the row slices at the C4 shape.
-        if (MC == 2 && NT == 2 && !POOL && skt >= 0) {
+        if (MC == 2 && !POOL && skt >= 0) {
             // part layout: [accumulator register 0..63][lane] (256-B rows: every store / load instruction is one contiguous piece)
             float *mine = sk.part + ((size_t)(2 * blockIdx.x + skseg) * 4 + wave) * 4096 + lane;
 #pragma unroll
@@ -713,8 +715,18 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         decode(v, m0, n0, mrows, c0, c1, skt);
         // whole tile: 2 x 2 waves of 64 x 64; 64-row slice: 2 x 2 waves of 32 x 64; 32-row slice: 1 x 4 waves of 32 x 32 (round
         // 4 -- it had been 32 x 64 on two of the four waves)
+        // N <= 64 (one column tile, no 32-row slices): the same row layouts with 32-column wave tiles
+        if constexpr (!POOL) {
+            if (N <= 64) {
+                if (mrows == DM)
+                    run_item(IntTag<2>{}, IntTag<1>{}, m0, n0, wm * 64, wn * 32, c0, c1, skt, v > n_rr ? 1 : 0);
+                else
+                    run_item(IntTag<1>{}, IntTag<1>{}, m0, n0, wm * 32, wn * 32, c0, c1, -1, 0);
+                continue;
+            }
+        }
         if (mrows == DM)
-            run_item(IntTag<2>{}, IntTag<2>{}, m0, n0, wm * 64, wn * 64, c0, c1, skt, v - n_rr);
+            run_item(IntTag<2>{}, IntTag<2>{}, m0, n0, wm * 64, wn * 64, c0, c1, skt, v > n_rr ? 1 : 0);
         else if (mrows == DM / 2)
             run_item(IntTag<1>{}, IntTag<2>{}, m0, n0, wm * 32, wn * 64, c0, c1, -1, 0);
         else
@@ -1547,9 +1559,12 @@ hipError_t launch_pool_combine(const PoolEpilogue &pe, int M, int N, hipStream_t
 // Stream-K scratch: one per (device, stream) -- launches on one stream run in order and may share it, launches on different
 // streams may not --, allocated at the first GEMM that wants it (never while the stream is being captured into a graph:
 // that launch takes the row slices) and kept for the life of the process.  64 MB of parts + the tile counters.
-// Used for K >= 1024 (32 chunks): measured at C4's 13F GEMM (52 chunks, 1153 tiles) 112.5 against 106 TFLOP/s with row slices,
-// at C5's K = 512 (16 chunks: runs of 7) 105 against 108 -- short runs are all pipeline prologue and fix-up.
-static constexpr int SK_MIN_Q = 6, SK_MIN_TOTAL = 32, SK_MAX_WG = 512, SK_MAX_STREAMS = 16;
+// Tail-only runs (fewer tiles than resident workgroups) for K >= 1024 (32 chunks): measured at C4's 13F GEMM (52 chunks, 1153
+// tiles) 112.5 against 106 TFLOP/s with row slices, at C5's K = 512 (16 chunks: runs of 7) 105 against 108 -- short runs are
+// all pipeline prologue and fix-up.  With every tile in the space (at least one whole round of tiles) a run is tiles * chunks /
+// 512 long, but nearly every tile then pays a fix-up (64 KB parked and read back): at K = 256 (8 chunks, 577 tiles) that took
+// the GEMM from 74 to 54 TFLOP/s, at K = 512 it is a wash, at K = 1664 it is +1.5 % on a 1.13-round shape: K >= 1024 as well.
+static constexpr int SK_MIN_Q = 6, SK_MIN_TOTAL = 32, SK_ALL_MIN_TOTAL = 32, SK_MAX_WG = 512, SK_MAX_STREAMS = 16;
 static bool stream_k_scratch(hipStream_t s, StreamK &out)
 {
     static std::mutex mu;
@@ -1601,7 +1616,11 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
         return hipErrorNotSupported; // (the pooling epilogue exists in k_linear_dma: the large-K segmented GEMM)
     }
     const int gm = (M + BM - 1) / BM;
-    if (N > 64 && options().gemm_dma) {
+    // (N in 33 .. 64 -- the last layer of the reference's benchmark models, 128 -> 64 -- takes the same kernel with 32-column
+    // wave tiles, when K is large enough to be worth the chunk pipeline: it ran in k_linear<1> at 0.20 of peak, a quarter of
+    // the ref6 PNA step)
+    const bool dma_narrow = N > 32 && N <= 64 && !pep && g.cpre[g.nseg] >= 8;
+    if ((N > 64 || dma_narrow) && options().gemm_dma) {
         bool plain = (ldw % 4 == 0) && (((uintptr_t)w & 15) == 0);
         for (int sg = 0; sg < g.nseg && plain; sg++)
             plain = g.avec[sg] && g.wvec[sg] && (g.k[sg] % BK == 0) && (g.koff[sg] % 4 == 0);
@@ -1623,16 +1642,24 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             int split = 1;
             StreamK sk;
             const int total = g.cpre[g.nseg], resident = DWGPC * num_cus;
-            if (options().gemm_tail_split == 2 && rem > 0 && !pep && total >= SK_MIN_TOTAL && resident <= SK_MAX_WG &&
-                stream_k_scratch(s, sk)) {
-                // equal runs over all resident workgroups, at least SK_MIN_Q chunks long (shorter ones are all pipeline
-                // prologue), at most one tile's K (a run spans two tiles at most)
-                sk.q = std::min(std::max((rem * total + resident - 1) / resident, SK_MIN_Q), total);
+            bool sk_all = false;
+            if (options().gemm_tail_split == 2 && rem > 0 && !pep && tiles >= resident && total >= SK_ALL_MIN_TOTAL &&
+                resident <= SK_MAX_WG && (long long)tiles * total < (1ll << 30) && stream_k_scratch(s, sk)) {
+                // at least one whole round of tiles: EVERY tile goes into the (tile, chunk) space and every resident workgroup
+                // takes one equal run of it (tiles * total / resident chunks: a partial tile, whole tiles, a partial tile) --
+                // there is no last round left; a tile is shared by two workgroups at most
+                sk.q = (int)(((long long)tiles * total + resident - 1) / resident);
+                sk_all = true;
+            } else if (options().gemm_tail_split == 2 && rem > 0 && !pep && total >= SK_MIN_TOTAL && resident <= SK_MAX_WG &&
+                       stream_k_scratch(s, sk)) {
+                // fewer tiles than resident workgroups or a K too short for the above: equal runs of the last round's space,
+                // at least SK_MIN_Q chunks long (shorter ones are all pipeline prologue)
+                sk.q = std::max((rem * total + resident - 1) / resident, SK_MIN_Q);
             } else if (options().gemm_tail_split && rem > 0 && !pep) { // (pooling epilogue: whole tiles only -- its blocks are 32-row aligned, every wave joins its barrier)
-                split = 4 * rem <= resident ? 4 : (2 * rem <= resident ? 2 : 1);
+                split = (4 * rem <= resident && !dma_narrow) ? 4 : (2 * rem <= resident ? 2 : 1);
             }
-            const int split_from = (split > 1 || sk.q > 0) ? tiles - rem : tiles;
-            const int grid = sk.q > 0 ? std::min(std::max(split_from, (rem * total + sk.q - 1) / sk.q), resident)
+            const int split_from = sk_all ? 0 : ((split > 1 || sk.q > 0) ? tiles - rem : tiles);
+            const int grid = sk.q > 0 ? std::min(std::max(split_from, (int)(((long long)(tiles - split_from) * total + sk.q - 1) / sk.q)), resident)
                                       : std::min(split_from + split * (tiles - split_from), resident);
 #define GNNB_DMA_LAUNCH(MATHV, POOLV)                                                                                    \
     hipLaunchKernelGGL((k_linear_dma<MATHV, POOLV>), dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, \

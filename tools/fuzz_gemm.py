@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised check of gnnb_linear's large-K path (k_linear_dma: tail slices, segments, row scalers, skip, activations,
+"""Randomised check of gnnb_linear's large-K path (k_linear_dma: tail slices / stream-K tail, narrow N, segments, row scalers, skip, activations,
 both math modes) against a float64 product on sampled rows.   python tools/fuzz_gemm.py [cases] [seed]"""
 import sys
 from pathlib import Path
@@ -19,9 +19,9 @@ acts = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "none"
 worst = [0.0, 0.0]
 for it in range(cases):
     M = int(rng.choice([rng.integers(1, 600), rng.integers(600, 40000), rng.integers(40000, 160000)]))
-    N = int(rng.integers(65, 300))
+    N = int(rng.integers(33, 300))                      # (33 .. 64: the 32-column wave tiles)
     nseg = int(rng.integers(1, 5))
-    ks = [32 * int(rng.integers(1, 9)) for _ in range(nseg)]
+    ks = [32 * int(rng.integers(1, 17 if it % 3 == 0 else 9)) for _ in range(nseg)]   # (K >= 1024: the stream-K tail)
     if nseg == 1 and ks[0] <= 128:
         ks[0] = 160                                     # (K <= 128 with one segment takes the register-resident kernels)
     act = str(rng.choice(list(acts)))
