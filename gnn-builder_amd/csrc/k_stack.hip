@@ -687,15 +687,19 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
             // layer 0's second linear, then per further layer: aggregate, first linear (ReLU, in place on A1), second
             // linear (-> H with skip + activation; the LAST one stays in the accumulators for the pooling below)
             m_inplace(H, ldh, IntTag<ACT>{}, 1); // (its own slice, index 0, was requested in front of M0)
+            G2_PT(6);
             for (int l = 1; l < nl; l++) {
                 // (layer l's first slice, index 2l - 1, is in flight since the previous in-place product)
                 phase_p1();
+                G2_PT(8);
                 g2_barrier();
                 m_inplace(A1, lda1, IntTag<GNNB_ACT_RELU>{}, 2 * l);
+                G2_PT(9);
                 if (l + 1 < nl) {
                     m_mid();
                     load_slice(Wmid + (size_t)(2 * l + 1) * mid_stride, bmid + (size_t)(2 * l + 1) * bmid_stride, n0c, h0);
                     g2_barrier();
+                    G2_PT(7);
                 }
             }
         } else {
