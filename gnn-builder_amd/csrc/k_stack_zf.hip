@@ -68,7 +68,7 @@ namespace gnnb {
 #ifndef ZF_PIN         // scheduler barriers pin "request block q + 1's fragments, THEN issue block q's MFMAs" in zf_mma (left alone the
 #define ZF_PIN 1       // compiler sinks every ds_read to just above its first use): 38.73 -> 38.55 us, 99 VGPRs
 #endif
-#ifndef ZF_SWZ         // H / Z rows unpadded, 16-B chunks XOR-swizzled by the row index: LDS bank conflicts 28 % -> 0 and the
+#ifndef ZF_SWZ         // H / Z rows unpadded, 16-B chunks XOR-swizzled by the row index: LDS bank conflicts 33 % -> 16 % of LDS cycles and the
 #define ZF_SWZ 0       // kernel 1.7 us SLOWER (38.8 -> 40.5 us, 117 VGPRs): the conflicts sit in M1's fragment reads, where the
 #endif                 // LDS array is < 25 % busy -- they cost nothing; the swizzle's address arithmetic does
 
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     // H / Z rows: 32, 64 or 128 floats, NOT padded; the 16-B chunks of row r are stored XOR-swizzled by r & kmask.  A
     // ds_read_b128 is served in four groups of sixteen lanes ({0-3, 12-15, 20-27}, ...): the fragment reads of M0 / M1 put
     // rows {-4..3} at chunk lg and rows {4..11} at chunk lg + 1 into one group -- with a padded row (33 slots) two of the
-    // sixteen always met on one slot (28 % of the kernel's LDS cycles were conflicts); XOR by the row index maps the two
+    // sixteen always met on one slot (a third of the kernel's LDS cycles are conflicts, most of them here); XOR by the row index maps the two
     // row sets onto disjoint slot sets whatever the chunk.  The region starts on a 512-B boundary so that a row's base
     // and its key do not share bits: P1 forms a neighbour's address as (record offset) ^ (the lane's chunk << 4).
     const int ldh = (h0 > 64 || h1 > 64) ? 128 : ((h0 > 32 || h1 > 32) ? 64 : 32);
