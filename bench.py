@@ -578,6 +578,13 @@ def main():
     # promise on the largest graph (validated on the device by every graph prep): lets molecule-sized
     # graphs be staged whole in LDS (fused conv stack)
     max_graph = int(max(np.diff(b.node_ptr)[:(sg[0] if sg else b.num_graphs)].max() for b, sg in zip(batches, segs)))
+    # PNA: promise on the largest in-degree too (the reference's degree_guess; validated on the device): molecules stay far
+    # below the 15 up to which the degree-class form of the post-NN product applies (gnnb_workspace_set_max_degree)
+    max_degree = 0
+    if w["conv"] == "pna" and not os.environ.get("GNNB_BENCH_NO_DEGREE_PROMISE"):
+        max_degree = int(max((np.bincount(b.coo[:, 1]).max() if b.num_edges else 0) for b in batches))
+        if max_degree > 15:
+            max_degree = 0
     if dry:
         import torch.nn  # noqa: F401
 
@@ -594,6 +601,9 @@ def main():
     else:
         cms = [runtime.CompiledModel.from_model(model, maxb, maxn, maxe, max_graph_nodes=max_graph)
                for _ in range(nstreams)]
+        if max_degree:
+            for c in cms:
+                c.set_max_degree(max_degree)
         cm = cms[0]
         streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
         dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr)) for b in batches]
@@ -702,6 +712,7 @@ def main():
                    "shard": args.shard, "rccl_ranks": rccl_ranks,
                    "batches_in_flight_per_gpu": nstreams, "max_graph_nodes_promise": max_graph,
                    "csr_build_in_timed_region": True,
+                   "max_degree_promise": max_degree or None,
                    "path": None if dry else cm.last_path()},
         "repeats": {"n": repeats, "statistic": "median", "steps_per_repeat": args.steps,
                     "value_min": graphs_done / max(times), "value_max": graphs_done / min(times),

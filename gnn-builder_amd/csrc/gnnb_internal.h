@@ -92,6 +92,7 @@ struct Options {
                          // workgroups, parts added up by the last one at each tile (stream-K; default), 1 = handed out as
                          // row slices (bit-identical to 0), 0 = whole tiles
     int pna_fold_lin;    // 1 = PNA's `lin` folded into its post-NN at upload: one 13F-wide GEMM per layer (default); 0 = two GEMMs
+    int pna_classes;     // 1 = PNA under a max_degree promise <= 15: rows sorted by degree, 5F-wide GEMM with per-class weights (default)
 };
 Options &options();
 
@@ -145,10 +146,22 @@ struct StreamK {
     float *part = nullptr;
     int *cnt = nullptr;
 };
+constexpr int GNNB_DEG_CLASSES = 15; // in-degrees 1 .. 15 (0 counts as 1: PNA clamps) get a class each; a larger promise keeps the general form
+// the batch's rows sorted into degree classes (k_misc.hip); work = 256 x 16 ints, perm = max_tiles * 128, tile_cls = max_tiles
+hipError_t launch_degree_classes(const BatchTables &t, int promise, int32_t *work, int32_t *perm, int32_t *tile_cls, int max_tiles,
+                                 hipStream_t s);
+// Row classes of k_linear_dma (PNA under a degree promise, k_gemm.hip): perm[position in the class-sorted space] = row or -1,
+// tile_cls[128-row tile of that space] = class, whose weight matrix starts w_stride floats after the previous one's.
+struct RowClasses {
+    const int32_t *perm = nullptr;
+    const int32_t *tile_cls = nullptr;
+    long w_stride = 0;
+};
 // pe != nullptr: y is not written; returns hipErrorNotSupported (nothing launched) when the GEMM shape has no pooling
 // epilogue -- the caller then runs the plain GEMM + a pooling pass
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
-                         const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pe = nullptr);
+                         const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pe = nullptr,
+                         const RowClasses *rc = nullptr);
 // the same narrow-input layer in ring form (k_first.hip): whole graphs staged in LDS once for ALL N <= 256 output columns;
 // F = width of x, K = F or (cat = F) 2 F.  hipErrorNotSupported -> launch_conv_gather's k_linear_reg form
 hipError_t launch_conv_first(const BatchTables &t, int agg_kind, float eps, const float *x, int F, int K, const float *w,

@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1)};
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1)};
     return o;
 }
 
@@ -171,6 +171,12 @@ struct gnnb_workspace {
     float2 *pool_part = nullptr; // pieces of graphs that cross the 32-row blocks of the pooling GEMM epilogue (PoolEpilogue::part)
     bool gcoef_ready = false; // t.gcoef holds the prepared batch's GCN coefficients (ensure_gcoef)
     int max_graph_nodes = 0; // caller's promise (0 = none)
+    int max_degree = 0;      // caller's promise on the in-degree (0 = none): gnnb_workspace_set_max_degree
+    // PNA degree classes of the prepared batch (launch_degree_classes): valid when deg_ready; deg_delta = the delta it was prepared with
+    int32_t *deg_work = nullptr, *deg_perm = nullptr, *deg_tile_cls = nullptr;
+    int deg_max_tiles = 0;
+    bool deg_ready = false;
+    float deg_delta = 0.0f;
     int last_path = GNNB_PATH_NONE; // which kernels the last forward on this workspace ran (gnnb_workspace_last_path)
     // "large segment" of the NEXT batches (gnnb_workspace_set_large_segment): graphs [large_g, B) -- nodes from large_n,
     // edges from large_e -- are exempt from the max_graph_nodes promise and run layer by layer; -1 = no such segment
@@ -254,6 +260,8 @@ int gnnb_set_option(const char *name, int value)
         o.gemm_tail_split = value;
     else if (!strcmp(name, "pna_fold_lin") && value >= 0 && value <= 1)
         o.pna_fold_lin = value;
+    else if (!strcmp(name, "pna_classes") && value >= 0 && value <= 1)
+        o.pna_classes = value;
     else if (!strcmp(name, "gemm_wlds") && value >= 0 && value <= 1)
         o.gemm_wlds = value;
     else if (!strcmp(name, "gemm_wlds_slots") && value >= 1 && value <= 4)
@@ -362,6 +370,26 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
                 }
                 conv_off[l].push_back(push(wm.data(), wm.size()));
                 conv_off[l].push_back(push(bm.data(), bm.size()));
+                // slot 8: the degree-class form (gnnb_workspace_set_max_degree): for d = 1 .. GNNB_DEG_CLASSES the matrix
+                // (W'_x | W'_1 + amp(d) W'_2 + att(d) W'_3), [out, 5 F] each, of the folded W' above; amp / att as graph prep
+                // computes them (k_prep.hip: logf(d + 1) / delta and its reciprocal)
+                if (fi % 32 == 0 && fo > 64) {
+                    const size_t K5 = 5 * fi;
+                    std::vector<float> wc((size_t)GNNB_DEG_CLASSES * fo * K5);
+                    for (int dg = 1; dg <= GNNB_DEG_CLASSES; dg++) {
+                        const float lg = logf((float)dg + 1.0f);
+                        const double amp = (double)(lg / d.pna_delta), att = (double)(d.pna_delta / lg);
+                        float *dst = &wc[(size_t)(dg - 1) * fo * K5];
+                        for (size_t o = 0; o < fo; o++) {
+                            const float *src = &wm[o * K13];
+                            for (size_t k = 0; k < fi; k++)
+                                dst[o * K5 + k] = src[k];
+                            for (size_t k = 0; k < 4 * fi; k++)
+                                dst[o * K5 + fi + k] = (float)((double)src[fi + k] + amp * (double)src[5 * fi + k] + att * (double)src[9 * fi + k]);
+                        }
+                    }
+                    conv_off[l].push_back(push(wc.data(), wc.size()));
+                }
             }
             break;
         }
@@ -517,6 +545,9 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_eid = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
                  o_att = carve(N * 4), o_gcoef = carve(N * 16), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_gptr = carve((B + 1) * 4),
                  o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4), o_cut = carve((4096 + 1) * 16),
+                 o_dwork = carve(d.conv_type == GNNB_CONV_PNA ? 1024 * 16 * 4 : 0),
+                 o_dperm = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 128 * 4 : 0),
+                 o_dcls = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 4 : 0),
                  o_ngraph = carve(pool_epi ? N * 4 : 0), o_part = carve(pool_epi ? ((N + 31) / 32) * 2 * (size_t)gnn_out_width(d) * 8 : 0),
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
                  o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
@@ -546,6 +577,11 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->t.agg_cut = (int4 *)(b + o_cut);
     ws->t.agg_cut_n = 0;
     ws->t.node_graph = pool_epi ? (int32_t *)(b + o_ngraph) : nullptr;
+    if (d.conv_type == GNNB_CONV_PNA) {
+        ws->deg_work = (int32_t *)(b + o_dwork);
+        ws->deg_perm = (int32_t *)(b + o_dperm);
+        ws->deg_tile_cls = (int32_t *)(b + o_dcls);
+    }
     ws->pool_part = pool_epi ? (float2 *)(b + o_part) : nullptr;
     ws->act[0] = (float *)(b + o_a0);
     ws->act[1] = (float *)(b + o_a1);
@@ -615,6 +651,14 @@ int gnnb_workspace_set_max_graph_nodes(gnnb_workspace *ws, int n)
     if (!ws || n < 0)
         return fail(GNNB_ERR_INVALID, "bad argument to gnnb_workspace_set_max_graph_nodes");
     ws->max_graph_nodes = n;
+    return GNNB_OK;
+}
+
+int gnnb_workspace_set_max_degree(gnnb_workspace *ws, int d)
+{
+    if (!ws || d < 0)
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_workspace_set_max_degree");
+    ws->max_degree = d;
     return GNNB_OK;
 }
 
@@ -694,6 +738,16 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
                                    (hipStream_t)stream));
     ws->prepared = true;
     ws->gcoef_ready = false;
+    // PNA under a degree promise: the rows sorted into degree classes, right behind the tables on the prep stream
+    ws->deg_ready = false;
+    if (ws->desc.conv_type == GNNB_CONV_PNA && ws->max_degree > 0 && ws->max_degree <= GNNB_DEG_CLASSES && options().pna_classes &&
+        ws->deg_perm && ws->large_g < 0 && ws->desc.fpx_w <= 0) {
+        ws->deg_max_tiles = (num_nodes + 127) / 128 + GNNB_DEG_CLASSES;
+        GNNB_HIP_TRY(launch_degree_classes(t, ws->max_degree, ws->deg_work, ws->deg_perm, ws->deg_tile_cls, ws->deg_max_tiles,
+                                           (hipStream_t)stream));
+        ws->deg_ready = true;
+        ws->deg_delta = pna_delta;
+    }
     // The GCN coefficient table (dinv_i dinv_j of the four inline sources; read by every layer-wise GCN aggregate) is
     // produced HERE, on the prep stream right behind the tables, whenever the batch can run layer by layer -- so that a
     // forward captured into a hipGraph contains no lazily launched table kernel and aggregates on other streams that are
@@ -737,7 +791,7 @@ int gnnb_workspace_check(gnnb_workspace *ws, void *stream)
     if (err != 0)
         return fail(GNNB_ERR_GRAPH, "malformed batch (flags 0x%x): 1/2 ptr arrays not monotone/complete, 4 an edge leaves "
                                     "its graph, 8 a graph exceeds the max_graph_nodes promise, 16 the large-segment offsets "
-                                    "disagree with node_ptr / edge_ptr", err);
+                                    "disagree with node_ptr / edge_ptr, 32 a node exceeds the max_degree promise", err);
     return GNNB_OK;
 }
 
@@ -1080,6 +1134,25 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
                                      {R(ws->agg, 4 * fi), nullptr, 4 * fi, 4 * fi},
                                      {R(ws->agg, 4 * fi), ws->t.amp + row_lo, 4 * fi, 4 * fi},
                                      {R(ws->agg, 4 * fi), ws->t.att + row_lo, 4 * fi, 4 * fi}};
+            if (p.size() >= 9 && options().pna_fold_lin && options().pna_classes && whole && ws->deg_ready && !fpx &&
+                ws->deg_delta == model->desc.pna_delta && fi % 32 == 0) {
+                // degree-class form (gnnb_workspace_set_max_degree): [x | A] . W_class^T over the class-sorted rows, written to
+                // the rows' own places; skip + activation in the epilogue (the last layer pools in the pass behind)
+                gnnb_gemm_seg s2[2] = {{cur, nullptr, fi, fi}, {ws->agg, nullptr, 4 * fi, 4 * fi}};
+                GemmArgs g;
+                if ((rc = build_gemm(g, s2, 2, p[8], 5 * fi)))
+                    return rc;
+                RowClasses rcl;
+                rcl.perm = ws->deg_perm;
+                rcl.tile_cls = ws->deg_tile_cls;
+                rcl.w_stride = (long)fo * 5 * fi;
+                hipError_t he = launch_linear(g, p[8], 5 * fi, p[7], skip, nxt, ws->deg_max_tiles * 128, fo, d.activation, (hipStream_t)stream,
+                                              nullptr, &rcl);
+                if (he == hipSuccess)
+                    break;
+                if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "degree-class GEMM launch failed: %s", hipGetErrorString(he));
+            }
             if (p.size() >= 8 && options().pna_fold_lin) {
                 // `lin` folded into the post-NN at upload (gnnb_model_create): one GEMM, skip + activation in its epilogue;
                 // the last layer of a whole-batch run pools there too (as GraphSAGE's)

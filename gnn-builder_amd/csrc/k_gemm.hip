@@ -195,13 +195,19 @@ static constexpr int DBUF_B = (DM + DN) * BK * 4; // 32 KB: A chunk | W chunk
 // the wave after the LDS read -- 24 MFMA of 8 passes instead of 32 of 16 per k block and accumulator quartet.
 // POOL: the pooling epilogue as its own instantiation (as a run-time branch of the one kernel it cost the plain GEMM 6-8 %:
 // 109 -> 101 TFLOP/s at the C4 shape, round 4)
-template <int MATH, bool POOL>
+// RC (round 4, PNA with a degree promise): the rows of A and Y are taken through a permutation that sorts them into DEGREE
+// CLASSES, and every 128-row tile multiplies by the weight matrix of its class (RowClasses): PNA's scalers depend on the
+// in-degree only, so [x | A | amp(d) A | att(d) A] . W^T = [x | A] . (W_x | W_1 + amp(d) W_2 + att(d) W_3)^T -- 5 F wide
+// instead of 13 F.  M is then the length of the sorted space (whole tiles), perm[position] = row or -1 (padding: loads
+// re-read row 0, nothing is stored).
+template <int MATH, int MODE>
 __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__restrict__ W, int ldw,
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ skip, float *__restrict__ Y, int M,
                                                     int N, int act, int tiles_m, int tiles_n, int split_from, int split,
-                                                    PoolEpilogue pe, StreamK sk)
+                                                    PoolEpilogue pe, StreamK sk, RowClasses rc)
 {
+    constexpr bool POOL = MODE == 1, RC = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1; // 2 x 2 waves: 64 rows x 64 columns each (a 32-row slice: 1 x 4 waves, 32 columns each)
@@ -263,9 +269,29 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     // the integer divisions are scalar instructions in front of every wave's next MFMA)
     int iss_v = 0, iss_c = 0, iss_c1 = 0, iss_buf = 0;
     int iss_m0 = 0, iss_n0 = 0, iss_mrows = 0;
+    constexpr int DA_PER_ = DM / 8 / DNW;
+    // (RC) the issue item's rows for this lane's DA_PER_ DMA instructions and its class's weight matrix
+    int irow[DA_PER_];
+    const float *iss_w = W;
+    auto issue_rows = [&]() {
+        if (!RC)
+            return;
+#pragma unroll
+        for (int i = 0; i < DA_PER_; i++) {
+            const int pos = min(iss_m0 + (wave * DA_PER_ + i) * 8 + drow, M - 1);
+            irow[i] = max(rc.perm[pos], 0);
+        }
+        iss_w = W + (size_t)__builtin_amdgcn_readfirstlane(rc.tile_cls[min(iss_m0 / DM, tiles_m - 1)]) * rc.w_stride; // (uniform: a scalar base for the DMA)
+        // (consumed HERE: left pending, every use inside the chunk loop would be guarded by s_waitcnt vmcnt(0), which also
+        // waits for the chunk DMA in flight -- see the note on the row scalers below)
+#pragma unroll
+        for (int i = 0; i < DA_PER_; i++)
+            asm volatile("" : "+v"(irow[i]));
+    };
     {
         int skt_;
         decode(0, iss_m0, iss_n0, iss_mrows, iss_c, iss_c1, skt_);
+        issue_rows();
     }
     int vm = 0; // vector-memory instructions this wave has issued (DMA + epilogue stores): for the counted waits
     // The next chunk's DMA goes out in FOUR parts, one per k step of the chunk being multiplied (a burst of eight
@@ -301,11 +327,24 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         // scalar bases (tile origin, clamped into the matrix) + per-lane 32-bit offsets: the address arithmetic stays
         // on the scalar unit
         const int m0c = min(m0, M - 1), n0c = min(n0, N - 1);
-        ic.ga = ap + (size_t)m0c * lda + kk;
-        ic.gw = W + (size_t)n0c * ldw + koff + kk;
+        ic.ga = RC ? ap + kk : ap + (size_t)m0c * lda + kk;
+        ic.gw = (RC ? iss_w : W) + (size_t)n0c * ldw + koff + kk;
         ic.ra_max = M - 1 - m0c, ic.rw_max = N - 1 - n0c; // rows past M / N re-read the last valid row (never stored)
         ic.la = smem_a + (uint32_t)iss_buf * DBUF_B, ic.lw = ic.la + DM * BK * 4;
         ic.lda_b = (uint32_t)lda * 4, ic.ldw_b = (uint32_t)ldw * 4;
+        if (RC) {
+            // (the class lookup sits behind per-lane loads in the cursor's update: the compiler no longer proves the bases
+            // uniform -- they are, and the DMA takes them as scalars)
+            auto uni = [](const float *p) {
+                const uint64_t v = (uint64_t)(uintptr_t)p;
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+                return reinterpret_cast<const float *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+            };
+            ic.ga = uni(ic.ga);
+            ic.gw = uni(ic.gw);
+            ic.la = __builtin_amdgcn_readfirstlane(ic.la);
+            ic.lw = __builtin_amdgcn_readfirstlane(ic.lw);
+        }
         return ic;
     };
     constexpr int DPARTS = BK / 8, DA_PER = DM / 8 / DNW, DW_PER = DN / 8 / DNW; // A / W instructions per wave and chunk
@@ -316,7 +355,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         if (i < DA_PER) {
             const int r0 = (wave * DA_PER + i) * 8;
             if (r0 < ic.mrows) {
-                dma16_to_lds_s(ic.ga, (uint32_t)min(r0 + drow, ic.ra_max) * ic.lda_b + dpiece_b, ic.la + (uint32_t)r0 * 128);
+                dma16_to_lds_s(ic.ga, (uint32_t)(RC ? irow[i < DA_PER_ ? i : 0] : min(r0 + drow, ic.ra_max)) * ic.lda_b + dpiece_b, ic.la + (uint32_t)r0 * 128);
                 vm++;
             }
         }
@@ -334,6 +373,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
             if (++iss_v < n_work) {
                 int skt_;
                 decode(iss_v, iss_m0, iss_n0, iss_mrows, iss_c, iss_c1, skt_);
+                issue_rows();
             }
         }
         return vm;
@@ -378,6 +418,11 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                 const int r = m0 + rbase + mi * 32 - 1 + lane;
                 if (lane < 34 && r >= 0 && r < M)
                     gidv[mi] = pe.node_graph[r];
+            }
+            // (RC: the row this lane's accumulator block goes to -- the same registers, the two modes exclude each other)
+            if (MC > 0 && RC) {
+                const int pos = m0 + rbase + mi * 32 + li;
+                gidv[mi] = pos < M ? rc.perm[pos] : -1;
             }
         }
         // per-row scalers of the scaled segments (PNA: amp . A, att . A), fetched once per item for the lane's A rows
@@ -664,8 +709,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
             constexpr int ACT = decltype(tag)::value;
 #pragma unroll
             for (int mi = 0; mi < MC; mi++) {
-                const int rowg = m0 + rbase + mi * 32 + li;
-                if (rowg >= M)
+                const int rowg = RC ? gidv[mi] : m0 + rbase + mi * 32 + li;
+                if (RC ? rowg < 0 : rowg >= M)
                     continue;
 #pragma unroll
                 for (int ni = 0; ni < NT; ni++)
@@ -702,7 +747,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         // the stores just issued sit between the prefetched chunk and the next waits: count them, or the first wait
         // of the next item would drain them.  Only blocks that certainly issued all eight 16-B stores are counted (an
         // under-count merely makes the next waits stricter; an over-count would let a wait return early).
-        if (vec && n0 + wcol + 32 * NT <= N) {
+        if (!RC && vec && n0 + wcol + 32 * NT <= N) { // (RC: padding rows store nothing -- not counted, the waits are merely stricter)
 #pragma unroll
             for (int mi = 0; mi < MC; mi++)
                 if (m0 + rbase + mi * 32 + 32 <= M)
@@ -1602,17 +1647,21 @@ static bool stream_k_scratch(hipStream_t s, StreamK &out)
 }
 
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
-                         const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pep)
+                         const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pep,
+                         const RowClasses *rcp)
 {
     if (M <= 0 || N <= 0)
-        return pep ? hipErrorNotSupported : hipSuccess;
+        return (pep || rcp) ? hipErrorNotSupported : hipSuccess;
+    if (rcp && (pep || !rcp->perm || !rcp->tile_cls || M % DM != 0 || N <= 64 || !options().gemm_dma))
+        return hipErrorNotSupported; // (row classes exist in k_linear_dma's whole-tile form only)
+    const RowClasses rc = rcp ? *rcp : RowClasses{};
     const PoolEpilogue pe = pep ? *pep : PoolEpilogue{};
-    if (!pep) {
+    if (!pep && !rcp) {
         if (linear_wlds_eligible(g, w, ldw, bias, skip, y, N))
             return launch_linear_wlds(g, w, ldw, bias, skip, y, M, N, act, s);
         if (linear_reg_eligible(g))
             return launch_linear_reg(g, w, ldw, bias, skip, y, M, N, act, s);
-    } else if (skip != nullptr || linear_wlds_eligible(g, w, ldw, bias, skip, y, N) || linear_reg_eligible(g)) {
+    } else if (pep && (skip != nullptr || linear_wlds_eligible(g, w, ldw, bias, skip, y, N) || linear_reg_eligible(g))) {
         return hipErrorNotSupported; // (the pooling epilogue exists in k_linear_dma: the large-K segmented GEMM)
     }
     const int gm = (M + BM - 1) / BM;
@@ -1627,8 +1676,10 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
         if (plain) {
             const size_t lds = (size_t)DNBUF * DBUF_B + 16; // (+ the stream-K arrival flag)
             {
-                const void *fn = pep ? (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, true>) : reinterpret_cast<const void *>(k_linear_dma<0, true>))
-                                     : (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, false>) : reinterpret_cast<const void *>(k_linear_dma<0, false>));
+                const int mode = pep ? 1 : (rcp ? 2 : 0);
+                const void *fn = mode == 1 ? (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, 1>) : reinterpret_cast<const void *>(k_linear_dma<0, 1>))
+                                 : mode == 2 ? (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, 2>) : reinterpret_cast<const void *>(k_linear_dma<0, 2>))
+                                             : (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, 0>) : reinterpret_cast<const void *>(k_linear_dma<0, 0>));
                 hipError_t e = ensure_dynamic_lds(fn, lds);
                 if (e != hipSuccess)
                     return e;
@@ -1661,25 +1712,29 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             const int split_from = sk_all ? 0 : ((split > 1 || sk.q > 0) ? tiles - rem : tiles);
             const int grid = sk.q > 0 ? std::min(std::max(split_from, (int)(((long long)(tiles - split_from) * total + sk.q - 1) / sk.q)), resident)
                                       : std::min(split_from + split * (tiles - split_from), resident);
-#define GNNB_DMA_LAUNCH(MATHV, POOLV)                                                                                    \
-    hipLaunchKernelGGL((k_linear_dma<MATHV, POOLV>), dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, \
-                       tn, split_from, split, pe, sk)
+#define GNNB_DMA_LAUNCH(MATHV, MODEV)                                                                                    \
+    hipLaunchKernelGGL((k_linear_dma<MATHV, MODEV>), dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, \
+                       tn, split_from, split, pe, sk, rc)
             if (options().math) {
                 if (pep)
-                    GNNB_DMA_LAUNCH(1, true);
+                    GNNB_DMA_LAUNCH(1, 1);
+                else if (rcp)
+                    GNNB_DMA_LAUNCH(1, 2);
                 else
-                    GNNB_DMA_LAUNCH(1, false);
+                    GNNB_DMA_LAUNCH(1, 0);
             } else {
                 if (pep)
-                    GNNB_DMA_LAUNCH(0, true);
+                    GNNB_DMA_LAUNCH(0, 1);
+                else if (rcp)
+                    GNNB_DMA_LAUNCH(0, 2);
                 else
-                    GNNB_DMA_LAUNCH(0, false);
+                    GNNB_DMA_LAUNCH(0, 0);
             }
 #undef GNNB_DMA_LAUNCH
             return hipGetLastError();
         }
     }
-    if (pep)
+    if (pep || rcp)
         return hipErrorNotSupported;
     if (N > 64) {
         constexpr int NT = 2;

@@ -72,7 +72,7 @@ PATH_NAMES = {0: "none", 1: "layerwise", 2: "stack", 3: "stack_zf"}  # gnnb_hip.
 EXPORTED_SYMBOLS = [
     "gnnb_version", "gnnb_last_error", "gnnb_device_count", "gnnb_stream_sync",
     "gnnb_model_num_params", "gnnb_model_create", "gnnb_model_destroy", "gnnb_model_get_desc",
-    "gnnb_workspace_create", "gnnb_workspace_destroy", "gnnb_workspace_bytes", "gnnb_workspace_set_max_graph_nodes",
+    "gnnb_workspace_create", "gnnb_workspace_destroy", "gnnb_workspace_bytes", "gnnb_workspace_set_max_graph_nodes", "gnnb_workspace_set_max_degree",
     "gnnb_workspace_last_path", "gnnb_workspace_set_large_segment",
     "gnnb_forward_batched", "gnnb_forward_prepared", "gnnb_forward_batched_host", "gnnb_workspace_check",
     "gnnb_graph_prep", "gnnb_graph_tables_to_host", "gnnb_aggregate", "gnnb_linear", "gnnb_global_pool",
@@ -137,6 +137,7 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
         lib.gnnb_stream_sync.argtypes = [C.c_void_p]
         lib.gnnb_set_option.argtypes = [C.c_char_p, C.c_int]
         lib.gnnb_workspace_set_max_graph_nodes.argtypes = [C.c_void_p, C.c_int]
+        lib.gnnb_workspace_set_max_degree.argtypes = [C.c_void_p, C.c_int]
         lib.gnnb_workspace_last_path.argtypes = [C.c_void_p]
         lib.gnnb_workspace_set_large_segment.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         lib.gnnb_aggregate_timed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -259,6 +260,11 @@ class CompiledModel:
 
     def set_max_graph_nodes(self, n: int) -> None:
         _check(self.lib.gnnb_workspace_set_max_graph_nodes(self._ws, int(n)))
+
+    def set_max_degree(self, d: int) -> None:
+        """Promise on the largest in-degree of the following batches (0 = none; the reference's ``degree_guess``): PNA models
+        then run their post-NN products in the degree-class form (d <= 15).  Validated on the device (``check()``)."""
+        _check(self.lib.gnnb_workspace_set_max_degree(self._ws, int(d)))
 
     def last_path(self) -> str:
         """Which kernels the last forward on this workspace ran: "layerwise", "stack" (k_gcn2_fused) or "stack_zf"

@@ -137,6 +137,15 @@ size_t gnnb_workspace_bytes(const gnnb_workspace *ws);
  * gnnb_graph_prep / gnnb_forward_batched on the workspace after a flagged batch has run returns GNNB_ERR_GRAPH
  * (read from a host-mapped word, no synchronisation; best effort -- the check is the authoritative answer). */
 int gnnb_workspace_set_max_graph_nodes(gnnb_workspace *ws, int n);
+/* Promise that no node of the batches run on this workspace has an in-degree above `d` (0 = no promise, the default) -- the
+ * reference's per-design degree bound (Project(..., degree_guess, ...), code_gen.py:63-82, its MAX_DEGREE).  PNA's scalers
+ * depend on the in-degree only (amp = log(d + 1) / delta, att = its reciprocal, gnn_builder_lib.h:1857-1875), so under a
+ * promise of d <= 15 (molecules: <= 6) a PNA layer's 13 F-wide post-NN product [x | A | amp A | att A] . W^T is evaluated as
+ * the 5 F-wide [x | A] . (W_x | W_1 + amp(d) W_2 + att(d) W_3)^T with the rows sorted by degree class and one pre-combined
+ * weight matrix per class (formed in double at gnnb_model_create): the same mathematics, 2.6x fewer flops.  Applies when
+ * the batch is prepared with the model's own pna_delta.  VALIDATED on the device by every graph prep like the node
+ * promise (flag 32 of gnnb_workspace_check).  Other conv types ignore it. */
+int gnnb_workspace_set_max_degree(gnnb_workspace *ws, int d);
 
 /* Which kernels the LAST forward on this workspace ran (diagnostics / benchmarks: the answer does not change any
  * result).  The reference has one dataflow per generated model (compute_gnn_head, model.cpp.jinja:151-359); here the
@@ -324,6 +333,8 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *   pna_fold_lin (default 1)     PNA: `lin` folded into the post-NN at upload (W' = W_lin W_post, formed in double): one 13F-wide
  *                                GEMM per layer with skip + activation (+ the last layer's pooling) in its epilogue; 0 = the
  *                                reference's two products.  Off under the fixed-point emulation
+ *   pna_classes (default 1)      PNA under a max_degree promise (gnnb_workspace_set_max_degree): the degree-class form; 0 = the
+ *                                general 13 F-wide form
  *   large_fork (default 2)       how a batch's large segment (gnnb_workspace_set_large_segment) runs: 2 = small per-layer
  *                                kernels behind the stack kernel, 1 = the same on a side stream, 0 = the big layer-wise kernels
  * "math": 0 (default) = native fp32 MFMA everywhere; 1 = every wide update (the fused GCN stack's A1.W1^T, the

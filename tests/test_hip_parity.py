@@ -399,6 +399,57 @@ def test_pna_lin_folded_into_the_post_nn(dev, hidden, out, layers, pools, act, s
     assert np.abs(outs[(1, 1)] - outs[(0, 1)]).max() < 3e-5 * scale and np.abs(outs[(1, 1)] - outs[(1, 0)]).max() < 3e-5 * scale
 
 
+@pytest.mark.parametrize("hidden,out,layers,pools,act,skip,fin", [(128, 128, 3, ("add", "mean", "max"), "relu", True, 11), (128, 64, 2, ("max", "add"), "tanh", False, 32),
+                                                                  (64, 128, 4, ("mean",), "gelu", True, 64), (128, 96, 1, ("add",), "sigmoid", False, 128),
+                                                                  (32, 128, 3, ("add", "mean", "max"), "relu", True, 32)])
+def test_pna_degree_classes(dev, hidden, out, layers, pools, act, skip, fin):
+    """PNA under a max_degree promise (round 4): the 13 F-wide post-NN product as the 5 F-wide [x | A] . W_class^T over rows
+    sorted into degree classes (one pre-combined matrix per in-degree 1 .. 15) -- against the general form (no promise),
+    against pna_classes = 0, and the oracle, every graph.  Batch: molecules, isolated nodes (degree 0 counts as 1), a node
+    of degree exactly the promise, empty graphs, a row count that is no multiple of the tile; layers whose widths do not
+    take the form (F % 32 != 0, out <= 64) run the general one in the same model.  A broken promise is flagged (32)."""
+    model = make_model("pna", in_dim=fin, hidden=hidden, out_dim=out, layers=layers, act=act, pools=pools, task_out=2, skip=skip, seed=hidden + layers + fin)
+    base = synthetic.make_batch("qm9", 600, seed=9)
+    rng = np.random.default_rng(fin)
+    empty = (np.zeros((0, fin), np.float32), np.zeros((0, 2), np.int32))
+
+    def regraph(g):
+        x, e = base.graph(g)
+        return rng.uniform(-1, 1, (x.shape[0], fin)).astype(np.float32), e
+
+    lone = (rng.uniform(-1, 1, (3, fin)).astype(np.float32), np.zeros((0, 2), np.int32))
+    star = (rng.uniform(-1, 1, (14, fin)).astype(np.float32), np.array([[i, 0] for i in range(1, 14)] + [[0, i] for i in range(1, 14)], np.int32))
+    graphs = [empty] + [regraph(g) for g in range(300)] + [lone, star, empty] + [regraph(g) for g in range(300, 600)] + [empty]
+    batch = pack_graphs(graphs)
+    maxdeg = int(np.bincount(batch.coo[:, 1]).max())
+    assert 13 <= maxdeg <= 15 and batch.num_nodes % 128 != 0
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    outs = {}
+    try:
+        for promise, classes in ((maxdeg, 1), (0, 1), (maxdeg, 0), (15, 1)):
+            runtime.set_option("pna_classes", classes)
+            cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+            cm.set_max_degree(promise)
+            outs[(promise, classes)] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            cm.check()
+            if (promise, classes) == (maxdeg, 1):
+                again = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+                assert np.array_equal(outs[(promise, classes)], again)  # (the order inside a class does not reach the results)
+    finally:
+        runtime.set_option("pna_classes", 1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for k, v in outs.items():
+        assert np.isfinite(v).all() and np.abs(v - ref).max() < TOL * scale, k
+    assert np.abs(outs[(maxdeg, 1)] - outs[(0, 1)]).max() < 3e-5 * scale
+    assert np.array_equal(outs[(0, 1)], outs[(maxdeg, 0)])
+    # a promise the batch breaks: flagged by graph prep
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    cm.set_max_degree(maxdeg - 1)
+    cm.forward(*to_dev(batch, dev))
+    with pytest.raises(runtime.GnnbError, match="0x20"):
+        cm.check()
+
+
 @pytest.mark.parametrize("conv,fin,hidden,act", [("sage", 9, 256, "relu"), ("sage", 16, 100, "tanh"), ("gcn", 11, 128, "relu"),
                                                  ("gcn", 20, 64, "gelu"), ("gin", 9, 128, "relu"), ("gin", 32, 256, "sigmoid"),
                                                  ("sage", 4, 16, "relu")])
