@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1)};
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1)};
     return o;
 }
 
@@ -262,6 +262,8 @@ int gnnb_set_option(const char *name, int value)
         o.pna_fold_lin = value;
     else if (!strcmp(name, "pna_classes") && value >= 0 && value <= 1)
         o.pna_classes = value;
+    else if (!strcmp(name, "fold_skip") && value >= 0 && value <= 1)
+        o.fold_skip = value;
     else if (!strcmp(name, "gemm_wlds") && value >= 0 && value <= 1)
         o.gemm_wlds = value;
     else if (!strcmp(name, "gemm_wlds_slots") && value >= 1 && value <= 4)
@@ -324,6 +326,11 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
         const LayerDims ld = layer_dims(d, l);
         const size_t fi = ld.fin, fo = ld.fout;
         const float *const *p = host_params + pi;
+        // the layer's skip connection (middle layers: y = conv(x) + x, models.py:562-564) where x itself is an operand of
+        // the layer's GEMM (GraphSAGE's root term, PNA's x segment): folded into that operand's weights as + I, so that the
+        // [N, out] skip operand is not read again in the epilogue (45 of 293 us of a 128-wide PNA layer's GEMM went there:
+        // 32-byte pieces of 128-byte lines)
+        const bool skip_fold = d.skip && l != 0 && l != d.num_layers - 1 && fi == fo && !fpx;
         switch (d.conv_type) {
         case GNNB_CONV_GCN:
             conv_off[l] = {push(p[0], fo * fi), push(p[1], fo)};
@@ -339,6 +346,11 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
                 memcpy(&cat[o * 2 * fi + fi], p[2] + o * fi, fi * sizeof(float));
             }
             conv_off[l] = {push(cat.data(), cat.size()), push(p[1], fo)};
+            if (skip_fold) { // slot 2: [Wl | Wr + I]
+                for (size_t o = 0; o < fo; o++)
+                    cat[o * 2 * fi + fi + o] += 1.0f;
+                conv_off[l].push_back(push(cat.data(), cat.size()));
+            }
             break;
         }
         case GNNB_CONV_PNA:
@@ -364,6 +376,8 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
                             acc[k] += wl * (double)wp[k];
                         ab += wl * (double)p[3][h];
                     }
+                    if (skip_fold)
+                        acc[o] += 1.0; // (+ I on the x segment: the skip connection)
                     for (size_t k = 0; k < K13; k++)
                         wm[o * K13 + k] = (float)acc[k];
                     bm[o] = (float)ab;
@@ -1036,6 +1050,8 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
         const std::vector<const float *> &p = model->conv[l];
         // skip connection on middle layers only (models.py:562-564); fused into the GEMM epilogue
         const float *skip = (d.skip && l != 0 && l != d.num_layers - 1) ? cur : nullptr;
+        // (GraphSAGE / PNA: derived weight slots of such a layer carry the skip connection as + I on x's own weights: gnnb_model_create)
+        const bool skip_fold = skip != nullptr && fi == fo && !fpx;
         float *nxt = ws->act[which];
         if ((const float *)nxt == cur) { // never write the buffer being read
             which ^= 1;
@@ -1116,6 +1132,11 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
                 if (he != hipErrorNotSupported)
                     return fail(GNNB_ERR_HIP, "pooling GEMM launch failed: %s", hipGetErrorString(he));
             }
+            if (skip_fold && p.size() >= 3 && options().fold_skip) { // (slot 2: [Wl | Wr + I])
+                if ((rc = gnnb_linear(segs, 2, p[2], 2 * fi, p[1], nullptr, Rw(nxt, fo), M, fo, d.activation, stream)))
+                    return rc;
+                break;
+            }
             if ((rc = gnnb_linear(segs, 2, p[0], 2 * fi, p[1], R(skip, fi), Rw(nxt, fo), M, fo, d.activation, stream)))
                 return rc;
             break;
@@ -1146,8 +1167,8 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
                 rcl.perm = ws->deg_perm;
                 rcl.tile_cls = ws->deg_tile_cls;
                 rcl.w_stride = (long)fo * 5 * fi;
-                hipError_t he = launch_linear(g, p[8], 5 * fi, p[7], skip, nxt, ws->deg_max_tiles * 128, fo, d.activation, (hipStream_t)stream,
-                                              nullptr, &rcl);
+                hipError_t he = launch_linear(g, p[8], 5 * fi, p[7], skip_fold ? nullptr : skip, nxt, ws->deg_max_tiles * 128, fo, d.activation,
+                                              (hipStream_t)stream, nullptr, &rcl);
                 if (he == hipSuccess)
                     break;
                 if (he != hipErrorNotSupported)
@@ -1178,7 +1199,7 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
                     if (he != hipErrorNotSupported)
                         return fail(GNNB_ERR_HIP, "pooling GEMM launch failed: %s", hipGetErrorString(he));
                 }
-                if ((rc = gnnb_linear(segs, 4, p[6], 13 * fi, p[7], R(skip, fo), Rw(nxt, fo), M, fo, d.activation, stream)))
+                if ((rc = gnnb_linear(segs, 4, p[6], 13 * fi, p[7], skip_fold ? nullptr : R(skip, fo), Rw(nxt, fo), M, fo, d.activation, stream)))
                     return rc;
                 break;
             }

@@ -335,6 +335,9 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *                                reference's two products.  Off under the fixed-point emulation
  *   pna_classes (default 1)      PNA under a max_degree promise (gnnb_workspace_set_max_degree): the degree-class form; 0 = the
  *                                general 13 F-wide form
+ *   fold_skip (default 1)        GraphSAGE: a middle layer's skip connection (y = conv(x) + x) as + I on the root weights -- x is an
+ *                                operand of the layer's GEMM anyway -- instead of a second read of x in the epilogue (PNA's folded
+ *                                forms always carry it); 0 = the skip operand
  *   large_fork (default 2)       how a batch's large segment (gnnb_workspace_set_large_segment) runs: 2 = small per-layer
  *                                kernels behind the stack kernel, 1 = the same on a side stream, 0 = the big layer-wise kernels
  * "math": 0 (default) = native fp32 MFMA everywhere; 1 = every wide update (the fused GCN stack's A1.W1^T, the
