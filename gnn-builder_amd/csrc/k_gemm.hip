@@ -276,6 +276,15 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     auto issue_rows = [&]() {
         if (!RC)
             return;
+        // (the cursor as explicit scalars: behind the per-lane loads below the compiler no longer proved it uniform and moved
+        // the whole address arithmetic of the chunk issue -- ~100 instructions per chunk -- from the scalar to the vector unit)
+        iss_m0 = __builtin_amdgcn_readfirstlane(iss_m0);
+        iss_n0 = __builtin_amdgcn_readfirstlane(iss_n0);
+        iss_mrows = __builtin_amdgcn_readfirstlane(iss_mrows);
+        iss_c = __builtin_amdgcn_readfirstlane(iss_c);
+        iss_c1 = __builtin_amdgcn_readfirstlane(iss_c1);
+        iss_v = __builtin_amdgcn_readfirstlane(iss_v);
+        iss_buf = __builtin_amdgcn_readfirstlane(iss_buf);
 #pragma unroll
         for (int i = 0; i < DA_PER_; i++) {
             const int pos = min(iss_m0 + (wave * DA_PER_ + i) * 8 + drow, M - 1);
@@ -747,10 +756,10 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         // the stores just issued sit between the prefetched chunk and the next waits: count them, or the first wait
         // of the next item would drain them.  Only blocks that certainly issued all eight 16-B stores are counted (an
         // under-count merely makes the next waits stricter; an over-count would let a wait return early).
-        if (!RC && vec && n0 + wcol + 32 * NT <= N) { // (RC: padding rows store nothing -- not counted, the waits are merely stricter)
+        if (vec && n0 + wcol + 32 * NT <= N) {
 #pragma unroll
             for (int mi = 0; mi < MC; mi++)
-                if (m0 + rbase + mi * 32 + 32 <= M)
+                if (RC ? __ballot(gidv[mi] < 0) == 0 : m0 + rbase + mi * 32 + 32 <= M) // (RC: a block without padding rows)
                     vm += 4 * NT;
         }
     };
