@@ -147,7 +147,8 @@ struct StreamK {
     float *part = nullptr;
     int *cnt = nullptr;
 };
-constexpr int GNNB_DEG_CLASSES = 15; // in-degrees 1 .. 15 (0 counts as 1: PNA clamps) get a class each; a larger promise keeps the general form
+constexpr int GNNB_DEG_CLASSES = 16; // in-degrees 0 .. 15 get a class each (0: PNA's scalers of degree 1, but no messages); a larger promise keeps the general form
+constexpr int GNNB_DEG_MAX = GNNB_DEG_CLASSES - 1;
 // the batch's rows sorted into degree classes (k_misc.hip); work = 256 x 16 ints, perm = max_tiles * 128, tile_cls = max_tiles
 hipError_t launch_degree_classes(const BatchTables &t, int promise, int32_t *work, int32_t *perm, int32_t *tile_cls, int max_tiles,
                                  hipStream_t s);
@@ -157,6 +158,7 @@ struct RowClasses {
     const int32_t *perm = nullptr;
     const int32_t *tile_cls = nullptr;
     long w_stride = 0;
+    int bias_stride = 0; // floats between the classes' biases (0: one bias)
 };
 // pe != nullptr: y is not written; returns hipErrorNotSupported (nothing launched) when the GEMM shape has no pooling
 // epilogue -- the caller then runs the plain GEMM + a pooling pass

@@ -174,6 +174,7 @@ struct gnnb_workspace {
     int max_degree = 0;      // caller's promise on the in-degree (0 = none): gnnb_workspace_set_max_degree
     // PNA degree classes of the prepared batch (launch_degree_classes): valid when deg_ready; deg_delta = the delta it was prepared with
     int32_t *deg_work = nullptr, *deg_perm = nullptr, *deg_tile_cls = nullptr;
+    float *zero_q = nullptr; // [max_nodes, maxw] zeros (never written): the destination term of PNA's aggregate in the degree-class form
     int deg_max_tiles = 0;
     bool deg_ready = false;
     float deg_delta = 0.0f;
@@ -384,25 +385,49 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
                 }
                 conv_off[l].push_back(push(wm.data(), wm.size()));
                 conv_off[l].push_back(push(bm.data(), bm.size()));
-                // slot 8: the degree-class form (gnnb_workspace_set_max_degree): for d = 1 .. GNNB_DEG_CLASSES the matrix
-                // (W'_x | W'_1 + amp(d) W'_2 + att(d) W'_3), [out, 5 F] each, of the folded W' above; amp / att as graph prep
-                // computes them (k_prep.hip: logf(d + 1) / delta and its reciprocal)
+                // slots 8, 9: the degree-class form (gnnb_workspace_set_max_degree): for every in-degree c = 0 .. 15 the matrix
+                //   ( W'_x + S_c Wq | W'_1 + amp W'_2 + att W'_3 ),  [out, 5 F],   and the bias  b' + S_c bq,
+                // of the folded W' above; amp / att as graph prep computes them (k_prep.hip: logf(d + 1) / delta and its
+                // reciprocal, d = max(c, 1)).  S_c = the max + min + mean column blocks of the class's A matrix: the
+                // destination's own pre-NN term q_i = Wq x_i + bq shifts max, min and mean of its messages by q_i and
+                // leaves std alone (gnn_builder_lib.h:1801-1850), so it is folded into x's weights too and the q GEMM is
+                // not run at all.  Class 0 (no messages: the four aggregates are 0, not q) carries no S term.
                 if (fi % 32 == 0 && fo > 64) {
                     const size_t K5 = 5 * fi;
-                    std::vector<float> wc((size_t)GNNB_DEG_CLASSES * fo * K5);
-                    for (int dg = 1; dg <= GNNB_DEG_CLASSES; dg++) {
-                        const float lg = logf((float)dg + 1.0f);
+                    std::vector<float> wc((size_t)GNNB_DEG_CLASSES * fo * K5), bc((size_t)GNNB_DEG_CLASSES * fo);
+                    std::vector<double> wa(4 * fi), sq(fi);
+                    const float *wq = p[0]; // W_pre [F, 2F]: columns [0, F) act on the destination x_i (lib:1801-1802), bias p[1]
+                    for (int c = 0; c < GNNB_DEG_CLASSES; c++) {
+                        const float lg = logf((float)std::max(c, 1) + 1.0f);
                         const double amp = (double)(lg / d.pna_delta), att = (double)(d.pna_delta / lg);
-                        float *dst = &wc[(size_t)(dg - 1) * fo * K5];
+                        float *dst = &wc[(size_t)c * fo * K5];
                         for (size_t o = 0; o < fo; o++) {
                             const float *src = &wm[o * K13];
-                            for (size_t k = 0; k < fi; k++)
-                                dst[o * K5 + k] = src[k];
                             for (size_t k = 0; k < 4 * fi; k++)
-                                dst[o * K5 + fi + k] = (float)((double)src[fi + k] + amp * (double)src[5 * fi + k] + att * (double)src[9 * fi + k]);
+                                wa[k] = (double)src[fi + k] + amp * (double)src[5 * fi + k] + att * (double)src[9 * fi + k];
+                            for (size_t k = 0; k < 4 * fi; k++)
+                                dst[o * K5 + fi + k] = (float)wa[k];
+                            double bsum = (double)bm[o];
+                            if (c > 0) {
+                                for (size_t k = 0; k < fi; k++)
+                                    sq[k] = wa[k] + wa[fi + k] + wa[2 * fi + k]; // S_c[o][k]: max + min + mean
+                                for (size_t j = 0; j < fi; j++) {               // (S_c Wq)[o][j] = sum_k S_c[o][k] Wq[k][j]
+                                    double a = (double)src[j];
+                                    for (size_t k = 0; k < fi; k++)
+                                        a += sq[k] * (double)wq[k * 2 * fi + j];
+                                    dst[o * K5 + j] = (float)a;
+                                }
+                                for (size_t k = 0; k < fi; k++)
+                                    bsum += sq[k] * (double)p[1][k];
+                            } else {
+                                for (size_t j = 0; j < fi; j++)
+                                    dst[o * K5 + j] = src[j];
+                            }
+                            bc[(size_t)c * fo + o] = (float)bsum;
                         }
                     }
                     conv_off[l].push_back(push(wc.data(), wc.size()));
+                    conv_off[l].push_back(push(bc.data(), bc.size()));
                 }
             }
             break;
@@ -562,6 +587,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
                  o_dwork = carve(d.conv_type == GNNB_CONV_PNA ? 1024 * 16 * 4 : 0),
                  o_dperm = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 128 * 4 : 0),
                  o_dcls = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 4 : 0),
+                 o_zq = carve(d.conv_type == GNNB_CONV_PNA ? N * (size_t)maxw * 4 : 0),
                  o_ngraph = carve(pool_epi ? N * 4 : 0), o_part = carve(pool_epi ? ((N + 31) / 32) * 2 * (size_t)gnn_out_width(d) * 8 : 0),
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
                  o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
@@ -595,6 +621,11 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
         ws->deg_work = (int32_t *)(b + o_dwork);
         ws->deg_perm = (int32_t *)(b + o_dperm);
         ws->deg_tile_cls = (int32_t *)(b + o_dcls);
+        ws->zero_q = (float *)(b + o_zq);
+        if (hipMemset(ws->zero_q, 0, N * (size_t)maxw * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            ws->zero_q = nullptr; // (the degree-class form is then not taken)
+        }
     }
     ws->pool_part = pool_epi ? (float2 *)(b + o_part) : nullptr;
     ws->act[0] = (float *)(b + o_a0);
@@ -754,7 +785,7 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     ws->gcoef_ready = false;
     // PNA under a degree promise: the rows sorted into degree classes, right behind the tables on the prep stream
     ws->deg_ready = false;
-    if (ws->desc.conv_type == GNNB_CONV_PNA && ws->max_degree > 0 && ws->max_degree <= GNNB_DEG_CLASSES && options().pna_classes &&
+    if (ws->desc.conv_type == GNNB_CONV_PNA && ws->max_degree > 0 && ws->max_degree <= GNNB_DEG_MAX && options().pna_classes &&
         ws->deg_perm && ws->large_g < 0 && ws->desc.fpx_w <= 0) {
         ws->deg_max_tiles = (num_nodes + 127) / 128 + GNNB_DEG_CLASSES;
         GNNB_HIP_TRY(launch_degree_classes(t, ws->max_degree, ws->deg_work, ws->deg_perm, ws->deg_tile_cls, ws->deg_max_tiles,
@@ -1144,19 +1175,22 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
         case GNNB_CONV_PNA: {
             // h_ij = Wpre [x_i || x_j] + b  ==  (Wpre[:, :F] x_i + b) + Wpre[:, F:] x_j
             float *q = ws->tmp0, *pp = ws->tmp1;
-            if ((rc = linear1(R(cur, fi), fi, fi, p[0], 2 * fi, p[1], nullptr, Rw(q, fi), M, fi, GNNB_ACT_NONE, stream)))
+            // degree-class form (gnnb_workspace_set_max_degree; decided here: it folds the destination's pre-NN term into x's
+            // class weights, so q is not computed and the aggregate takes zeros in its place)
+            const bool classes = p.size() >= 10 && options().pna_fold_lin && options().pna_classes && whole && ws->deg_ready && !fpx &&
+                                 ws->deg_delta == model->desc.pna_delta && fi % 32 == 0 && fo > 64 && options().gemm_dma && ws->zero_q;
+            if (!classes && (rc = linear1(R(cur, fi), fi, fi, p[0], 2 * fi, p[1], nullptr, Rw(q, fi), M, fi, GNNB_ACT_NONE, stream)))
                 return rc;
             if ((rc = linear1(R(cur, fi), fi, fi, p[0] + fi, 2 * fi, nullptr, nullptr, Rw(pp, fi), M, fi, GNNB_ACT_NONE, stream)))
                 return rc;
-            if ((rc = aggregate(GNNB_AGG_PNA, pp, q, ws->agg, fi, 0.f)))
+            if ((rc = aggregate(GNNB_AGG_PNA, pp, classes ? ws->zero_q : q, ws->agg, fi, 0.f)))
                 return rc;
             // [x | A | amp.A | att.A] . Wpost^T without materialising the 13F concat
             gnnb_gemm_seg segs[4] = {{R(cur, fi), nullptr, fi, fi},
                                      {R(ws->agg, 4 * fi), nullptr, 4 * fi, 4 * fi},
                                      {R(ws->agg, 4 * fi), ws->t.amp + row_lo, 4 * fi, 4 * fi},
                                      {R(ws->agg, 4 * fi), ws->t.att + row_lo, 4 * fi, 4 * fi}};
-            if (p.size() >= 9 && options().pna_fold_lin && options().pna_classes && whole && ws->deg_ready && !fpx &&
-                ws->deg_delta == model->desc.pna_delta && fi % 32 == 0) {
+            if (classes) {
                 // degree-class form (gnnb_workspace_set_max_degree): [x | A] . W_class^T over the class-sorted rows, written to
                 // the rows' own places; skip + activation in the epilogue (the last layer pools in the pass behind)
                 gnnb_gemm_seg s2[2] = {{cur, nullptr, fi, fi}, {ws->agg, nullptr, 4 * fi, 4 * fi}};
@@ -1167,12 +1201,13 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
                 rcl.perm = ws->deg_perm;
                 rcl.tile_cls = ws->deg_tile_cls;
                 rcl.w_stride = (long)fo * 5 * fi;
-                hipError_t he = launch_linear(g, p[8], 5 * fi, p[7], skip_fold ? nullptr : skip, nxt, ws->deg_max_tiles * 128, fo, d.activation,
+                rcl.bias_stride = fo;
+                hipError_t he = launch_linear(g, p[8], 5 * fi, p[9], skip_fold ? nullptr : skip, nxt, ws->deg_max_tiles * 128, fo, d.activation,
                                               (hipStream_t)stream, nullptr, &rcl);
                 if (he == hipSuccess)
                     break;
-                if (he != hipErrorNotSupported)
-                    return fail(GNNB_ERR_HIP, "degree-class GEMM launch failed: %s", hipGetErrorString(he));
+                // (no way back from here: the aggregate above ran without the destination term)
+                return fail(GNNB_ERR_HIP, "degree-class GEMM launch failed: %s", hipGetErrorString(he));
             }
             if (p.size() >= 8 && options().pna_fold_lin) {
                 // `lin` folded into the post-NN at upload (gnnb_model_create): one GEMM, skip + activation in its epilogue;

@@ -714,6 +714,10 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         }
 
         // D = W_tile . A_tile^T: lane (li, lh) holds Y[row = m_base + li][col = n_base + 8 (reg >> 2) + 4 lh + (reg & 3)]
+        // (RC: the bias of the tile's class -- rc.bias_stride floats apart, 0: one bias for all)
+        const float *const bias_all = bias;
+        [[maybe_unused]] const float *bias = RC && bias_all ? bias_all + (size_t)__builtin_amdgcn_readfirstlane(rc.tile_cls[min(m0 / DM, tiles_m - 1)]) * rc.bias_stride
+                                                           : bias_all;
         auto epilogue = [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
 #pragma unroll

@@ -30,14 +30,14 @@ hipError_t launch_output_activation(float *out, int num_graphs, int n, int kind,
     return hipGetLastError();
 }
 
-// ---- degree classes (PNA under a degree promise <= GNNB_DEG_CLASSES): the batch's rows sorted by clamp(in-degree, 1) into
+// ---- degree classes (PNA under a degree promise <= GNNB_DEG_CLASSES): the batch's rows sorted by in-degree (0 .. 15) into
 // 128-row tiles of ONE class each, for k_linear_dma's row-class mode (k_gemm.hip).  perm[position] = row (-1: padding),
-// tile_cls[tile] = class - 1.  A STABLE counting sort without atomics (same-address atomics from every wave of the batch
+// tile_cls[tile] = class = in-degree.  A STABLE counting sort without atomics (same-address atomics from every wave of the batch
 // cost 150 us per pass at BASELINE config 4): GNNB_DEG_RUNS waves take one contiguous run of rows each -- count per (run,
 // class) -> one workgroup turns the counts into bases (classes padded to whole tiles, runs in order) -> every wave places its
 // rows in order.  Rows keep their order inside a class, so a tile's rows are near each other in memory.
 static constexpr int GNNB_DEG_RUNS = 256;
-__device__ __forceinline__ int deg_class_of(const int32_t *__restrict__ row_ptr, int v) { return min(max(row_ptr[v + 1] - row_ptr[v], 1), GNNB_DEG_CLASSES) - 1; }
+__device__ __forceinline__ int deg_class_of(const int32_t *__restrict__ row_ptr, int v) { return min(max(row_ptr[v + 1] - row_ptr[v], 0), GNNB_DEG_MAX); }
 
 __global__ __launch_bounds__(WG) void k_deg_count(const int32_t *__restrict__ row_ptr, int N, int promise, int32_t *__restrict__ work,
                                                   int32_t *__restrict__ err, int32_t *__restrict__ err_host)
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(WG) void k_deg_count(const int32_t *__restrict__ ro
         int c = -1;
         if (v < r1) {
             const int d = row_ptr[v + 1] - row_ptr[v];
-            bad |= d > promise || d > GNNB_DEG_CLASSES;
-            c = min(max(d, 1), GNNB_DEG_CLASSES) - 1;
+            bad |= d > promise || d > GNNB_DEG_MAX;
+            c = min(max(d, 0), GNNB_DEG_MAX);
         }
 #pragma unroll
         for (int k = 0; k < GNNB_DEG_CLASSES; k++) {
