@@ -5,7 +5,7 @@ GCN / GIN without a promise -- against the oracle on one GPU.
     python tests/fuzz_layerwise.py [cases] [seed]      (lives under tests/: it uses the oracle, which is test infrastructure)
 Random model shapes (depth 1..4, hidden 16 / 32 / 64 / 128 / 256, out any multiple of 4 up to hidden, F_in 1..32, activation,
 skip, pool order), random batches (molecule-like graphs + empty graphs, isolated nodes, self loops, duplicate edges, hubs,
-a few graphs of 100-400 nodes), every option combination of fuse_pool / pna_fold_lin / first_ring / gemm_tail_split drawn
+a few graphs of 100-400 nodes), PNA with and without a max_degree promise, every option combination of fuse_pool / pna_fold_lin / first_ring / gemm_tail_split drawn
 per case.  Prints the worst error; exits non-zero on a mismatch."""
 import sys
 from pathlib import Path
@@ -46,7 +46,7 @@ try:
             n = 0 if r == 0 else (int(rng.integers(100, 400)) if r == 1 and g % 7 == 0 else int(np.clip(rng.normal(mean_n, mean_n / 3), 1, 60)))
             e = int(rng.integers(0, 3 * n + 1)) if n else 0
             coo = np.stack([rng.integers(0, max(n, 1), e), rng.integers(0, max(n, 1), e)], 1).astype(np.int32) if e else np.zeros((0, 2), np.int32)
-            if n and rng.integers(0, 30) == 0:            # a hub: many edges into one node
+            if n and rng.integers(0, 30) == 0 and it % 3 == 0:   # a hub: many edges into one node (a third of the cases)
                 hub = int(rng.integers(0, n))
                 coo = np.concatenate([coo, np.stack([rng.integers(0, n, 20), np.full(20, hub)], 1).astype(np.int32)])
             graphs.append((rng.uniform(-1, 1, (n, fin)).astype(np.float32), coo))
@@ -58,6 +58,11 @@ try:
             runtime.set_option(k, v)
         ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
         cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1))
+        maxdeg = int(np.bincount(batch.coo[:, 1]).max()) if batch.num_edges else 0
+        promise = 0
+        if conv == "pna" and 0 < maxdeg <= 15 and rng.integers(0, 4) != 0:
+            promise = maxdeg if rng.integers(0, 2) else 15   # (the degree-class form of the post-NN product)
+            cm.set_max_degree(promise)
         args = to_dev(batch, dev)
         got = cm.forward(*args).cpu().numpy()
         cm.check()
@@ -65,7 +70,7 @@ try:
         err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
         worst = max(worst, err)
         tag = (f"{conv} L={L} h={h} out={out} F={fin} {act} skip={int(skip)} pools={'/'.join(pools)} B={B} N={batch.num_nodes} "
-               f"opts={opts} path={cm.last_path()}")
+               f"opts={opts} maxdeg={maxdeg} promise={promise} path={cm.last_path()}")
         if not err < 1e-4 or not np.array_equal(got, again):
             print(f"FAIL case {it}: {tag}: err={err:.3e} repeatable={np.array_equal(got, again)}")
             sys.exit(1)
