@@ -156,9 +156,11 @@ def measure_update_mfma(w, N, dev, iters=100):
                 frac=flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, shape=f"M={N} K={d} N={d}")
 
 
-def measure_segmented_gemm(w, N, dev, iters=50):
+def measure_segmented_gemm(w, N, dev, iters=50, pna_classes=False):
     """The large-K update of the workload's full-width layer as the forward runs it: SAGE [mean | x].[Wl|Wr]^T
-    (2 segments, K = 2d) or PNA [x | A | amp.A | att.A].Wpost^T (4 segments, K = 13d, per-row scalers).
+    (2 segments, K = 2d) or PNA [x | A | amp.A | att.A].Wpost^T (4 segments, K = 13d, per-row scalers) -- under a
+    max_degree promise PNA's degree-class form [x | A].W_class^T (2 segments, K = 5d: the same kernel, the rows taken
+    through the class permutation in the forward, in place here: the row-class mode is reachable through a model only).
     Launches come from Python here (the kernel is > 300 us, the launch cost is ~10 us and overlaps);
     HIP events on the launch stream."""
     import torch
@@ -168,6 +170,10 @@ def measure_segmented_gemm(w, N, dev, iters=50):
     if w["conv"] == "sage":
         segs = [(torch.rand(N, d, device=dev) - 0.5, None), (torch.rand(N, d, device=dev) - 0.5, None)]
         K, what = 2 * d, "SAGE [mean|x].[Wl|Wr]^T, 2 segments"
+    elif pna_classes:
+        segs = [(torch.rand(N, d, device=dev) - 0.5, None), (torch.rand(N, 4 * d, device=dev) - 0.5, None)]
+        K, what = 5 * d, ("PNA degree-class form [x|A].W_class^T, 2 segments (max_degree promise: the 13d-wide product with the "
+                         "degree scalers folded into one weight matrix per in-degree; flops counted at K = 5d)")
     else:
         agg = torch.rand(N, 4 * d, device=dev) - 0.5
         amp, att = torch.rand(N, device=dev) + 0.5, torch.rand(N, device=dev) + 0.5
@@ -807,7 +813,7 @@ def main():
             # layer-wise workloads with a wide concatenated update: the large-K segmented GEMM dominates the step
             result["roofline"] = dict(kernel="k_linear_dma (fp32 MFMA 32x32x2, chunks global -> LDS by DMA)", bound="mfma",
                                       peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", traffic=None,
-                                      **measure_segmented_gemm(w, batches[0].num_nodes, dev))
+                                      **measure_segmented_gemm(w, batches[0].num_nodes, dev, pna_classes=bool(max_degree)))
         elif w["conv"] == "gin":
             result["roofline"] = upd
         else:
