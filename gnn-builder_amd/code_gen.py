@@ -82,6 +82,7 @@ class Project:
         n_jobs: int = 1,
         cosim_wave_debug: bool = False,
         arch: str = "gfx950",
+        max_degree: Optional[int] = None,
     ):
         self.model = model
         self.dataset = dataset
@@ -91,6 +92,21 @@ class Project:
         self.num_nodes_guess = self.max_nodes if num_nodes_guess is None else num_nodes_guess
         self.num_edges_guess = self.max_edges if num_edges_guess is None else num_edges_guess
         self.degree_guess = self.max_nodes if degree_guess is None else degree_guess
+        # (MI355X backend only, beside the reference's arguments) a BOUND on the in-degree of every node the generated design
+        # will see -- unlike `degree_guess`, which only sizes HLS loop trip counts (reference code_gen.py:63-82) --, passed to
+        # the runtime as a promise that is validated on the device (gnnb_workspace_set_max_degree): with a bound <= 15 PNA
+        # layers run their post-NN product in degree classes.  None: taken from `dataset` when one is given, else no promise.
+        self.max_degree = max_degree
+        if self.max_degree is None and dataset is not None:
+            try:
+                md = 0
+                for data in dataset:
+                    ei = data.edge_index
+                    if ei.numel():
+                        md = max(md, int(ei[1].bincount().max()))
+                self.max_degree = md
+            except Exception:
+                self.max_degree = None
 
         self.pyg_output_encoding = pyg_output_encoding
         valid_output_encodings = ["regression", "classification_integer", "classification_onehot"]
@@ -173,6 +189,7 @@ class Project:
             "NAME": self.name.upper(),
             "model_top_name": self.name,
             "max_nodes": self.max_nodes,
+            "max_degree": int(self.max_degree or 0),
             "max_edges": self.max_edges,
             "in_dim": self.model.input_node_features_dim,
             "out_dim": self.model.output_features_dim,
