@@ -584,7 +584,7 @@ def main():
     # promise on the largest graph (validated on the device by every graph prep): lets molecule-sized
     # graphs be staged whole in LDS (fused conv stack)
     max_graph = int(max(np.diff(b.node_ptr)[:(sg[0] if sg else b.num_graphs)].max() for b, sg in zip(batches, segs)))
-    # PNA: promise on the largest in-degree too (the reference's degree_guess; validated on the device): molecules stay far
+    # PNA: promise on the largest in-degree too (a bound where the reference's degree_guess is a hint; validated on the device): molecules stay far
     # below the 15 up to which the degree-class form of the post-NN product applies (gnnb_workspace_set_max_degree)
     max_degree = 0
     if w["conv"] == "pna" and not os.environ.get("GNNB_BENCH_NO_DEGREE_PROMISE"):

@@ -262,7 +262,7 @@ class CompiledModel:
         _check(self.lib.gnnb_workspace_set_max_graph_nodes(self._ws, int(n)))
 
     def set_max_degree(self, d: int) -> None:
-        """Promise on the largest in-degree of the following batches (0 = none; the reference's ``degree_guess``): PNA models
+        """Promise on the largest in-degree of the following batches (0 = none; a bound, where the reference's ``degree_guess`` is a hint): PNA models
         then run their post-NN products in the degree-class form (d <= 15).  Validated on the device (``check()``)."""
         _check(self.lib.gnnb_workspace_set_max_degree(self._ws, int(d)))
 

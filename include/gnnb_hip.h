@@ -137,8 +137,9 @@ size_t gnnb_workspace_bytes(const gnnb_workspace *ws);
  * gnnb_graph_prep / gnnb_forward_batched on the workspace after a flagged batch has run returns GNNB_ERR_GRAPH
  * (read from a host-mapped word, no synchronisation; best effort -- the check is the authoritative answer). */
 int gnnb_workspace_set_max_graph_nodes(gnnb_workspace *ws, int n);
-/* Promise that no node of the batches run on this workspace has an in-degree above `d` (0 = no promise, the default) -- the
- * reference's per-design degree bound (Project(..., degree_guess, ...), code_gen.py:63-82, its MAX_DEGREE).  PNA's scalers
+/* Promise that no node of the batches run on this workspace has an in-degree above `d` (0 = no promise, the default).  The
+ * reference knows a per-design degree figure only as a hint (Project(..., degree_guess, ...), code_gen.py:63-82: HLS loop trip
+ * counts); here it is a BOUND, checked.  PNA's scalers
  * depend on the in-degree only (amp = log(d + 1) / delta, att = its reciprocal, gnn_builder_lib.h:1857-1875), so under a
  * promise of d <= 15 (molecules: <= 6) a PNA layer's 13 F-wide post-NN product [x | A | amp A | att A] . W^T is evaluated as
  * the 5 F-wide [x | A] . (W_x | W_1 + amp(d) W_2 + att(d) W_3)^T with the rows sorted by degree class and one pre-combined
