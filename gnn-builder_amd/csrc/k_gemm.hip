@@ -21,12 +21,22 @@ namespace gnnb {
 // wide) run as ONE GEMM without materialising the concatenation in HBM: the per-row scaler is
 // applied while the A tile is staged.
 
-template <int NT> // workgroup tile = 128 x (64*NT); wave tile = 64 x (32*NT)
+// RC (round 4): the row-class mode of k_linear_dma (see there) for the shapes that kernel does not take -- PNA's FIRST layer
+// under a degree promise: [x | A] with F = 11, K = 55 --: rows of A and Y through rc.perm, the weight matrix and bias of the
+// 128-row tile's class.  M = the length of the class-sorted space.
+template <int NT, bool RC = false> // workgroup tile = 128 x (64*NT); wave tile = 64 x (32*NT)
 __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restrict__ W, int ldw,
                                                const float *__restrict__ bias,
                                                const float *__restrict__ skip,
-                                               float *__restrict__ Y, int M, int N, int act)
+                                               float *__restrict__ Y, int M, int N, int act, RowClasses rc = RowClasses{})
 {
+    static_assert(BM == 128, "a row-class tile is one workgroup tile");
+    if (RC) {
+        const int cls = __builtin_amdgcn_readfirstlane(rc.tile_cls[blockIdx.x]);
+        W += (size_t)cls * rc.w_stride;
+        if (bias)
+            bias += (size_t)cls * rc.bias_stride;
+    }
     constexpr int BN = 64 * NT;
     constexpr int BROWS = BN / 32; // W-tile staging passes per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -54,6 +64,12 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 
     float4 ra[4], rb[BROWS];
     const int total = g.cpre[g.nseg];
+    int arow[4]; // (RC) the rows this thread stages: the same four in every chunk
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int pos = m0 + r0 + 32 * p;
+        arow[p] = RC ? (pos < M ? rc.perm[pos] : -1) : (pos < M ? pos : -1);
+    }
 
     auto load_chunk = [&](int c) {
         // segment lookup with static indexing only (keeps the kernarg struct out of scratch)
@@ -77,9 +93,9 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
         const int rem = ks - kk;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const int row = m0 + r0 + 32 * p;
+            const int row = arow[p];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < M) {
+            if (row >= 0) {
                 v = load4_guard(ap + (size_t)row * lda + kk, rem, av != 0);
                 if (rs != nullptr) {
                     const float sc = rs[row];
@@ -159,8 +175,9 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
                 const float bv = bias ? bias[colg] : 0.0f;
 #pragma unroll
                 for (int reg = 0; reg < 16; reg++) {
-                    const int rowg = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                    if (rowg < M) {
+                    const int pos = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    const int rowg = RC ? (pos < M ? rc.perm[pos] : -1) : (pos < M ? pos : -1);
+                    if (rowg >= 0) {
                         float v = acc[mi][ni][reg] + bv;
                         if (skip)
                             v += skip[(size_t)rowg * N + colg];
@@ -1665,8 +1682,8 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
 {
     if (M <= 0 || N <= 0)
         return (pep || rcp) ? hipErrorNotSupported : hipSuccess;
-    if (rcp && (pep || !rcp->perm || !rcp->tile_cls || M % DM != 0 || N <= 64 || !options().gemm_dma))
-        return hipErrorNotSupported; // (row classes exist in k_linear_dma's whole-tile form only)
+    if (rcp && (pep || !rcp->perm || !rcp->tile_cls || M % DM != 0 || N <= 64))
+        return hipErrorNotSupported; // (row classes: whole 128-row tiles, k_linear_dma or the generic kernel)
     const RowClasses rc = rcp ? *rcp : RowClasses{};
     const PoolEpilogue pe = pep ? *pep : PoolEpilogue{};
     if (!pep && !rcp) {
@@ -1747,23 +1764,32 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             return hipGetLastError();
         }
     }
-    if (pep || rcp)
+    if (pep)
         return hipErrorNotSupported;
+    if (rcp) { // (row classes outside the DMA kernel's shapes: the generic tiles, one workgroup per class tile)
+        constexpr int NT = 2;
+        const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * 64 * NT * LDS_LD) * 4;
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_linear<NT, true>), lds);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL((k_linear<NT, true>), dim3(M / BM, (N + 127) / 128), dim3(WG), lds, s, g, w, ldw, bias, skip, y, M, N, act, rc);
+        return hipGetLastError();
+    }
     if (N > 64) {
         constexpr int NT = 2;
         const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * 64 * NT * LDS_LD) * 4;
         {
-            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_linear<NT>), lds);
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_linear<NT, false>), lds);
             if (e != hipSuccess)
                 return e;
         }
-        hipLaunchKernelGGL(k_linear<NT>, dim3(gm, (N + 127) / 128), dim3(WG), lds, s, g, w, ldw,
-                           bias, skip, y, M, N, act);
+        hipLaunchKernelGGL((k_linear<NT, false>), dim3(gm, (N + 127) / 128), dim3(WG), lds, s, g, w, ldw,
+                           bias, skip, y, M, N, act, RowClasses{});
     } else {
         constexpr int NT = 1;
         const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * 64 * NT * LDS_LD) * 4;
-        hipLaunchKernelGGL(k_linear<NT>, dim3(gm, 1), dim3(WG), lds, s, g, w, ldw, bias, skip, y, M,
-                           N, act);
+        hipLaunchKernelGGL((k_linear<NT, false>), dim3(gm, 1), dim3(WG), lds, s, g, w, ldw, bias, skip, y, M,
+                           N, act, RowClasses{});
     }
     return hipGetLastError();
 }
