@@ -6,9 +6,9 @@ ROOT = Path(__file__).resolve().parent.parent
 P = ROOT / "profiles"
 NAMES = [("c2", "C2 GCN L2 d128 B4096", "`k_gcn2_zf`"), ("c3", "C3 GIN L3 d128 B4096", "`k_gcn2_fused<GIN>`"),
          ("c3t", "C3t = C3 with the data set's heavy tail", "`k_gcn2_fused<GIN>` (+ large segment)"),
-         ("c4", "C4 PNA L3 d128 B8192", "13F segmented GEMM `k_linear_dma`"), ("c5", "C5 SAGE L2 d256 B8192/GPU", "K=512 GEMM `k_linear_dma`"),
+         ("c4", "C4 PNA L3 d128 B8192 (max_degree promise)", "degree-class GEMM `k_linear_dma` (K = 5F)"), ("c5", "C5 SAGE L2 d256 B8192/GPU", "K=512 GEMM `k_linear_dma`"),
          ("ref6_gcn", "ref6 GCN (6 layers 128→64, MLP 4×64) B4096", "`k_gcn2_fused` (6 layers)"), ("ref6_gin", "ref6 GIN", "`k_gcn2_fused<GIN>` (6 layers)"),
-         ("ref6_sage", "ref6 SAGE", "K=256 GEMM `k_linear_dma`"), ("ref6_pna", "ref6 PNA", "13F GEMM `k_linear_dma`")]
+         ("ref6_sage", "ref6 SAGE", "K=256 GEMM `k_linear_dma`"), ("ref6_pna", "ref6 PNA (max_degree promise)", "degree-class GEMM `k_linear_dma` (K = 5F)")]
 
 
 def fmt(v):
