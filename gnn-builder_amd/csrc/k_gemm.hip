@@ -604,6 +604,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                 char *scr = smem + (size_t)((buf + DNBUF - 1) % DNBUF) * DBUF_B + (size_t)wave * 8192;
                 const int colg = n0 + wcol + lane; // this lane's column in the row walk
                 const bool col_ok = colg < N;
+                const bool any_col = __ballot(col_ok) != 0;
 #pragma unroll
                 for (int mi = 0; mi < MC; mi++) {
                     const int blk0 = m0 + rbase + mi * 32;
@@ -633,6 +634,11 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                     int cur = __builtin_amdgcn_readlane(gid, 1), nrows = 0;
                     bool open_start = cur >= 0 && __builtin_amdgcn_readlane(gid, 0) == cur;
                     auto flush = [&](int g, int n, bool os, bool oe) { // (g, n, os, oe: wave-uniform)
+                        // the stores are COUNTED (wave-uniformly: the instruction issues when any lane has a column): left
+                        // uncounted, the first counted wait of the next tile drained them -- a full write round trip per tile
+                        // with every wave of the workgroup idle (found in the row-class mode: 341 -> 272 us there)
+                        if (g >= 0 && g < pe.num_graphs && any_col)
+                            vm += (!os && !oe) ? pe.np : 1;
                         if (g < 0 || g >= pe.num_graphs || !col_ok)
                             return;
                         if (!os && !oe) {
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                 }
             };
             GNNB_DISPATCH_ACT(act, pool_epi)
-            return; // (the stores above are not counted in `vm`: the next waits are merely stricter)
+            return;
         }
 
         // ---- stream-K run: park the accumulators; the last workgroup at the tile adds the runs up and goes on to the epilogue.
