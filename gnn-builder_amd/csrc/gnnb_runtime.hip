@@ -392,7 +392,7 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
                 // destination's own pre-NN term q_i = Wq x_i + bq shifts max, min and mean of its messages by q_i and
                 // leaves std alone (gnn_builder_lib.h:1801-1850), so it is folded into x's weights too and the q GEMM is
                 // not run at all.  Class 0 (no messages: the four aggregates are 0, not q) carries no S term.
-                if (fo > 64) { // (any input width: whole 32-wide chunks take k_linear_dma's row-class mode, others the generic kernel's)
+                if (fo > 32) { // (any input width: whole 32-wide chunks take k_linear_dma's row-class mode, others the generic kernel's)
                     const size_t K5 = 5 * fi;
                     std::vector<float> wc((size_t)GNNB_DEG_CLASSES * fo * K5), bc((size_t)GNNB_DEG_CLASSES * fo);
                     std::vector<double> wa(4 * fi), sq(fi);
@@ -1178,7 +1178,7 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
             // degree-class form (gnnb_workspace_set_max_degree; decided here: it folds the destination's pre-NN term into x's
             // class weights, so q is not computed and the aggregate takes zeros in its place)
             const bool classes = p.size() >= 10 && options().pna_fold_lin && options().pna_classes && whole && ws->deg_ready && !fpx &&
-                                 ws->deg_delta == model->desc.pna_delta && fo > 64 && ws->zero_q;
+                                 ws->deg_delta == model->desc.pna_delta && fo > 32 && ws->zero_q;
             if (!classes && (rc = linear1(R(cur, fi), fi, fi, p[0], 2 * fi, p[1], nullptr, Rw(q, fi), M, fi, GNNB_ACT_NONE, stream)))
                 return rc;
             if ((rc = linear1(R(cur, fi), fi, fi, p[0] + fi, 2 * fi, nullptr, nullptr, Rw(pp, fi), M, fi, GNNB_ACT_NONE, stream)))

@@ -1688,7 +1688,7 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
 {
     if (M <= 0 || N <= 0)
         return (pep || rcp) ? hipErrorNotSupported : hipSuccess;
-    if (rcp && (pep || !rcp->perm || !rcp->tile_cls || M % DM != 0 || N <= 64))
+    if (rcp && (pep || !rcp->perm || !rcp->tile_cls || M % DM != 0 || N <= 32))
         return hipErrorNotSupported; // (row classes: whole 128-row tiles, k_linear_dma or the generic kernel)
     const RowClasses rc = rcp ? *rcp : RowClasses{};
     const PoolEpilogue pe = pep ? *pep : PoolEpilogue{};

@@ -401,13 +401,15 @@ def test_pna_lin_folded_into_the_post_nn(dev, hidden, out, layers, pools, act, s
 
 @pytest.mark.parametrize("hidden,out,layers,pools,act,skip,fin", [(128, 128, 3, ("add", "mean", "max"), "relu", True, 11), (128, 64, 2, ("max", "add"), "tanh", False, 32),
                                                                   (64, 128, 4, ("mean",), "gelu", True, 64), (128, 96, 1, ("add",), "sigmoid", False, 128),
-                                                                  (32, 128, 3, ("add", "mean", "max"), "relu", True, 32)])
+                                                                  (32, 128, 3, ("add", "mean", "max"), "relu", True, 32),
+                                                                  (128, 48, 3, ("add", "max"), "relu", True, 11), (64, 36, 2, ("mean",), "tanh", False, 20)])
 def test_pna_degree_classes(dev, hidden, out, layers, pools, act, skip, fin):
     """PNA under a max_degree promise (round 4): the 13 F-wide post-NN product as the 5 F-wide [x | A] . W_class^T over rows
     sorted into degree classes (one pre-combined matrix per in-degree 1 .. 15) -- against the general form (no promise),
     against pna_classes = 0, and the oracle, every graph.  Batch: molecules, isolated nodes (degree 0 counts as 1), a node
     of degree exactly the promise, empty graphs, a row count that is no multiple of the tile; layers whose widths do not
-    take the form (F % 32 != 0, out <= 64) run the general one in the same model.  A broken promise is flagged (32)."""
+    take the form (out <= 32) run the general one in the same model; 33 .. 64 output columns and input widths that are no whole
+    32-wide chunks take it through the narrow / generic kernels.  A broken promise is flagged (32)."""
     model = make_model("pna", in_dim=fin, hidden=hidden, out_dim=out, layers=layers, act=act, pools=pools, task_out=2, skip=skip, seed=hidden + layers + fin)
     base = synthetic.make_batch("qm9", 600, seed=9)
     rng = np.random.default_rng(fin)
