@@ -174,7 +174,6 @@ struct gnnb_workspace {
     int max_degree = 0;      // caller's promise on the in-degree (0 = none): gnnb_workspace_set_max_degree
     // PNA degree classes of the prepared batch (launch_degree_classes): valid when deg_ready; deg_delta = the delta it was prepared with
     int32_t *deg_work = nullptr, *deg_perm = nullptr, *deg_tile_cls = nullptr;
-    float *zero_q = nullptr; // [max_nodes, maxw] zeros (never written): the destination term of PNA's aggregate in the degree-class form
     int deg_max_tiles = 0;
     bool deg_ready = false;
     float deg_delta = 0.0f;
@@ -587,7 +586,6 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
                  o_dwork = carve(d.conv_type == GNNB_CONV_PNA ? 1024 * 16 * 4 : 0),
                  o_dperm = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 128 * 4 : 0),
                  o_dcls = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 4 : 0),
-                 o_zq = carve(d.conv_type == GNNB_CONV_PNA ? N * (size_t)maxw * 4 : 0),
                  o_ngraph = carve(pool_epi ? N * 4 : 0), o_part = carve(pool_epi ? ((N + 31) / 32) * 2 * (size_t)gnn_out_width(d) * 8 : 0),
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
                  o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
@@ -621,11 +619,6 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
         ws->deg_work = (int32_t *)(b + o_dwork);
         ws->deg_perm = (int32_t *)(b + o_dperm);
         ws->deg_tile_cls = (int32_t *)(b + o_dcls);
-        ws->zero_q = (float *)(b + o_zq);
-        if (hipMemset(ws->zero_q, 0, N * (size_t)maxw * 4) != hipSuccess) {
-            (void)hipGetLastError();
-            ws->zero_q = nullptr; // (the degree-class form is then not taken)
-        }
     }
     ws->pool_part = pool_epi ? (float2 *)(b + o_part) : nullptr;
     ws->act[0] = (float *)(b + o_a0);
@@ -1176,14 +1169,14 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
             // h_ij = Wpre [x_i || x_j] + b  ==  (Wpre[:, :F] x_i + b) + Wpre[:, F:] x_j
             float *q = ws->tmp0, *pp = ws->tmp1;
             // degree-class form (gnnb_workspace_set_max_degree; decided here: it folds the destination's pre-NN term into x's
-            // class weights, so q is not computed and the aggregate takes zeros in its place)
+            // class weights, so q is not computed and the aggregate runs without a destination term)
             const bool classes = p.size() >= 10 && options().pna_fold_lin && options().pna_classes && whole && ws->deg_ready && !fpx &&
-                                 ws->deg_delta == model->desc.pna_delta && fo > 32 && ws->zero_q;
+                                 ws->deg_delta == model->desc.pna_delta && fo > 32;
             if (!classes && (rc = linear1(R(cur, fi), fi, fi, p[0], 2 * fi, p[1], nullptr, Rw(q, fi), M, fi, GNNB_ACT_NONE, stream)))
                 return rc;
             if ((rc = linear1(R(cur, fi), fi, fi, p[0] + fi, 2 * fi, nullptr, nullptr, Rw(pp, fi), M, fi, GNNB_ACT_NONE, stream)))
                 return rc;
-            if ((rc = aggregate(GNNB_AGG_PNA, pp, classes ? ws->zero_q : q, ws->agg, fi, 0.f)))
+            if ((rc = aggregate(GNNB_AGG_PNA, pp, classes ? nullptr : q, ws->agg, fi, 0.f)))
                 return rc;
             // [x | A | amp.A | att.A] . Wpost^T without materialising the 13F concat
             gnnb_gemm_seg segs[4] = {{R(cur, fi), nullptr, fi, fi},

@@ -123,7 +123,8 @@ struct LdsRow {
         jr[2] = r1.x - nb;
         jr[3] = r1.y - nb;
         if (MODE == GNNB_AGG_PNA)
-            xi = QLDS ? V::load(sq + (size_t)r_ * w + fo) : V::load(selfq + (size_t)node * w + fo);
+            xi = selfq == nullptr ? V::splat(0.0f) // (no destination term: PNA's degree-class form folds it into the post-NN weights)
+                                  : (QLDS ? V::load(sq + (size_t)r_ * w + fo) : V::load(selfq + (size_t)node * w + fo));
         else if (MODE == GNNB_AGG_GCN || MODE == GNNB_AGG_SUM)
             xi = V::load(sx + (size_t)r_ * w + fo);
 #pragma unroll
@@ -274,7 +275,7 @@ __device__ inline void agg_row_direct(int node, const float *__restrict__ x, con
     const float di = (MODE == GNNB_AGG_GCN) ? dinv[node] : 0.0f;
     V xi = V::splat(0.0f);
     if (MODE == GNNB_AGG_PNA)
-        xi = V::load(selfq + (size_t)node * w + fo);
+        xi = selfq == nullptr ? V::splat(0.0f) : V::load(selfq + (size_t)node * w + fo);
     else if (MODE == GNNB_AGG_GCN || MODE == GNNB_AGG_SUM || MODE == GNNB_AGG_COPY)
         xi = V::load(x + (size_t)node * w + fo);
     for (int k = rp0; k < rp0 + deg; k++) {
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
                         dma4_to_lds_u(gx + (size_t)(c + lane) * 4, sb + (size_t)c * 4);
             }
         }
-        if (HASQ) {
+        if (HASQ && selfq != nullptr) {
             const char *gq = reinterpret_cast<const char *>(selfq + (size_t)nb_ * w);
             if (VEC == 4) {
                 for (int c = sw * 1024; c < bytes; c += sn * 1024, ops++)
