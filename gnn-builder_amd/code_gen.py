@@ -95,18 +95,14 @@ class Project:
         # (MI355X backend only, beside the reference's arguments) a BOUND on the in-degree of every node the generated design
         # will see -- unlike `degree_guess`, which only sizes HLS loop trip counts (reference code_gen.py:63-82) --, passed to
         # the runtime as a promise that is validated on the device (gnnb_workspace_set_max_degree): with a bound <= 15 PNA
-        # layers run their post-NN product in degree classes.  None: taken from `dataset` when one is given, else no promise.
+        # layers run their post-NN product in degree classes.  An explicit value is the caller's contract and is emitted as
+        # given.  None: the build-time data set only HINTS (as the reference's degree_guess does) -- when its largest
+        # in-degree is covered by the degree classes (<= 15) the design is generated with the WIDEST class-covered bound, 15,
+        # so that unseen graphs within MAX_NODES / MAX_EDGES whose degrees exceed the build-time maximum (but not 15) are
+        # still accepted; a data set with larger degrees, or none, gives no promise (the general 13F form).
         self.max_degree = max_degree
         if self.max_degree is None and dataset is not None:
-            try:
-                md = 0
-                for data in dataset:
-                    ei = data.edge_index
-                    if ei.numel():
-                        md = max(md, int(ei[1].bincount().max()))
-                self.max_degree = md
-            except Exception:
-                self.max_degree = None
+            self.max_degree = self._degree_bound_from(dataset)
 
         self.pyg_output_encoding = pyg_output_encoding
         valid_output_encodings = ["regression", "classification_integer", "classification_onehot"]
@@ -208,6 +204,24 @@ class Project:
         write_file(self.model_dir / out_name, template_env.get_template(template).render(self.template_dict))
 
     # ------------------------------------------------------------------ emission (reference code_gen.py:201-337)
+    #: in-degrees 0 .. 15 have a class each in the runtime's degree-class form (gnnb_internal.h: GNNB_DEG_MAX)
+    DEGREE_CLASS_MAX = 15
+
+    @classmethod
+    def _degree_bound_from(cls, dataset) -> Optional[int]:
+        """The promise a data set supports: ``DEGREE_CLASS_MAX`` when every in-degree it holds is covered by the degree
+        classes, else None.  Items without an ``edge_index`` tensor (no PyG-style data set) give None."""
+        md = 0
+        for data in dataset:
+            ei = getattr(data, "edge_index", None)
+            if ei is None or not hasattr(ei, "numel"):
+                return None
+            if ei.numel():
+                md = max(md, int(ei[1].bincount().max()))
+                if md > cls.DEGREE_CLASS_MAX:
+                    return None
+        return cls.DEGREE_CLASS_MAX
+
     def gen_hw_model(self):
         """Emit the host shim (``model.h`` / ``model.cpp``) and the model manifest."""
         self._render("model.h.jinja", "model.h")

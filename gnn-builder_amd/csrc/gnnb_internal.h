@@ -141,12 +141,21 @@ struct PoolEpilogue {
     int32_t num_graphs = 0, np = 0, pools[3] = {0, 0, 0};
 };
 // Stream-K tail of k_linear_dma (k_gemm.hip): q chunks per run; part[2 * workgroup + segment][4 waves][64 x 64 lanes]
-// accumulators, cnt[tail tile] arrival counters (zero between launches).  q = 0: off.
+// accumulators, cnt[first workgroup of a shared tile] arrival counters (zero between launches).  q = 0: off.
 struct StreamK {
     int q = 0;
     float *part = nullptr;
     int *cnt = nullptr;
 };
+// a workspace's own stream-K scratch: stream_k_scratch_bytes() of device memory whose counter part (the tail) the owner has
+// zeroed; stream_k_scratch_at(base) names its two pieces.  Handed to launch_linear(..., sk_owned); without one (the
+// standalone gnnb_linear entry) launch_linear keeps a scratch per (device, stream) and never uses it under graph capture.
+size_t stream_k_scratch_bytes();
+StreamK stream_k_scratch_at(void *base);
+hipError_t stream_k_scratch_init(void *base, hipStream_t s); // counters zeroed, guard pattern written (in stream order)
+// diagnostics: 1 = the scratch's counters are all zero and the guard region behind them is whole, 0 = not, -1 = read-back failed.
+// owned == nullptr: the standalone scratch of (current device, s), 1 when there is none yet.  Synchronises s.
+int stream_k_guard_intact(const StreamK *owned, hipStream_t s);
 constexpr int GNNB_DEG_CLASSES = 16; // in-degrees 0 .. 15 get a class each (0: PNA's scalers of degree 1, but no messages); a larger promise keeps the general form
 constexpr int GNNB_DEG_MAX = GNNB_DEG_CLASSES - 1;
 // the batch's rows sorted into degree classes (k_misc.hip); work = 256 x 16 ints, perm = max_tiles * 128, tile_cls = max_tiles
@@ -164,7 +173,7 @@ struct RowClasses {
 // epilogue -- the caller then runs the plain GEMM + a pooling pass
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
                          const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pe = nullptr,
-                         const RowClasses *rc = nullptr);
+                         const RowClasses *rc = nullptr, const StreamK *sk_owned = nullptr);
 // the same narrow-input layer in ring form (k_first.hip): whole graphs staged in LDS once for ALL N <= 256 output columns;
 // F = width of x, K = F or (cat = F) 2 F.  hipErrorNotSupported -> launch_conv_gather's k_linear_reg form
 hipError_t launch_conv_first(const BatchTables &t, int agg_kind, float eps, const float *x, int F, int K, const float *w,

@@ -186,6 +186,7 @@ struct gnnb_workspace {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int device = 0;
     int32_t *err_host = nullptr; // host-mapped word the prep kernel drops "flagged" into (lazy detection, see gnnb_graph_prep)
+    StreamK sk{};            // this workspace's own stream-K scratch (k_linear_dma's large-K tail; part == nullptr: the model has no such GEMM)
     char *stage = nullptr;   // device staging of the host-buffer entry (x | coo | node_ptr | edge_ptr | out), sized for
     size_t stage_bytes = 0;  // the workspace's capacities; allocated by the first gnnb_forward_batched_host call
 };
@@ -558,6 +559,14 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
         aggw = std::max(aggw, d.conv_type == GNNB_CONV_PNA ? 4 * ld.fin : ld.fin);
     }
     tmpw = std::max(tmpw, maxw);
+    // the widest GEMM K of the conv layers: from 1024 on k_linear_dma may cut its tiles along K (stream-K) and needs a scratch,
+    // which belongs to the workspace -- forwards of different workspaces never share one, whatever streams or graphs run them
+    int max_k = 0;
+    for (int l = 0; l < d.num_layers; l++) {
+        const LayerDims ld = layer_dims(d, l);
+        max_k = std::max(max_k, d.conv_type == GNNB_CONV_PNA ? 13 * ld.fin : d.conv_type == GNNB_CONV_SAGE ? 2 * ld.fin : std::max(ld.fin, ld.fout));
+    }
+    const bool want_sk = max_k >= 1024;
     const int pooledw = d.num_pools * gnn_out_width(d);
     const int mlpw = std::max(d.mlp_hidden, d.mlp_out);
     const int min_tile_rows = 4;
@@ -590,7 +599,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
                  o_a0 = carve(N * maxw * 4), o_a1 = carve(N * maxw * 4), o_agg = carve(N * aggw * 4),
                  o_t0 = carve(N * tmpw * 4), o_t1 = carve(N * tmpw * 4),
                  o_pool = carve(B * pooledw * 4), o_m0 = carve(B * mlpw * 4),
-                 o_m1 = carve(B * mlpw * 4);
+                 o_m1 = carve(B * mlpw * 4), o_sk = carve(want_sk ? stream_k_scratch_bytes() : 0);
     ws->bytes = off;
     hipError_t e = hipMalloc((void **)&ws->blob, ws->bytes);
     if (e != hipSuccess) {
@@ -630,6 +639,11 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->mlp[0] = (float *)(b + o_m0);
     ws->mlp[1] = (float *)(b + o_m1);
     (void)hipMemset(ws->t.err, 0, sizeof(int32_t));
+    if (want_sk) {
+        ws->sk = stream_k_scratch_at(b + o_sk);
+        (void)stream_k_scratch_init(b + o_sk, nullptr); // arrival counters zero (as every launch leaves them), guard pattern behind them
+        (void)hipStreamSynchronize(nullptr);
+    }
     // best effort: without the mapped word only gnnb_workspace_check reports a malformed batch
     ws->t.err_host_dev = nullptr;
     if (hipHostMalloc((void **)&ws->err_host, 64, hipHostMallocMapped) == hipSuccess && ws->err_host) {
@@ -783,7 +797,7 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
         ws->deg_max_tiles = (num_nodes + 127) / 128 + GNNB_DEG_CLASSES;
         GNNB_HIP_TRY(launch_degree_classes(t, ws->max_degree, ws->deg_work, ws->deg_perm, ws->deg_tile_cls, ws->deg_max_tiles,
                                            (hipStream_t)stream));
-        ws->deg_ready = true;
+        ws->deg_ready = num_nodes > 0; // (an empty batch has no class tables: launch_degree_classes returns before it writes any)
         ws->deg_delta = pna_delta;
     }
     // The GCN coefficient table (dinv_i dinv_j of the four inline sources; read by every layer-wise GCN aggregate) is
@@ -952,9 +966,9 @@ static int build_gemm(GemmArgs &g, const gnnb_gemm_seg *segs, int num_segs, cons
     return GNNB_OK;
 }
 
-int gnnb_linear(const gnnb_gemm_seg *segs, int num_segs, const float *w_dev, int ldw,
-                const float *bias_dev, const float *skip_dev, float *y_dev, int M, int N, int act,
-                void *stream)
+// sk_owned: the calling workspace's stream-K scratch (nullptr: the standalone entry -- one per (device, stream), never under capture)
+static int linear_segs(const StreamK *sk_owned, const gnnb_gemm_seg *segs, int num_segs, const float *w_dev, int ldw,
+                       const float *bias_dev, const float *skip_dev, float *y_dev, int M, int N, int act, void *stream)
 {
     if (!w_dev || !y_dev || M < 0 || N < 1)
         return fail(GNNB_ERR_INVALID, "bad argument to gnnb_linear");
@@ -964,7 +978,24 @@ int gnnb_linear(const gnnb_gemm_seg *segs, int num_segs, const float *w_dev, int
     int rc = build_gemm(g, segs, num_segs, w_dev, ldw);
     if (rc != GNNB_OK)
         return rc;
-    GNNB_HIP_TRY(launch_linear(g, w_dev, ldw, bias_dev, skip_dev, y_dev, M, N, act, (hipStream_t)stream));
+    GNNB_HIP_TRY(launch_linear(g, w_dev, ldw, bias_dev, skip_dev, y_dev, M, N, act, (hipStream_t)stream, nullptr, nullptr, sk_owned));
+    return GNNB_OK;
+}
+
+int gnnb_linear(const gnnb_gemm_seg *segs, int num_segs, const float *w_dev, int ldw,
+                const float *bias_dev, const float *skip_dev, float *y_dev, int M, int N, int act,
+                void *stream)
+{
+    return linear_segs(nullptr, segs, num_segs, w_dev, ldw, bias_dev, skip_dev, y_dev, M, N, act, stream);
+}
+
+int gnnb_debug_stream_k_guard(gnnb_workspace *ws, void *stream)
+{
+    const int ok = stream_k_guard_intact(ws && ws->sk.part ? &ws->sk : nullptr, (hipStream_t)stream);
+    if (ok < 0)
+        return fail(GNNB_ERR_HIP, "reading the stream-K scratch back failed");
+    if (ok == 0)
+        return fail(GNNB_ERR_INVALID, "stream-K scratch: an arrival counter was left non-zero or the guard region behind the counters was written");
     return GNNB_OK;
 }
 
@@ -1052,6 +1083,16 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
     };
     BatchTables tv = ws->t;
     tv.tile_lo = tile_lo;
+    const StreamK *const sko = ws->sk.part ? &ws->sk : nullptr; // this workspace's stream-K scratch
+    auto gnnb_linear = [&](const gnnb_gemm_seg *segs, int num_segs, const float *w_dev, int ldw, const float *bias_dev, const float *skip_dev,
+                           float *y_dev, int M_, int N_, int act, void *st) -> int {
+        return linear_segs(sko, segs, num_segs, w_dev, ldw, bias_dev, skip_dev, y_dev, M_, N_, act, st);
+    };
+    auto linear1 = [&](const float *a, int lda, int k, const float *w, int ldw, const float *bias, const float *skip_, float *y, int M_, int N_,
+                       int act, void *st) -> int {
+        gnnb_gemm_seg seg = {a, nullptr, lda, k};
+        return linear_segs(sko, &seg, 1, w, ldw, bias, skip_, y, M_, N_, act, st);
+    };
     auto aggregate = [&](int kind, const float *x, const float *selfq, float *out, int w, float eps) -> int {
         if (M <= 0)
             return GNNB_OK;
@@ -1170,7 +1211,7 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
             float *q = ws->tmp0, *pp = ws->tmp1;
             // degree-class form (gnnb_workspace_set_max_degree; decided here: it folds the destination's pre-NN term into x's
             // class weights, so q is not computed and the aggregate runs without a destination term)
-            const bool classes = p.size() >= 10 && options().pna_fold_lin && options().pna_classes && whole && ws->deg_ready && !fpx &&
+            const bool classes = p.size() >= 10 && options().pna_fold_lin && options().pna_classes && whole && ws->deg_ready && M > 0 && !fpx &&
                                  ws->deg_delta == model->desc.pna_delta && fo > 32;
             if (!classes && (rc = linear1(R(cur, fi), fi, fi, p[0], 2 * fi, p[1], nullptr, Rw(q, fi), M, fi, GNNB_ACT_NONE, stream)))
                 return rc;
@@ -1196,7 +1237,7 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
                 rcl.w_stride = (long)fo * 5 * fi;
                 rcl.bias_stride = fo;
                 hipError_t he = launch_linear(g, p[8], 5 * fi, p[9], skip_fold ? nullptr : skip, nxt, ws->deg_max_tiles * 128, fo, d.activation,
-                                              (hipStream_t)stream, nullptr, &rcl);
+                                              (hipStream_t)stream, nullptr, &rcl, sko);
                 if (he == hipSuccess)
                     break;
                 // (no way back from here: the aggregate above ran without the destination term)

@@ -1,5 +1,7 @@
 // k_gemm.hip -- dense update on the fp32 matrix cores: k_linear, k_linear_dma, k_linear_reg, k_linear_wlds
 // Part of libgnnb_hip.so (hand-written gfx950 / CDNA4 kernels of the GNNBuilder hot path); wavefront = 64 lanes.
+#include <vector>
+
 #include "gnnb_device.h"
 
 namespace gnnb {
@@ -246,7 +248,9 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     // their (tile, chunk) space is cut into equal runs of q chunks, one run per workgroup: a partial tile, whole tiles, a
     // partial tile.  A workgroup multiplies its run at full tile width; where it holds only a part of a tile's K it parks the
     // accumulators in sk.part[2 * workgroup + (0: the run's first tile, 1: its last)], and the LAST workgroup to arrive at a
-    // tile (sk.cnt, one counter per tile, reset by that workgroup) adds the parts up IN RUN ORDER and runs the epilogue:
+    // tile (sk.cnt, one counter per SHARED tile, indexed by the first run that touches the tile -- a run begins inside one tile
+    // at most, so the index is unique and < gridDim.x <= SK_MAX_WG whatever the tile count --, reset by that workgroup) adds
+    // the parts up IN RUN ORDER and runs the epilogue:
     // deterministic, one summation order per shape.  The launcher puts ALL tiles into that space when there is at least one
     // whole round of them (split_from = 0: no last round is left), else the tiles of the partial round.
     const int num_tiles = tiles_m * tiles_n;
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
             int *flag = reinterpret_cast<int *>(smem + (size_t)DNBUF * DBUF_B);
             const int w_first = (skt * total) / sk.q, w_last = ((skt + 1) * total - 1) / sk.q;
             if (tid == 0)
-                *flag = __hip_atomic_fetch_add(sk.cnt + skt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = __hip_atomic_fetch_add(sk.cnt + w_first, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const bool last = *flag == w_last - w_first;
             if (!last)
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             acc[mi][ni][i] += theirs[((mi * NT + ni) * 16 + i) * 64];
             }
             if (tid == 0)
-                sk.cnt[skt] = 0; // (nobody else comes to this tile in this launch; the next launch finds it cleared)
+                sk.cnt[w_first] = 0; // (nobody else comes to this tile in this launch; the next launch finds it cleared)
         }
 
         // D = W_tile . A_tile^T: lane (li, lh) holds Y[row = m_base + li][col = n_base + 8 (reg >> 2) + 4 lh + (reg & 3)]
@@ -1637,46 +1641,99 @@ hipError_t launch_pool_combine(const PoolEpilogue &pe, int M, int N, hipStream_t
     return hipGetLastError();
 }
 
-// Stream-K scratch: one per (device, stream) -- launches on one stream run in order and may share it, launches on different
-// streams may not --, allocated at the first GEMM that wants it (never while the stream is being captured into a graph:
-// that launch takes the row slices) and kept for the life of the process.  64 MB of parts + the tile counters.
+// Stream-K scratch: SK_PART_BYTES of parked accumulators + SK_CNT_INTS arrival counters (zero between launches).  A workspace
+// owns its own (stream_k_scratch_create at gnnb_workspace_create, freed with it, handed to launch_linear): forwards of different
+// workspaces -- on any streams, eager or replayed from hipGraphs -- never share one.  The standalone gnnb_linear entry has no
+// workspace: it takes one scratch per (device, stream) from the map below -- launches on one stream run in order and may share
+// it -- allocated at the first GEMM that wants it, and NEVER while the stream is being captured (a captured launch takes the
+// row slices: a graph replayed on another stream, or beside an eager launch, must not carry the shared scratch's address).
 // Tail-only runs (fewer tiles than resident workgroups) for K >= 1024 (32 chunks): measured at C4's 13F GEMM (52 chunks, 1153
 // tiles) 112.5 against 106 TFLOP/s with row slices, at C5's K = 512 (16 chunks: runs of 7) 105 against 108 -- short runs are
 // all pipeline prologue and fix-up.  With every tile in the space (at least one whole round of tiles) a run is tiles * chunks /
 // 512 long, but nearly every tile then pays a fix-up (64 KB parked and read back): at K = 256 (8 chunks, 577 tiles) that took
 // the GEMM from 74 to 54 TFLOP/s, at K = 512 it is a wash, at K = 1664 it is +1.5 % on a 1.13-round shape: K >= 1024 as well.
 static constexpr int SK_MIN_Q = 6, SK_MIN_TOTAL = 32, SK_ALL_MIN_TOTAL = 32, SK_MAX_WG = 512, SK_MAX_STREAMS = 16;
-static bool stream_k_scratch(hipStream_t s, StreamK &out)
+static constexpr size_t SK_PART_BYTES = (size_t)2 * SK_MAX_WG * DM * DN * sizeof(float);
+static constexpr int SK_CNT_INTS = 1024; // the counter of a shared tile is indexed by a workgroup: < grid <= SK_MAX_WG
+static_assert(SK_MAX_WG <= SK_CNT_INTS, "one arrival counter per resident workgroup at least");
+static constexpr size_t SK_GUARD_BYTES = 4096; // behind the counters: a fixed pattern nothing may touch (stream_k_guard_intact)
+static constexpr size_t SK_TAIL_BYTES = (size_t)SK_CNT_INTS * sizeof(int) + SK_GUARD_BYTES;
+size_t stream_k_scratch_bytes() { return SK_PART_BYTES + SK_TAIL_BYTES; }
+hipError_t stream_k_scratch_init(void *base, hipStream_t s)
 {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, StreamK> have;
+    char *p = reinterpret_cast<char *>(base);
+    hipError_t e = hipMemsetAsync(p + SK_PART_BYTES, 0, (size_t)SK_CNT_INTS * sizeof(int), s);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(p + SK_PART_BYTES + (size_t)SK_CNT_INTS * sizeof(int), 0xA5, SK_GUARD_BYTES, s);
+    return e;
+}
+// 1 = counters all zero (no launch in flight on `s`) and the guard pattern whole, 0 = not, -1 = the read-back failed
+static int stream_k_tail_ok(const StreamK &k, hipStream_t s)
+{
+    std::vector<unsigned char> h(SK_TAIL_BYTES);
+    if (hipMemcpyAsync(h.data(), k.cnt, SK_TAIL_BYTES, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return -1;
+    for (size_t i = 0; i < SK_TAIL_BYTES; i++)
+        if (h[i] != (i < (size_t)SK_CNT_INTS * sizeof(int) ? 0x00 : 0xA5))
+            return 0;
+    return 1;
+}
+StreamK stream_k_scratch_at(void *base)
+{
+    StreamK k;
+    k.part = reinterpret_cast<float *>(base);
+    k.cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(base) + SK_PART_BYTES);
+    return k;
+}
+static std::mutex g_sk_mu;
+static std::map<std::pair<int, hipStream_t>, StreamK> g_sk_have;
+int stream_k_guard_intact(const StreamK *owned, hipStream_t s)
+{
+    if (owned && owned->cnt)
+        return stream_k_tail_ok(*owned, s);
+    StreamK k;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(g_sk_mu);
+        auto it = g_sk_have.find(std::make_pair(dev, s));
+        if (it == g_sk_have.end())
+            return 1; // (no scratch yet: nothing to damage)
+        k = it->second;
+    }
+    return stream_k_tail_ok(k, s);
+}
+static bool stream_k_scratch(hipStream_t s, const StreamK *owned, StreamK &out)
+{
+    if (owned && owned->part && owned->cnt) {
+        out = *owned;
+        out.q = 0;
+        return true;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return false;
+    }
+    std::map<std::pair<int, hipStream_t>, StreamK> &have = g_sk_have;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_sk_mu);
     auto it = have.find(std::make_pair(dev, s));
     if (it == have.end()) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-            (void)hipGetLastError();
-            return false;
-        }
         if ((int)have.size() >= SK_MAX_STREAMS)
             return false;
-        StreamK k;
-        const size_t part_b = (size_t)2 * SK_MAX_WG * DM * DN * sizeof(float), cnt_b = 4096;
         char *p = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&p), part_b + cnt_b) != hipSuccess) {
+        if (hipMalloc(reinterpret_cast<void **>(&p), stream_k_scratch_bytes()) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
-        if (hipMemsetAsync(p + part_b, 0, cnt_b, s) != hipSuccess) { // (in stream order, in front of the first launch that counts)
+        if (stream_k_scratch_init(p, s) != hipSuccess) { // (in stream order, in front of the first launch that counts)
             (void)hipGetLastError();
             (void)hipFree(p);
             return false;
         }
-        k.part = reinterpret_cast<float *>(p);
-        k.cnt = reinterpret_cast<int *>(p + part_b);
-        it = have.emplace(std::make_pair(dev, s), k).first;
+        it = have.emplace(std::make_pair(dev, s), stream_k_scratch_at(p)).first;
     }
     out = it->second;
     return true;
@@ -1684,7 +1741,7 @@ static bool stream_k_scratch(hipStream_t s, StreamK &out)
 
 hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float *bias,
                          const float *skip, float *y, int M, int N, int act, hipStream_t s, const PoolEpilogue *pep,
-                         const RowClasses *rcp)
+                         const RowClasses *rcp, const StreamK *sk_owned)
 {
     if (M <= 0 || N <= 0)
         return (pep || rcp) ? hipErrorNotSupported : hipSuccess;
@@ -1731,14 +1788,14 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             const int total = g.cpre[g.nseg], resident = DWGPC * num_cus;
             bool sk_all = false;
             if (options().gemm_tail_split == 2 && rem > 0 && !pep && tiles >= resident && total >= SK_ALL_MIN_TOTAL &&
-                resident <= SK_MAX_WG && (long long)tiles * total < (1ll << 30) && stream_k_scratch(s, sk)) {
+                resident <= SK_MAX_WG && (long long)tiles * total < (1ll << 30) && stream_k_scratch(s, sk_owned, sk)) {
                 // at least one whole round of tiles: EVERY tile goes into the (tile, chunk) space and every resident workgroup
                 // takes one equal run of it (tiles * total / resident chunks: a partial tile, whole tiles, a partial tile) --
                 // there is no last round left; a tile is shared by two workgroups at most
                 sk.q = (int)(((long long)tiles * total + resident - 1) / resident);
                 sk_all = true;
             } else if (options().gemm_tail_split == 2 && rem > 0 && !pep && total >= SK_MIN_TOTAL && resident <= SK_MAX_WG &&
-                       stream_k_scratch(s, sk)) {
+                       (long long)rem * total < (1ll << 30) && stream_k_scratch(s, sk_owned, sk)) {
                 // fewer tiles than resident workgroups or a K too short for the above: equal runs of the last round's space,
                 // at least SK_MIN_Q chunks long (shorter ones are all pipeline prologue)
                 sk.q = std::max((rem * total + resident - 1) / resident, SK_MIN_Q);

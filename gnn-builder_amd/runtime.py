@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
     "gnnb_malloc", "gnnb_free", "gnnb_memcpy_h2d", "gnnb_memcpy_d2h", "gnnb_set_option",
     "gnnb_aggregate_timed", "gnnb_linear_timed", "gnnb_gcn_stack_timed",
-    "gnnb_aggregate_edges", "gnnb_edge_index_table_to_host",
+    "gnnb_aggregate_edges", "gnnb_edge_index_table_to_host", "gnnb_debug_stream_k_guard",
 ]
 
 
@@ -147,6 +147,7 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
                                           C.POINTER(C.c_float)]
         lib.gnnb_aggregate_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         lib.gnnb_edge_index_table_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.gnnb_debug_stream_k_guard.argtypes = [C.c_void_p, C.c_void_p]
         lib.gnnb_gcn_stack_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                              C.POINTER(C.c_float)]
         _lib = lib
@@ -265,6 +266,11 @@ class CompiledModel:
         """Promise on the largest in-degree of the following batches (0 = none; a bound, where the reference's ``degree_guess`` is a hint): PNA models
         then run their post-NN products in the degree-class form (d <= 15).  Validated on the device (``check()``)."""
         _check(self.lib.gnnb_workspace_set_max_degree(self._ws, int(d)))
+
+    def stream_k_guard(self, stream=None) -> None:
+        """Diagnostics (``gnnb_debug_stream_k_guard``): raises unless this workspace's stream-K scratch has every arrival
+        counter at zero and an untouched guard region behind the counters.  Synchronises the stream."""
+        _check(self.lib.gnnb_debug_stream_k_guard(self._ws, _stream_ptr(stream)))
 
     def last_path(self) -> str:
         """Which kernels the last forward on this workspace ran: "layerwise", "stack" (k_gcn2_fused) or "stack_zf"
@@ -493,6 +499,11 @@ def linear(segments, weight, bias=None, skip=None, act: str = "none", out=None, 
                            _dptr(skip) if skip is not None else None, _dptr(out), M, N, ACT[act],
                            _stream_ptr(stream)))
     return out
+
+
+def stream_k_guard(stream=None) -> None:
+    """Diagnostics: the standalone ``linear``'s stream-K scratch of (current device, stream) -- counters zero, guard whole."""
+    _check(load_library().gnnb_debug_stream_k_guard(None, _stream_ptr(stream)))
 
 
 def linear_timed(a, weight, bias, out, act: str, iters: int, stream=None) -> float:

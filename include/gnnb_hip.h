@@ -272,6 +272,16 @@ int gnnb_linear(const gnnb_gemm_seg *segs, int num_segs, const float *w_dev, int
                 const float *bias_dev /*[N] or NULL*/, const float *skip_dev /*[M,N] or NULL*/,
                 float *y_dev /*[M,N]*/, int M, int N, int act, void *stream);
 
+/* Diagnostics for the large-K GEMM's stream-K tail (K >= 1024: a tile's K range may be shared by several workgroups, which
+ * park partial sums in a scratch and count their arrivals per shared tile).  The scratch belongs to the WORKSPACE whose
+ * forward launches the GEMM (allocated with it, freed with it: forwards of different workspaces -- on any streams, eager or
+ * replayed from hipGraphs -- never share one); the standalone gnnb_linear has one per (device, stream) and never uses it
+ * while `stream` is being captured (a captured gnnb_linear takes row slices).  This call reads the scratch's arrival
+ * counters and the guard region behind them back: GNNB_OK when every counter is zero (as each launch must leave them) and
+ * the guard is untouched, GNNB_ERR_INVALID otherwise.  ws == NULL: the standalone scratch of (current device, stream).
+ * Synchronises `stream`.  No reference counterpart (gnn_builder_lib.h:808-905 `linear` is one scalar loop per node). */
+int gnnb_debug_stream_k_guard(gnnb_workspace *ws, void *stream);
+
 /* global_{add,mean,max}_pool per graph, concatenated in `pools` order
  * (gnn_builder_lib.h:2709-2803, model.cpp.jinja:440-448): x_dev [N,d] -> out_dev [B, num_pools*d] */
 int gnnb_global_pool(gnnb_workspace *ws, const float *x_dev, int d, const int32_t *pools,

@@ -1265,6 +1265,10 @@ def test_linear_dma_stream_k_tail(dev, M, N, K, segs):
     assert (outs[0][rows].double() - ref).abs().max().item() < 3e-5
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[3])
     assert (outs[0] - outs[2]).abs().max().item() < 2e-5
+    # the arrival counters are indexed by the first workgroup of a shared tile (< 512), never by the tile (1153 here): every
+    # counter back at zero and the guard region behind the 1024 counters untouched (round-4 advisor finding: tile 1025 wrote
+    # past the allocation)
+    runtime.stream_k_guard()
 
 
 @pytest.mark.parametrize("promise,math,zf", [(34, 0, 0), (50, 0, 0), (55, 0, 0), (57, 0, 0), (58, 0, 0), (61, 0, 0), (62, 0, 0),
@@ -1488,31 +1492,89 @@ FULL_SIZE = [
 ]
 
 
-@pytest.mark.parametrize("case", FULL_SIZE, ids=lambda c: c[0])
-def test_full_size_configs_3_4_5(dev, case):
-    """BASELINE configs 3 / 4 / 5 at the per-GPU batch the bench runs (tile tables, grids and the large-K GEMM at
-    M = 104 k / 147 k / 209 k rows): 256 sampled graphs against the oracle at the north-star tolerance, and
-    batch-composition independence (the same graphs in reverse order give the same rows)."""
+def _full_size_check(dev, case, as_bench):
     name, conv, shape, hidden, layers, pools, B = case
     fin, out = synthetic.SHAPES[shape]["f_in"], synthetic.SHAPES[shape]["out"]
     model = make_model(conv, in_dim=fin, hidden=hidden, layers=layers, pools=pools, task_out=out, seed=B + hidden)
     batch = synthetic.make_batch(shape, B, seed=31)
-    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    indeg = np.bincount(batch.coo[:, 1], minlength=batch.num_nodes)
+    promise = int(np.diff(batch.node_ptr).max()) if as_bench else 0
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise)
+    if as_bench and conv == "pna":
+        assert int(indeg.max()) <= 15
+        cm.set_max_degree(int(indeg.max()))                      # bench.py:589-593: the batches' largest in-degree
     out_d = cm.forward(*to_dev(batch, dev)).cpu().numpy()
     cm.check()
+    if conv == "pna":
+        cm.stream_k_guard()                                      # (13F form: 1153 tiles through the stream-K space)
     assert np.isfinite(out_d).all()
     idx = np.sort(np.random.default_rng(B).choice(B, 256, replace=False))
     idx[0], idx[-1] = 0, B - 1                                   # the batch's two ends are always checked
-    big = int(np.argmax(np.diff(batch.node_ptr)))                # and its largest graph
-    idx[1] = big
+    big = int(np.argmax(np.diff(batch.node_ptr)))                # its largest graph
+    hub = int(np.searchsorted(batch.node_ptr, int(np.argmax(indeg)), side="right") - 1)  # the graph of its highest-degree node
+    idx[1], idx[2] = big, hub
+    idx = np.unique(idx)
     sub = pack_graphs([batch.graph(int(g)) for g in idx])
     ref = O.forward_batched(model.spec(), canon(model), sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
     err = np.abs(out_d[idx] - ref).max()
-    assert err < TOL, f"{name}: max err {err:.3e} (|ref| max {np.abs(ref).max():.3e})"
+    assert err < TOL * max(1.0, float(np.abs(ref).max())), f"{name}: max err {err:.3e} (|ref| max {np.abs(ref).max():.3e})"
     order = np.arange(B - 1, -1, -1)
     rev = pack_graphs([batch.graph(int(g)) for g in order])
     out_rev = cm.forward(*to_dev(rev, dev)).cpu().numpy()
+    cm.check()
     assert np.abs(out_rev[::-1] - out_d).max() < 2e-5 * max(1.0, float(np.abs(out_d).max()))
+    return cm, model, batch, out_d
+
+
+@pytest.mark.parametrize("case", FULL_SIZE, ids=lambda c: c[0])
+def test_full_size_configs_3_4_5(dev, case):
+    """BASELINE configs 3 / 4 / 5 at the per-GPU batch the bench runs (tile tables, grids and the large-K GEMM at
+    M = 104 k / 147 k / 209 k rows) WITHOUT any promise -- the general layer-by-layer forms (PNA: the 13F-wide product with
+    its stream-K tail) --: 256 sampled graphs (both ends, the largest graph, the graph of the highest-degree node) against
+    the oracle at the north-star tolerance, and batch-composition independence (the same graphs in reverse order give the
+    same rows)."""
+    _full_size_check(dev, case, as_bench=False)
+
+
+@pytest.mark.parametrize("case", FULL_SIZE, ids=lambda c: c[0])
+def test_full_size_configs_3_4_5_on_the_routes_bench_times(dev, case):
+    """The same three configs set up EXACTLY as bench.py sets them up (bench.py:584-612): the largest graph of the batch as the
+    max_graph_nodes promise and -- PNA -- the batch's largest in-degree as the max_degree promise.  So C4 runs the
+    degree-class form at B = 8192 (rows counting-sorted by in-degree over 147 k rows, 5F-wide k_linear_dma in row-class mode,
+    its partial last round of tiles), C3 the fused GIN stack, C5 the ring-form first layer + the pooling GEMM.  Same sample
+    (both ends, largest graph, highest-degree node's graph) against the oracle, reversed-order independence, and the route is
+    asserted, not assumed."""
+    cm, model, batch, out_d = _full_size_check(dev, case, as_bench=True)
+    assert cm.last_path() == {"c3": "stack", "c4": "layerwise", "c5": "layerwise"}[case[0]]
+    if case[1] == "pna":
+        # the degree-class form is what ran: switching it off changes the rounding (not the mathematics)
+        try:
+            runtime.set_option("pna_classes", 0)
+            gen = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+            out_g = gen.forward(*to_dev(batch, dev)).cpu().numpy()
+        finally:
+            runtime.set_option("pna_classes", 1)
+        diff = np.abs(out_g - out_d).max()
+        assert 0.0 < diff < 5e-5 * max(1.0, float(np.abs(out_d).max()))
+
+
+def test_pna_degree_promise_with_an_empty_batch(dev):
+    """A PNA workspace with a max_degree promise and a batch WITHOUT nodes (graph prep allows it): no class tables are written
+    for such a batch, so the forward must not take the class GEMM over stale tables (round-4 advisor finding).  Every graph's
+    output is the head applied to a pooled row of zeros; the workspace then runs a real batch correctly."""
+    model = make_model("pna", in_dim=11, hidden=128, layers=2, pools=("add", "mean", "max"), task_out=3, seed=5)
+    real = synthetic.make_batch("qm9", 300, seed=2)
+    empty = pack_graphs([(np.zeros((0, 11), np.float32), np.zeros((0, 2), np.int32))] * 5)
+    cm = runtime.CompiledModel.from_model(model, real.num_graphs, real.num_nodes, real.num_edges)
+    cm.set_max_degree(int(np.bincount(real.coo[:, 1]).max()))
+    ref_real = O.forward_batched(model.spec(), canon(model), real.x, real.coo, real.node_ptr, real.edge_ptr)
+    ref_empty = O.forward_batched(model.spec(), canon(model), empty.x, empty.coo, empty.node_ptr, empty.edge_ptr)
+    for _ in range(2):
+        got = cm.forward(*to_dev(real, dev)).cpu().numpy()
+        cm.check()
+        assert np.abs(got - ref_real).max() < TOL * max(1.0, float(np.abs(ref_real).max()))
+        got0 = cm.forward_host(empty.x, empty.coo, empty.node_ptr, empty.edge_ptr)   # (host entry: checks the batch itself)
+        assert got0.shape == (5, 3) and np.abs(got0 - ref_empty).max() < 1e-6
 
 
 def test_full_size_config3_on_the_fused_gin_stack(dev):
