@@ -101,13 +101,15 @@ def build_model(w, seed=0):
 WORKLOAD_AGG = {"gcn": ("gcn", 1), "gin": ("sum", 1), "sage": ("mean", 1), "pna": ("pna", 4)}
 
 
-def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("hbm", "l3_resident"), kind="gcn"):
+def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("hbm", "l3_resident"), kind="gcn", pna_self_term=True):
     """Gather-aggregate of `kind` at `width`, timed with HIP events on the launch stream.  Returns both
     the HBM regime (inputs/outputs rotate over > 256 MiB of distinct buffers) and the regime the
     kernel sees inside the pipeline (same buffers every launch: Infinity-Cache resident).
     Algorithmic bytes as SURVEY.md 8(d): every input row read once + every output row written once (PNA: four output
     matrices -- max, min, mean, std) + CSR + graph ptr; PNA's per-destination term q [N, w] (the x_i half of the pre-NN,
-    which the kernel reads beside the gathered p rows) is reported separately as `extra_read_bytes`."""
+    which the kernel reads beside the gathered p rows) is reported separately as `extra_read_bytes` -- and only when the
+    timed forward reads it: under a max_degree promise the degree-class form folds q into x's class weights and the
+    aggregate runs WITHOUT a destination term (`pna_self_term` False)."""
     import torch
 
     x, coo, nptr, eptr = batch_dev
@@ -119,7 +121,7 @@ def measure_aggregate_roofline(cm, batch_dev, width, dev, iters=200, regimes=("h
     nbuf = max(2, int(np.ceil(320 * 2**20 / per_pair)) + 1)
     ins = [torch.rand(N, width, device=dev) * 2 - 1 for _ in range(nbuf)]
     outs = [torch.empty(N, width * k_out, device=dev) for _ in range(nbuf)]
-    selfq = torch.rand(N, width, device=dev) * 2 - 1 if kind == "pna" else None
+    selfq = torch.rand(N, width, device=dev) * 2 - 1 if kind == "pna" and pna_self_term else None
     res = {}
     for regime, n in (("hbm", nbuf), ("l3_resident", 1)):
         if regime not in regimes:
@@ -332,29 +334,43 @@ def cpu_baseline(model, batches, budget_s=12.0):
     return res
 
 
-def torch_allcores_leg(model, batch, ncpus, budget_s=4.0):
-    """GNNModel.forward (the model definition; the PyG-equivalent op sequence without PyG) on one whole batch,
-    torch's default intra-op thread pool on every core the process may use."""
+def torch_allcores_leg(model, batch, ncpus, budget_s=6.0):
+    """GNNModel.forward (the model definition; the PyG-equivalent op sequence without PyG) on one whole batch on the host's
+    cores.  torch's default pool (one thread per logical CPU) oversubscribes this op mix (index_add / scatter_reduce over
+    ~10^5 short rows are serial or memory-bound; only F.linear scales), so the thread count is SWEPT and the best is
+    reported with its count, every point beside it."""
     import torch
 
-    nthreads = torch.get_num_threads()
+    nthreads0 = torch.get_num_threads()
     x = torch.from_numpy(batch.x)
     ei = torch.from_numpy(np.ascontiguousarray(batch.coo.T).astype(np.int64))
     bv = torch.from_numpy(np.repeat(np.arange(batch.num_graphs), np.diff(batch.node_ptr)).astype(np.int64))
-    with torch.no_grad():
-        model(x, ei, bv)
-        trials, t_spent = [], 0.0
-        while len(trials) < 5 or (t_spent < budget_s and len(trials) < 50):
-            t0 = time.perf_counter()
-            model(x, ei, bv)
-            dt = time.perf_counter() - t0
-            trials.append(dt)
-            t_spent += dt
+    counts = sorted({c for c in (1, 4, 8, 16, 32, 64, nthreads0) if 1 <= c <= max(ncpus, 1)})
+    sweep = {}
+    try:
+        with torch.no_grad():
+            for c in counts:
+                torch.set_num_threads(c)
+                model(x, ei, bv)
+                trials, t_spent = [], 0.0
+                while len(trials) < 3 or (t_spent < budget_s / len(counts) and len(trials) < 30):
+                    t0 = time.perf_counter()
+                    model(x, ei, bv)
+                    dt = time.perf_counter() - t0
+                    trials.append(dt)
+                    t_spent += dt
+                sweep[c] = batch.num_graphs / float(np.median(trials))
+    finally:
+        torch.set_num_threads(nthreads0)
+    best = max(sweep, key=sweep.get)
     return {"torch_allcores_batched": {
-        "value": batch.num_graphs / float(np.median(trials)), "unit": "graphs/s", "cores": ncpus,
-        "torch_threads": nthreads, "trials": len(trials), "graphs_per_call": batch.num_graphs,
-        "protocol": "GNNModel.forward on one whole batch (index_add / scatter_reduce / F.linear), torch's default "
-                    "thread pool, median of the trials"}}
+        "value": sweep[best], "unit": "graphs/s", "cores": ncpus, "torch_threads": best,
+        "thread_sweep_graphs_per_s": {str(k): v for k, v in sweep.items()}, "graphs_per_call": batch.num_graphs,
+        "protocol": "GNNModel.forward on one whole batch (index_add / scatter_reduce / F.linear), torch.set_num_threads swept, "
+                    "median of the trials per count, best count reported",
+        "note": "the batched PyTorch op mix does not scale with threads: the scatter / index_add passes over ~10^5 short rows "
+                "are single-threaded or memory-bound on the host and only the dense F.linear parallelises; the 1-core "
+                "reference-library figure stays `cpu_baseline.value`"}}
 
 
 def torch_1core_leg(model, batch, budget_s=6.0):
@@ -384,6 +400,113 @@ def torch_1core_leg(model, batch, budget_s=6.0):
         "protocol": "GNNModel.forward per graph (bs=1), torch.set_num_threads(1) + sched_setaffinity to one core, "
                     "torch.utils.benchmark.Timer.timeit(5).mean per graph, mean over graphs "
                     "(reference experiments/build_base_benchmarks.py:188-208)"}}
+
+
+# --------------------------------------------------------------------------------------- the timed pipeline
+def workload_promises(w, batches, segs):
+    """The promises the timed forward is set up with (validated on the device by every graph prep): the largest graph of
+    the batches in front of their large segments, and -- PNA -- the largest in-degree when the degree classes cover it."""
+    max_graph = int(max(np.diff(b.node_ptr)[:(sg[0] if sg else b.num_graphs)].max() for b, sg in zip(batches, segs)))
+    max_degree = 0
+    if w["conv"] == "pna" and not os.environ.get("GNNB_BENCH_NO_DEGREE_PROMISE"):
+        max_degree = int(max((np.bincount(b.coo[:, 1]).max() if b.num_edges else 0) for b in batches))
+        if max_degree > 15:
+            max_degree = 0
+    return max_graph, max_degree
+
+
+class Pipeline:
+    """`nstreams` batches in flight on one GPU: one workspace + one HIP stream each; step i = one batched forward (graph
+    prep included) of batch i (mod the rotation) on stream i mod nstreams."""
+
+    def __init__(self, model, batches, segs, nstreams, dev, max_graph, max_degree):
+        import torch
+        from gnnbuilder_amd import runtime
+
+        self.batches, self.segs, self.nstreams = batches, segs, nstreams
+        maxn, maxe, maxb = (max(getattr(b, a) for b in batches) for a in ("num_nodes", "num_edges", "num_graphs"))
+        self.cms = [runtime.CompiledModel.from_model(model, maxb, maxn, maxe, max_graph_nodes=max_graph) for _ in range(nstreams)]
+        if max_degree:
+            for c in self.cms:
+                c.set_max_degree(max_degree)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
+        self.dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr)) for b in batches]
+        self.outs = [torch.empty(b.num_graphs, self.cms[0].out_dim, device=dev) for b in batches]
+        torch.cuda.synchronize()
+
+    def step(self, i):
+        k, j = i % len(self.dev_batches), i % self.nstreams
+        if self.segs[k] is not None:
+            self.cms[j].set_large_segment(*self.segs[k])
+        self.cms[j].forward(*self.dev_batches[k], out=self.outs[k], stream=self.streams[j])
+
+    def check(self):
+        for c, st in zip(self.cms, self.streams):
+            c.check(stream=st)  # device-side batch validation (synchronises)
+
+    def prepare_topology(self):
+        """workspace j keeps batch j prepared (tables + classes): the prep-EXCLUDED rate runs on the same streams"""
+        for j in range(self.nstreams):
+            k = j % len(self.dev_batches)
+            x, coo, nptr, eptr = self.dev_batches[k]
+            if self.segs[k] is not None:
+                self.cms[j].set_large_segment(*self.segs[k])
+            self.cms[j].graph_prep(coo, nptr, eptr, int(x.shape[0]), stream=self.streams[j])
+
+    def step_prepared(self, i):
+        j = i % self.nstreams
+        k = j % len(self.dev_batches)
+        self.cms[j].forward_prepared(self.dev_batches[k][0], out=self.outs[k], stream=self.streams[j])
+
+
+def other_config_leg(name, dev, nstreams, budget_s=1.0):
+    """One of BASELINE's other single-GPU configs, timed the way `value` is (same pipeline, CSR build included, median of
+    the repeats) but briefly: three batches, no CPU leg.  Runs AFTER `value` is computed: the C2 timed region is untouched."""
+    import torch
+    from gnnbuilder_amd import synthetic
+
+    w = WORKLOADS[name]
+    model = build_model(w)
+    batches = [synthetic.make_batch(w["shape"], w["batch"], seed=5000 + i) for i in range(max(3, nstreams))]
+    segs = [None] * len(batches)
+    max_graph, max_degree = workload_promises(w, batches, segs)
+    pipe = Pipeline(model, batches, segs, nstreams, dev, max_graph, max_degree)
+    for i in range(2 * len(batches)):
+        pipe.step(i)
+    pipe.check()
+    # size the region from one probe region, then five repeats of it within the budget
+    def region(k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            pipe.step(i)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    t_probe = region(6) / 6
+    k = int(min(200, max(6, budget_s / 5 / max(t_probe, 1e-6))))
+    times = [region(k) for _ in range(5)]
+    el = float(np.median(times))
+    graphs = float(sum(batches[i % len(batches)].num_graphs for i in range(k)))
+    cm = pipe.cms[0]
+    path = cm.last_path()
+    res = {"workload": w["desc"], "name": name, "value": graphs / el, "unit": "graphs/s", "ms_per_step": el / k * 1e3, "steps": k, "repeats": 5,
+           "value_min": graphs / max(times), "value_max": graphs / min(times),
+           "path": path, "max_graph_nodes_promise": max_graph, "max_degree_promise": max_degree or None,
+           "batches_in_flight": nstreams, "csr_build_in_timed_region": True}
+    if w["conv"] in ("gcn", "gin"):
+        fused = measure_fused_stack(cm, pipe.dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w.get("out_dim", w["hidden"]), len(w["pools"])),
+                                    iters=50, conv=w["conv"], layers=w["layers"])
+        if fused is not None:
+            res["roofline"] = {"kernel": {"stack_zf": "k_gcn2_zf", "stack": "k_gcn2_fused<%s>" % w["conv"].upper()}.get(cm.last_path(), cm.last_path()),
+                               "bound": "mfma", "us_per_launch": fused["us"], "achieved": fused["tflops"], "unit": "TFLOP/s",
+                               "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS}
+    else:
+        g = measure_segmented_gemm(w, batches[0].num_nodes, dev, iters=10, pna_classes=bool(max_degree))
+        res["roofline"] = {"kernel": "k_linear_dma (%s)" % g["what"], "bound": "mfma", "us_per_launch": g["us_per_launch"],
+                           "achieved": g["achieved"], "unit": "TFLOP/s", "frac": g["frac"], "shape": g["shape"]}
+    del pipe
+    torch.cuda.synchronize()
+    return res
 
 
 # --------------------------------------------------------------------------------------- launcher
@@ -483,6 +606,7 @@ def main():
                          "(batching.shard_bounds), one per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the brief c3 / c4 / c5 legs of the default (c2, one GPU) line")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the HBM-regime gather-aggregate loop (for a rocprofv3 run whose kernel average is that loop)")
     ap.add_argument("--dry-launch", action="store_true",
@@ -577,20 +701,12 @@ def main():
         from gnnbuilder_amd.batching import order_large_last
         for i, b in enumerate(batches):
             batches[i], _, segs[i] = order_large_last(b, w["large_limit"])
-    maxn = max(b.num_nodes for b in batches)
-    maxe = max(b.num_edges for b in batches)
-    maxb = max(b.num_graphs for b in batches)
     nstreams = max(1, args.streams)
     # promise on the largest graph (validated on the device by every graph prep): lets molecule-sized
     # graphs be staged whole in LDS (fused conv stack)
-    max_graph = int(max(np.diff(b.node_ptr)[:(sg[0] if sg else b.num_graphs)].max() for b, sg in zip(batches, segs)))
     # PNA: promise on the largest in-degree too (a bound where the reference's degree_guess is a hint; validated on the device): molecules stay far
     # below the 15 up to which the degree-class form of the post-NN product applies (gnnb_workspace_set_max_degree)
-    max_degree = 0
-    if w["conv"] == "pna" and not os.environ.get("GNNB_BENCH_NO_DEGREE_PROMISE"):
-        max_degree = int(max((np.bincount(b.coo[:, 1]).max() if b.num_edges else 0) for b in batches))
-        if max_degree > 15:
-            max_degree = 0
+    max_graph, max_degree = workload_promises(w, batches, segs)
     if dry:
         import torch.nn  # noqa: F401
 
@@ -603,30 +719,15 @@ def main():
             k = i % len(dev_batches)
             with torch.no_grad():
                 outs[k] = model(*dev_batches[k])
-        cms, streams, cm = [], [], None
+        pipe, cm = None, None
     else:
-        cms = [runtime.CompiledModel.from_model(model, maxb, maxn, maxe, max_graph_nodes=max_graph)
-               for _ in range(nstreams)]
-        if max_degree:
-            for c in cms:
-                c.set_max_degree(max_degree)
-        cm = cms[0]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
-        dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in (b.x, b.coo, b.node_ptr, b.edge_ptr)) for b in batches]
-        outs = [torch.empty(b.num_graphs, cm.out_dim, device=dev) for b in batches]
-        torch.cuda.synchronize()
-
-        def step(i):
-            # step i = one batched forward of batch i (mod the rotation) on stream i mod nstreams
-            k = i % len(dev_batches)
-            if segs[k] is not None:
-                cms[i % nstreams].set_large_segment(*segs[k])
-            cms[i % nstreams].forward(*dev_batches[k], out=outs[k], stream=streams[i % nstreams])
+        pipe = Pipeline(model, batches, segs, nstreams, dev, max_graph, max_degree)
+        cm, dev_batches, outs, step = pipe.cms[0], pipe.dev_batches, pipe.outs, pipe.step
 
     for i in range(args.warmup):
         step(i)
-    for c, st in zip(cms, streams):
-        c.check(stream=st)  # device-side batch validation (synchronises)
+    if pipe is not None:
+        pipe.check()  # device-side batch validation (synchronises)
 
     def barrier():
         if world > 1:
@@ -639,13 +740,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # RCCL over xGMI: 8 bytes, latency only
         return float(t.item())
 
-    def timed_region():
+    def timed_region(step_fn=None):
+        step_fn = step_fn or step
         sync()
         barrier()
         sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(i)
+            step_fn(i)
         sync()
         barrier()
         sync()
@@ -674,13 +776,16 @@ def main():
         split_rate = graphs_done / el2
         split_ms = el2 / args.steps * 1e3
 
-    # the prep-excluded rate (topology tables re-used; only features change)
-    ms_noprep = None
+    # the prep-EXCLUDED rate (both side by side): topology tables re-used, only features change.  Same pipeline as
+    # `value` -- the same streams, one prepared batch per workspace, the same K-step region and statistic -- so the two are
+    # comparable; the one-stream figure (a single workspace, forwards back to back) is kept beside it
+    ms_noprep = ms_noprep_1s = None
     if not dry:
+        pipe.prepare_topology()
+        for i in range(max(args.warmup, pipe.nstreams)):
+            pipe.step_prepared(i)
+        ms_noprep = float(np.median([timed_region(pipe.step_prepared) for _ in range(repeats)])) / args.steps * 1e3
         x0, coo0, np0, ep0 = dev_batches[0]
-        if segs[0] is not None:
-            cm.set_large_segment(*segs[0])
-        cm.graph_prep(coo0, np0, ep0, int(x0.shape[0]))
         for _ in range(5):
             cm.forward_prepared(x0, out=outs[0])
         torch.cuda.synchronize()
@@ -689,7 +794,7 @@ def main():
         for _ in range(nprep):
             cm.forward_prepared(x0, out=outs[0])
         torch.cuda.synchronize()
-        ms_noprep = (time.perf_counter() - t1) / nprep * 1e3
+        ms_noprep_1s = (time.perf_counter() - t1) / nprep * 1e3
 
     if world > 1:
         dist.barrier()
@@ -724,6 +829,12 @@ def main():
                     "value_min": graphs_done / max(times), "value_max": graphs_done / min(times),
                     "ms_per_step_all": [t / args.steps * 1e3 for t in times]},
         "ms_per_step_prepared_topology": ms_noprep,
+        "prepared_topology": None if ms_noprep is None else {
+            "ms_per_step": ms_noprep, "value": graphs_done / (ms_noprep * 1e-3 * args.steps), "unit": "graphs/s",
+            "batches_in_flight_per_gpu": nstreams, "ms_per_step_single_stream": ms_noprep_1s,
+            "note": "CSR build EXCLUDED: every workspace keeps one batch's tables prepared, only the features are read anew; "
+                    "same streams / region / statistic as `value` (which includes the CSR build); single_stream = one workspace, "
+                    "forwards back to back on one stream"},
     }
     if segs[0] is not None:
         result["config"]["large_segment"] = {
@@ -773,15 +884,17 @@ def main():
         if wkind != "gcn":
             # the aggregate this workload's layer-by-layer forward actually runs at its full width (SUM / MEAN / PNA with four
             # output matrices), beside the GCN kind the north star names: same batch, same protocol
-            ab, ag = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev, kind=wkind)
+            ab, ag = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev, kind=wkind, pna_self_term=not max_degree)
             gather["workload_kind"] = {
                 "kernel": "k_aggregate_ring<%s> (width %d, %d output matri%s)" % (wkind.upper(), w["hidden"], k_out, "x" if k_out == 1 else "ces"),
                 "bound": "hbm", "achieved": ag["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ag["hbm"]["gbps"] / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": ab, "us_per_launch": ag["hbm"]["us"],
                 "traffic": pmc_traffic("aggregate_%s" % wkind, args.workload, ab),
                 "in_pipeline_l3_resident": ag.get("l3_resident"), "extra_read_bytes": ag.get("extra_read_bytes", 0),
-                "note": "algorithmic bytes per SURVEY 8(d): 4 w N (1 + k_out) + CSR + graph ptr; PNA's per-destination "
-                        "term q [N, w] is read on top (extra_read_bytes) and not counted"}
+                "destination_term": bool(wkind == "pna" and not max_degree),
+                "note": "algorithmic bytes per SURVEY 8(d): 4 w N (1 + k_out) + CSR + graph ptr; PNA WITHOUT a max_degree promise "
+                        "reads its per-destination term q [N, w] on top (extra_read_bytes, not counted); with the promise -- "
+                        "what the timed step runs -- the aggregate takes no destination term"}
         fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w.get("out_dim", w["hidden"]), len(w["pools"])),
                                     conv=w["conv"], layers=w["layers"], seg=segs[0]) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
         upd = dict(kernel="k_linear_wlds (fp32 MFMA, weights in LDS), full-width layer update", bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS,
@@ -799,7 +912,7 @@ def main():
                 "us_per_launch": fused["us"],
                 # the solo launch time against the one-stream prepared forward (NOT against the timed step: with
                 # several batches in flight the stack kernels of consecutive batches overlap their edges)
-                "share_of_single_stream_forward": fused["us"] / (ms_noprep * 1e3),
+                "share_of_single_stream_forward": fused["us"] / (ms_noprep_1s * 1e3),
                 # the same flops against the timed step itself: what the kernel delivers inside the pipeline
                 "in_pipeline": {"us_per_step": step_us, "achieved": fused["flops"] / (step_us * 1e-6) / 1e12,
                                 "frac": fused["flops"] / (step_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
@@ -820,6 +933,17 @@ def main():
             result["roofline"] = gather
         result["roofline_gather_aggregate"] = gather
         result["roofline_update"] = upd
+    if world == 1 and args.workload == "c2" and not args.no_other_configs:
+        # BASELINE's other single-GPU configs, briefly (appended after `value` was computed: the C2 region is untouched)
+        del pipe, cm
+        torch.cuda.synchronize()
+        oc = []
+        for name in ("c3", "c4", "c5"):
+            try:
+                oc.append(other_config_leg(name, dev, nstreams))
+            except Exception as e:  # never lose the bench line to a side leg
+                oc.append({"name": name, "error": repr(e)})
+        result["other_configs"] = oc
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(model, batches)
 

@@ -86,3 +86,16 @@ def test_bench_line_keeps_the_contract(tmp_path):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] == 1
     assert d["value"] > 1e6 and 0.0 < d["roofline"]["frac"] < 1.0
+    # BASELINE's other single-GPU configs ride along (brief legs behind the C2 timed region), each on the route the full-size
+    # parity tests prove (tests/test_hip_parity.py::test_full_size_configs_3_4_5_on_the_routes_bench_times)
+    oc = {o["name"]: o for o in d["other_configs"]}
+    assert sorted(oc) == ["c3", "c4", "c5"]
+    for name, o in oc.items():
+        assert "error" not in o, o
+        for k in ("workload", "value", "ms_per_step", "path", "max_degree_promise", "roofline"):
+            assert k in o, (name, k)
+        assert o["value"] > 1e6 and 0.0 < o["roofline"]["frac"] < 1.0 and "kernel" in o["roofline"]
+    assert oc["c3"]["path"] == "stack" and oc["c4"]["max_degree_promise"] and oc["c4"]["path"] == "layerwise"
+    # CSR-included and CSR-excluded rates on the SAME pipeline
+    pt = d["prepared_topology"]
+    assert pt["batches_in_flight_per_gpu"] == d["config"]["batches_in_flight_per_gpu"] and pt["ms_per_step"] <= d["ms_per_step"] * 1.1
