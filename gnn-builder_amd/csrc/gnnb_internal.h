@@ -94,6 +94,13 @@ struct Options {
     int pna_fold_lin;    // 1 = PNA's `lin` folded into its post-NN at upload: one 13F-wide GEMM per layer (default); 0 = two GEMMs
     int pna_classes;     // 1 = PNA under a max_degree promise <= 15: rows sorted by degree, 5F-wide GEMM with per-class weights (default)
     int fold_skip;       // 1 = GraphSAGE: a middle layer's skip connection folded into the root weights (Wr + I) instead of read as an operand (default)
+    int agg_form;        // gather-aggregate kernel: 0 = LDS ring (k_aggregate_ring), 1 = register gather (k_aggregate_rg: no LDS, no
+                         // barrier; widths 64 / 128 / 256, kinds GCN / SUM / MEAN / SIMPLE / PNA; anything else falls back to the ring),
+                         // 2 = register gather for PNA only.  Default 0: DESIGN 3.2 (a wash at config 2, slower inside config 4's step)
+    int agg_rg_r;        // ... row-instructions in flight per wave and batch (0 = 1)
+    int agg_rg_wgs;      // ... 256-thread workgroups per CU, resident or not (0 = 32 at one row-instruction per batch)
+    int agg_rg_flags;    // ... bit 0: sources past the degree are not loaded (exec-masked; default) instead of aliasing the row itself;
+                         //     bit 1: the run pre-touched line by line (slower); bits 2, 3: ablations (GCN, w = 128, one row-instruction)
 };
 Options &options();
 
@@ -103,6 +110,9 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s);
+// the register-gather form (k_aggregate_rg.hip); hipErrorNotSupported (nothing launched) -> the ring form
+hipError_t launch_aggregate_rg(const BatchTables &t, int kind, const float *x, const float *selfq, float *out, int width,
+                               float eps, hipStream_t s);
 // t.gcoef from t.node_rec / t.dinv: what launch_aggregate(GNNB_AGG_GCN) reads (call once per prepared batch)
 hipError_t launch_gcn_coef(const BatchTables &t, hipStream_t s);
 // workgroups the ring-form gather-aggregate kernel launches on the current device (CUs x agg_ring_wg_per_cu): what graph

@@ -60,7 +60,8 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1)};
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1),
+                        env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1)};
     return o;
 }
 
@@ -231,6 +232,14 @@ int gnnb_set_option(const char *name, int value)
         o.agg_nt_store = value;
     else if (!strcmp(name, "agg_balance") && value >= 0 && value <= 1)
         o.agg_balance = value;
+    else if (!strcmp(name, "agg_form") && value >= 0 && value <= 2)
+        o.agg_form = value;
+    else if (!strcmp(name, "agg_rg_r") && value >= 0 && value <= 4)
+        o.agg_rg_r = value;
+    else if (!strcmp(name, "agg_rg_wgs") && value >= 0 && value <= 64)
+        o.agg_rg_wgs = value;
+    else if (!strcmp(name, "agg_rg_flags") && value >= 0 && value <= 15)
+        o.agg_rg_flags = value;
     else if (!strcmp(name, "fuse_narrow") && value >= 0 && value <= 1)
         o.fuse_narrow = value;
     else if (!strcmp(name, "first_ring") && value >= 0 && value <= 1)

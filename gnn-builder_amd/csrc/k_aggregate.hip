@@ -717,6 +717,16 @@ int aggregate_ring_grid() { return device_cu_count() * std::max(options().agg_ri
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s)
 {
+    // agg_form: 0 = the ring (default), 1 = the register-gather form (k_aggregate_rg.hip) wherever it exists, 2 = that form for PNA
+    // only.  Measured (round 5, same box, HBM regime, us per launch ring / register gather): GCN w = 128 at BASELINE config 2
+    // 15.0-15.3 / 14.7-15.3 (a wash); PNA at config 4 72.7 / 65.0 solo -- but the config-4 STEP is 1.2 % slower with it (844.5
+    // against 835 us: its thousands of short waves take issue slots from the GEMMs of the other batches in flight); MEAN
+    // w = 256 at config 5 80-81 / 81; SUM at config 3 22.2 / 27.4
+    if (options().agg_form == 1 || (options().agg_form == 2 && kind == GNNB_AGG_PNA)) {
+        const hipError_t e = launch_aggregate_rg(t, kind, x, selfq, out, width, eps, s);
+        if (e != hipErrorNotSupported)
+            return e;
+    }
     const bool v4 = (width % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0) &&
                     (selfq == nullptr || ((uintptr_t)selfq & 15) == 0);
 #define GNNB_AGG_CASE(K)                                                                         \

@@ -1558,6 +1558,59 @@ def test_full_size_configs_3_4_5_on_the_routes_bench_times(dev, case):
         assert 0.0 < diff < 5e-5 * max(1.0, float(np.abs(out_d).max()))
 
 
+@pytest.mark.parametrize("width", [64, 128, 256])
+def test_register_gather_aggregate_matches_the_ring(dev, width):
+    """k_aggregate_rg (round 5: no LDS, no barrier; a lane group per destination row, the gather straight into registers) against
+    k_aggregate_ring on every kind and launch depth it takes: same sums in the same order (SUM / MEAN / SIMPLE / PNA bit for
+    bit; GCN within one rounding -- its coefficient products contract differently), on a batch with isolated nodes, hubs of
+    degree > 4 (the CSR tail), empty graphs and a row count that divides by nothing.  Whole models on that form against the
+    oracle: `agg_form` 1 on a layer-wise GCN and on PNA with its destination term."""
+    rng = np.random.default_rng(width)
+    base = synthetic.make_batch("molhiv", 300, seed=4)
+    graphs = [base.graph(g) for g in range(300)]
+    star = (rng.uniform(-1, 1, (20, 9)).astype(np.float32), np.array([[i, 0] for i in range(1, 20)] + [[0, i] for i in range(1, 20)], np.int32))
+    lone = (rng.uniform(-1, 1, (3, 9)).astype(np.float32), np.zeros((0, 2), np.int32))
+    empty = (np.zeros((0, 9), np.float32), np.zeros((0, 2), np.int32))
+    batch = pack_graphs([empty, star] + graphs[:150] + [lone, empty] + graphs[150:] + [star])
+    model = make_model("sage", in_dim=9, hidden=32, layers=1, pools=("add",), task_out=1)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    _, coo, nptr, eptr = to_dev(batch, dev)
+    cm.graph_prep(coo, nptr, eptr, batch.num_nodes)
+    x = torch.rand(batch.num_nodes, width, device=dev) * 2 - 1
+    q = torch.rand(batch.num_nodes, width, device=dev) * 2 - 1
+    try:
+        for kind, st in (("gcn", None), ("sum", None), ("mean", None), ("simple", None), ("pna", q)):
+            runtime.set_option("agg_form", 0)
+            ref = cm.aggregate(kind, x, self_term=st, eps=0.25).clone()
+            for r, wgs, flags in ((1, 0, 1), (1, 3, 0), (2, 0, 1), (2, 5, 0), (3, 0, 1), (4, 2, 0), (1, 64, 1)):
+                runtime.set_option("agg_form", 1)
+                runtime.set_option("agg_rg_r", r)
+                runtime.set_option("agg_rg_wgs", wgs)
+                runtime.set_option("agg_rg_flags", flags)
+                got = cm.aggregate(kind, x, self_term=st, eps=0.25)
+                if kind == "gcn":
+                    assert (got - ref).abs().max().item() < 5e-7, (kind, r, wgs, flags)
+                else:
+                    assert torch.equal(got, ref), (kind, r, wgs, flags)
+    finally:
+        for k, v in (("agg_form", 0), ("agg_rg_r", 0), ("agg_rg_wgs", 0), ("agg_rg_flags", 1)):
+            runtime.set_option(k, v)
+    if width != 128:
+        return
+    try:
+        runtime.set_option("agg_form", 1)
+        for conv in ("gcn", "pna", "sage", "gin"):
+            m = make_model(conv, in_dim=9, hidden=128, layers=3, pools=("add", "mean", "max"), task_out=2, seed=11)
+            ref = O.forward_batched(m.spec(), canon(m), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+            c2 = runtime.CompiledModel.from_model(m, batch.num_graphs, batch.num_nodes, batch.num_edges)
+            got = c2.forward(*to_dev(batch, dev)).cpu().numpy()
+            c2.check()
+            assert c2.last_path() == "layerwise"
+            assert np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max())), conv
+    finally:
+        runtime.set_option("agg_form", 0)
+
+
 def test_pna_degree_promise_with_an_empty_batch(dev):
     """A PNA workspace with a max_degree promise and a batch WITHOUT nodes (graph prep allows it): no class tables are written
     for such a batch, so the forward must not take the class GEMM over stale tables (round-4 advisor finding).  Every graph's
