@@ -94,6 +94,7 @@ struct Options {
     int pna_fold_lin;    // 1 = PNA's `lin` folded into its post-NN at upload: one 13F-wide GEMM per layer (default); 0 = two GEMMs
     int pna_classes;     // 1 = PNA under a max_degree promise <= 15: rows sorted by degree, 5F-wide GEMM with per-class weights (default)
     int fold_skip;       // 1 = GraphSAGE: a middle layer's skip connection folded into the root weights (Wr + I) instead of read as an operand (default)
+    int zf_head;         // 1 = k_gcn2_zf runs the MLP head on the graphs it pooled (conv stack + pooling + head in one launch; default)
     int agg_form;        // gather-aggregate kernel: 0 = LDS ring (k_aggregate_ring), 1 = register gather (k_aggregate_rg: no LDS, no
                          // barrier; widths 64 / 128 / 256, kinds GCN / SUM / MEAN / SIMPLE / PNA; anything else falls back to the ring),
                          // 2 = register gather for PNA only.  Default 0: DESIGN 3.2 (a wash at config 2, slower inside config 4's step)
@@ -122,6 +123,13 @@ int aggregate_ring_grid();
 hipError_t launch_aggregate_edges(const BatchTables &t, const float *x, const float *eterm, float *out, int width,
                                   float eps, hipStream_t s);
 
+// Fused readout: global pooling + the whole MLP head in one launch (16 graphs per workgroup).
+struct HeadArgs {
+    const float *w[8];
+    const float *b[8];
+    int32_t dims[9]; // dims[0] = num_pools * d, dims[i+1] = output width of linear i
+    int32_t nlin;
+};
 struct GemmArgs {
     const float *a[4];
     const float *rs[4];
@@ -191,13 +199,6 @@ hipError_t launch_conv_first(const BatchTables &t, int agg_kind, float eps, cons
 // the pieces of graphs that cross 32-row blocks -> pooled (and zeros for empty graphs); after launch_linear(..., pe)
 hipError_t launch_pool_combine(const PoolEpilogue &pe, int M, int N, hipStream_t s);
 
-// Fused readout: global pooling + the whole MLP head in one launch (16 graphs per workgroup).
-struct HeadArgs {
-    const float *w[8];
-    const float *b[8];
-    int32_t dims[9]; // dims[0] = num_pools * d, dims[i+1] = output width of linear i
-    int32_t nlin;
-};
 // returns hipErrorNotSupported when the head does not fit the fused kernel (caller falls back)
 hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_graphs, int d,
                            const int32_t *pools, int num_pools, const HeadArgs &head, int act,
@@ -224,9 +225,13 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
                              const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const G2Deep &deep = G2Deep{});
 
 // The same stack for exactly two GCN layers in fp32 math, last layer transformed before it is aggregated (k_stack_zf.hip)
+// head != nullptr: the MLP head (activation = `act`) runs inside the kernel too when its shape allows (*head_fused says so):
+// out [B, mlp_out] is then complete and the caller launches no readout for these graphs
 hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                           int h0, const float *w1, const float *b1, int h1, int act,
-                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1_frag_order = nullptr);
+                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1_frag_order = nullptr,
+                          const HeadArgs *head = nullptr, const HeadArgs *head_dev = nullptr, float *head_out = nullptr,
+                          bool *head_fused = nullptr); // (head: host copy for the shape checks; head_dev: the same in device memory, what the kernel reads)
 
 // One GCN / GIN conv layer for node rows [row_lo, N) in the small-footprint form that co-resides with the stack kernels
 // (k_conv_rows.hip: the large segment of a batch).  hipErrorNotSupported: widths beyond 128 or another conv type.

@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1),
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_ZF_HEAD", 0),
                         env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1)};
     return o;
 }
@@ -154,6 +154,8 @@ struct gnnb_model {
     // benchmark model: 128 -> 64, models.py:530-545) is zero-padded to hidden x hidden: its extra output columns are
     // act(0 + 0) and never leave the kernel.  nullptr when the model is no GIN stack the kernel takes.
     const float *gin_w = nullptr, *gin_b = nullptr;
+    HeadArgs *head_dev = nullptr; // the MLP head's {weights, biases, widths} once more in device memory: k_gcn2_zf reads it at the
+                                  // end of a workgroup's life (by value the 42 dwords stayed in scalar registers through its stage loop)
     int device = 0;
 };
 
@@ -191,6 +193,23 @@ struct gnnb_workspace {
     char *stage = nullptr;   // device staging of the host-buffer entry (x | coo | node_ptr | edge_ptr | out), sized for
     size_t stage_bytes = 0;  // the workspace's capacities; allocated by the first gnnb_forward_batched_host call
 };
+
+static HeadArgs model_head_args(const gnnb_model *model)
+{
+    const gnnb_model_desc &d = model->desc;
+    HeadArgs head;
+    memset(&head, 0, sizeof(head));
+    head.nlin = d.mlp_num_linear;
+    for (int i = 0; i < head.nlin && i < 8; i++) {
+        int din, dout;
+        mlp_dims(d, i, &din, &dout);
+        head.w[i] = model->head_w[i];
+        head.b[i] = model->head_b[i];
+        head.dims[i] = din;
+        head.dims[i + 1] = dout;
+    }
+    return head;
+}
 
 // ---------------------------------------------------------------------------------------
 extern "C" {
@@ -232,6 +251,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_nt_store = value;
     else if (!strcmp(name, "agg_balance") && value >= 0 && value <= 1)
         o.agg_balance = value;
+    else if (!strcmp(name, "zf_head") && value >= 0 && value <= 1)
+        o.zf_head = value;
     else if (!strcmp(name, "agg_form") && value >= 0 && value <= 2)
         o.agg_form = value;
     else if (!strcmp(name, "agg_rg_r") && value >= 0 && value <= 4)
@@ -527,6 +548,16 @@ int gnnb_model_create(const gnnb_model_desc *desc, const float *const *host_para
         m->head_w.push_back(m->blob + hw[i]);
         m->head_b.push_back(m->blob + hb[i]);
     }
+    if (d.mlp_num_linear <= 8) { // (best effort: without the device copy the stack kernels leave the head to its own launch)
+        const HeadArgs h = model_head_args(m);
+        if (hipMalloc((void **)&m->head_dev, sizeof(HeadArgs)) != hipSuccess ||
+            hipMemcpy(m->head_dev, &h, sizeof(HeadArgs), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            if (m->head_dev)
+                (void)hipFree(m->head_dev);
+            m->head_dev = nullptr;
+        }
+    }
     *out_model = m;
     return GNNB_OK;
 }
@@ -537,6 +568,8 @@ void gnnb_model_destroy(gnnb_model *model)
         return;
     if (model->blob)
         (void)hipFree(model->blob);
+    if (model->head_dev)
+        (void)hipFree(model->head_dev);
     delete model;
 }
 
@@ -1354,15 +1387,23 @@ static BatchTables small_segment(const gnnb_workspace *ws)
     return t;
 }
 
+// head_out != nullptr: the stack kernel may run the MLP head on the graphs of `t` as well (k_gcn2_zf does when the head's
+// activation is the conv stack's and its shape suits: *head_fused); out rows [0, t.num_graphs) are then complete
 static hipError_t launch_conv_stack(const gnnb_model *model, gnnb_workspace *ws, const BatchTables &t, const float *x_dev,
-                                    const G2Deep &deep, hipStream_t s, int *path)
+                                    const G2Deep &deep, hipStream_t s, int *path, float *head_out = nullptr, bool *head_fused = nullptr)
 {
     const gnnb_model_desc &d = model->desc;
     const int L = d.num_layers;
     hipError_t he = hipErrorNotSupported;
-    if (!deep.gin && L == 2) // two GCN layers, fp32: the transform-first form with 96-row stages (k_stack_zf.hip)
+    if (head_fused)
+        *head_fused = false;
+    if (!deep.gin && L == 2) { // two GCN layers, fp32: the transform-first form with 96-row stages (k_stack_zf.hip)
+        const bool offer = head_out != nullptr && model->head_dev != nullptr && d.mlp_num_linear <= 8 && d.mlp_activation == d.activation;
+        const HeadArgs head = model_head_args(model);
         he = launch_gcn2_zf(t, x_dev, d.in_dim, model->conv[0][0], model->conv[0][1], d.hidden_dim, model->conv[1][0],
-                            model->conv[1][1], d.out_dim, d.activation, d.pools, d.num_pools, ws->pooled, s, model->zf_w1f);
+                            model->conv[1][1], d.out_dim, d.activation, d.pools, d.num_pools, ws->pooled, s, model->zf_w1f,
+                            offer ? &head : nullptr, offer ? model->head_dev : nullptr, offer ? head_out : nullptr, head_fused);
+    }
     *path = GNNB_PATH_STACK_ZF;
     if (he == hipErrorNotSupported) {
         *path = GNNB_PATH_STACK;
@@ -1465,7 +1506,8 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
             }
             forked = hl == hipSuccess;
         }
-        hipError_t he = launch_conv_stack(model, ws, small_segment(ws), x_dev, deep, (hipStream_t)stream, &ws->last_path);
+        bool head_fused = false;
+        hipError_t he = launch_conv_stack(model, ws, small_segment(ws), x_dev, deep, (hipStream_t)stream, &ws->last_path, out_dev, &head_fused);
         if (side_forked)
             GNNB_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ws->ev_join, 0));
         if (he == hipSuccess) {
@@ -1486,31 +1528,26 @@ static int forward_prepared_body(const gnnb_model *model, gnnb_workspace *ws, co
                                                 ws->pooled + (size_t)ws->large_g * d.num_pools * gwl, (hipStream_t)stream));
                 ws->last_path |= GNNB_PATH_LARGE_LAYERWISE;
             }
-            HeadArgs head;
-            memset(&head, 0, sizeof(head));
-            head.nlin = d.mlp_num_linear;
-            for (int i = 0; i < head.nlin; i++) {
-                int din, dout;
-                mlp_dims(d, i, &din, &dout);
-                head.w[i] = model->head_w[i];
-                head.b[i] = model->head_b[i];
-                head.dims[i] = din;
-                head.dims[i + 1] = dout;
-            }
-            he = launch_pool_mlp(nullptr, ws->t.graph_ptr, B, d.out_dim, d.pools, d.num_pools, head, d.mlp_activation,
-                                 out_dev, (hipStream_t)stream, ws->pooled);
+            const HeadArgs head = model_head_args(model);
+            // (the stack kernel ran the head on its own graphs: what is left are the graphs of the large segment, if any)
+            const int hg0 = head_fused ? (seg ? ws->large_g : B) : 0;
+            if (hg0 >= B)
+                return GNNB_OK;
+            const size_t pw = (size_t)d.num_pools * d.out_dim;
+            he = launch_pool_mlp(nullptr, ws->t.graph_ptr + hg0, B - hg0, d.out_dim, d.pools, d.num_pools, head, d.mlp_activation,
+                                 out_dev + (size_t)hg0 * d.mlp_out, (hipStream_t)stream, ws->pooled + (size_t)hg0 * pw);
             if (he == hipSuccess)
                 return GNNB_OK;
             if (he != hipErrorNotSupported)
                 return fail(GNNB_ERR_HIP, "readout launch failed: %s", hipGetErrorString(he));
             // head too large for the fused readout: plain GEMM chain on the pooled matrix
-            const float *h = ws->pooled;
+            const float *h = ws->pooled + (size_t)hg0 * pw;
             for (int i = 0; i < d.mlp_num_linear; i++) {
                 int din, dout;
                 mlp_dims(d, i, &din, &dout);
                 const bool last = (i == d.mlp_num_linear - 1);
-                float *y = last ? out_dev : ws->mlp[i & 1];
-                if ((rc = linear1(h, din, din, model->head_w[i], din, model->head_b[i], nullptr, y, B, dout,
+                float *y = last ? out_dev + (size_t)hg0 * d.mlp_out : ws->mlp[i & 1];
+                if ((rc = linear1(h, din, din, model->head_w[i], din, model->head_b[i], nullptr, y, B - hg0, dout,
                                   last ? GNNB_ACT_NONE : d.mlp_activation, stream)))
                     return rc;
                 h = y;
@@ -1716,7 +1753,9 @@ int gnnb_gcn_stack_timed(const gnnb_model *model, gnnb_workspace *ws, const floa
     if (deep.nl < 2)
         return fail(GNNB_ERR_INVALID, "the fused stack exists for GCN / GIN models of two or more layers");
     hipStream_t s = (hipStream_t)stream;
-    auto launch = [&]() { return launch_conv_stack(model, ws, small_segment(ws), x_dev, deep, s, &ws->last_path); };
+    // (as the forward launches it: with the MLP head inside where k_gcn2_zf takes it; its output goes to a workspace buffer)
+    bool head_fused = false;
+    auto launch = [&]() { return launch_conv_stack(model, ws, small_segment(ws), x_dev, deep, s, &ws->last_path, ws->mlp[0], &head_fused); };
     hipEvent_t e0, e1;
     GNNB_HIP_TRY(hipEventCreate(&e0));
     GNNB_HIP_TRY(hipEventCreate(&e1));

@@ -1,6 +1,7 @@
 // k_readout.hip -- per-graph add / mean / max pooling + MLP head: k_global_pool, k_pool_mlp, k_head_small
 // Part of libgnnb_hip.so (hand-written gfx950 / CDNA4 kernels of the GNNBuilder hot path); wavefront = 64 lanes.
 #include "gnnb_device.h"
+#include "gnnb_head.h"
 
 namespace gnnb {
 
@@ -374,7 +375,6 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_pool_mlp(const float *__restri
 // are shared by all workgroups), only the 16 x width activations between layers live in LDS.
 // One workgroup = 16 graphs; wave w takes the 16-column output slices w, w + 4, ...
 static constexpr int HS_THREADS = 256;
-static constexpr int HS_MAXW = 128; // widest hidden layer this form takes
 
 template <int ACT>
 __global__ __launch_bounds__(HS_THREADS, 5) void k_head_small(const float *__restrict__ pooled, int B, HeadArgs head,
@@ -384,96 +384,20 @@ __global__ __launch_bounds__(HS_THREADS, 5) void k_head_small(const float *__res
     __builtin_amdgcn_s_setprio(GNNB_GUEST_PRIO); // (co-runs with the next batch's conv-stack kernel: see k_graph_prep)
     float *sact = reinterpret_cast<float *>(smem); // [2][16][ldact]: ldact = widest hidden layer + 4 (padded rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lg = lane >> 4;
-    const int g0 = blockIdx.x * 16;
-    const int grow = min(g0 + li, B - 1); // (rows past the batch re-read the last graph and are dropped at the store)
-    int cur = 0;
-#pragma unroll 1
-    for (int l = 0; l < head.nlin; l++) {
-        const int k = head.dims[l], n = head.dims[l + 1];
-        const bool last = (l == head.nlin - 1);
-        const float *__restrict__ W = head.w[l];
-        const float *__restrict__ bias = head.b[l];
-        for (int sl = wave; sl * 16 < n; sl += HS_THREADS / 64) {
-            const int nn = sl * 16 + li;
-            const int nnc = nn < n ? nn : n - 1;
-            const float *wrow = W + (size_t)nnc * k + 4 * lg;
-            const float *arow_g = pooled + (size_t)grow * k + 4 * lg; // layer 0: A straight from the pooled matrix
-            const float *arow_l = sact + (cur * 16 + li) * ldact + 4 * lg; // later layers: from LDS
-            // four accumulator chains over interleaved 16-wide k blocks, 64 k values per step
-            f32x4 accs[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                accs[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            auto loadf = [&](int kb, float4 (&a)[4], float4 (&w)[4]) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int kk = kb + 16 * u; // (+ 4 lg inside the row pointers)
-                    const bool ok = kk + 4 * lg < k; // k % 4 == 0: a float4 is whole or absent
-                    const int kc = ok ? kk : 0;
-                    w[u] = *reinterpret_cast<const float4 *>(wrow + kc);
-                    a[u] = l == 0 ? *reinterpret_cast<const float4 *>(arow_g + kc)
-                                  : *reinterpret_cast<const float4 *>(arow_l + kc);
-                    if (!ok)
-                        a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            };
-            // (no operand double-buffering: the register budget is what lets this kernel share a SIMD with
-            // the conv-stack kernel, and it runs in that kernel's shadow anyway)
-            for (int kb = 0; kb < k; kb += 64) {
-                float4 a[4], w[4];
-                loadf(kb, a, w);
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, w[u].x, accs[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, w[u].y, accs[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, w[u].z, accs[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, w[u].w, accs[u], 0, 0, 0);
-            }
-            // C/D: col = lane&15 (output column nn), row = (lane>>4)*4 + r (graph inside the tile)
-            if (nn < n) {
-                const float bvv = bias ? bias[nn] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int gi = lg * 4 + r;
-                    const float v = (accs[0][r] + accs[1][r]) + (accs[2][r] + accs[3][r]) + bvv;
-                    if (last) {
-                        if (g0 + gi < B)
-                            out[(size_t)(g0 + gi) * n + nn] = v;
-                    } else {
-                        sact[((cur ^ 1) * 16 + gi) * ldact + nn] = act_t<ACT>(v);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
+    // one workgroup = one group of four waves = one tile of 16 graphs (gnnb_head.h)
+    head_small_run<ACT>(pooled, 0, B, head, out, ldact, sact, lane, wave, (int)blockIdx.x, 0, 1, [] { __syncthreads(); });
 }
 
 // hipErrorNotSupported when the head's shape does not suit the small form (caller takes k_pool_mlp)
 static hipError_t launch_head_small(int num_graphs, const HeadArgs &head, int act, float *out, hipStream_t s,
                                     const float *prepooled)
 {
-    if (!prepooled || head.nlin < 1 || head.nlin > 8 || (((uintptr_t)prepooled) & 15))
+    if (!prepooled || (((uintptr_t)prepooled) & 15))
         return hipErrorNotSupported;
-    for (int l = 0; l < head.nlin; l++) {
-        if ((head.dims[l] & 3) || (((uintptr_t)head.w[l]) & 15))
-            return hipErrorNotSupported; // float4 operand fetches
-        if (l > 0 && head.dims[l] > HS_MAXW)
-            return hipErrorNotSupported; // hidden activations live in the fixed LDS tile
-    }
-    int maxw = 4;
-    for (int l = 1; l < head.nlin; l++)
-        maxw = std::max(maxw, (int)head.dims[l]);
-    const int ldact = ((maxw + 3) & ~3) + 4;
-    const size_t lds = (size_t)2 * 16 * ldact * 4;
+    const int ldact = head_small_ldact(head);
+    if (ldact <= 0)
+        return hipErrorNotSupported;
+    const size_t lds = head_small_lds_bytes(ldact);
     const int grid = (num_graphs + 15) / 16;
     auto go = [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;

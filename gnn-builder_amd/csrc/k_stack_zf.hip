@@ -1,6 +1,9 @@
 // k_stack_zf.hip -- 2-layer GCN stack + pooling in one persistent kernel, last layer TRANSFORMED BEFORE it is aggregated
 // Part of libgnnb_hip.so (hand-written gfx950 / CDNA4 kernels of the GNNBuilder hot path); wavefront = 64 lanes.
+#include <cstring>
+
 #include "gnnb_stack.h"
+#include "gnnb_head.h"
 
 namespace gnnb {
 
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_graph, const int32_t *__restrict__ tile_edge,
     const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, int N, int E, const float *__restrict__ W0,
     const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ W1f,
-    const float *__restrict__ b1, int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled
+    const float *__restrict__ b1, int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled,
+    const HeadArgs *__restrict__ head_dev, float *__restrict__ head_out, int head_ldact // head_dev != nullptr: the MLP head runs here too (round 5, below)
 #ifdef GNNB_ZF_ABLATE
     , unsigned long long *dbg_span // [2]: min start / max end wall clock (100 MHz) over the workgroups of this launch
     , int dbg // development only (-DGNNB_ZF_ABLATE): bit 0 skips P1, 1 skips P0', 2 skips M1, 3 skips M0, 4 skips the Z write
@@ -562,6 +566,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     // whichever workgroup is in M1, and the other one's narrow phases cost what their instructions cost.
     __builtin_amdgcn_s_setprio(ZF_PRIO);
     int b = 0;
+    const int hg0 = cur.ga; // the graphs this workgroup pools: [hg0, hg1) -- its stages' ranges are consecutive
+    int hg1 = cur.gb;
     while (cur.ok) {
         // The thread index is re-made OPAQUE every stage and every per-lane quantity is derived from it again
         // (otherwise the compiler hoists dozens of loop-invariant LDS offsets out of the stage loop and spills them)
@@ -966,6 +972,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         // instructions), handed over through LDS
         if (wv == G2_NW - 1)
             publish(plan(nxt.chunk, STAB[tv & 63], STAB[64 + (tv & 63)], STAB[128 + (tv & 63)], tv & 63), tv & 63);
+        hg1 = max(hg1, cur.gb);
         cur = nxt;
         b ^= 1;
         g2_barrier(); // A0 / REC of the next stage complete; everybody is done with Z
@@ -974,6 +981,21 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #ifdef GNNB_PROBE
         nst++;
 #endif
+    }
+    // ---- the MLP head on the graphs this workgroup pooled (round 5: reference compute_mlp_head inside the same top as
+    // compute_gnn_head and compute_global_graph_pooling, templates/model.cpp.jinja:454-530, :737-765).  The pooled rows were
+    // just stored by this workgroup's own P1 waves: every wave drains its stores (they are then in the XCD's L2, which this
+    // CU reads through -- none of these lines can sit in its vector L1: the kernel has not read them), one barrier, then
+    // groups of four waves take tiles of 16 graphs through gnnb_head.h -- weights and pooled rows as MFMA operands from L2,
+    // the 16 x width activations in the (dead) H region.  ~2 us at the end of a workgroup's life instead of a third launch.
+    if (head_dev != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g2_barrier();
+        const HeadArgs &head = *head_dev; // (read HERE, through the scalar cache: nothing of it lives through the stage loop)
+        constexpr int NGRP = NW / 4;
+        float *spart = reinterpret_cast<float *>(H);                 // [NGRP][16][ldact]: the groups' partial tiles of layer 0
+        float *sact = spart + (size_t)NGRP * 16 * head_ldact;       // [2][16][ldact]
+        head_tail_run<ACT, NGRP>(pooled, hg0, hg1, head, head_out, head_ldact, spart, sact, tid, [] { g2_barrier(); });
     }
 #ifdef GNNB_PROBE
     if (lane == 0 && blockIdx.x * NW < 4096) {
@@ -1040,8 +1062,11 @@ extern "C" int gnnb_zf_dbg_spans(unsigned long long *host, int *launches)
 
 hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                           int h0, const float *w1, const float *b1, int h1, int act,
-                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1f)
+                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1f,
+                          const HeadArgs *head_in, const HeadArgs *head_dev_in, float *head_out, bool *head_fused)
 {
+    if (head_fused)
+        *head_fused = false;
     const Options &o = options();
     // (math = 1, the opt-in bf16x6 mode, does not switch this kernel off: its fp32 form is faster than the bf16x6 form of
     // k_gcn2_fused -- 39 vs 43 us at BASELINE config 2 -- and the mode must never be slower than the default)
@@ -1080,6 +1105,18 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
 #define lds lds_req
 #endif
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
+    // the MLP head inside the kernel (the caller offers it when the head's activation is the stack's): the small form's
+    // shape conditions, its input = the pooled row, and its activation tiles (one per group of four waves) inside the H region
+    const HeadArgs *head_dev = nullptr;
+    int head_ldact = 0;
+    if (head_in && head_dev_in && head_out && o.zf_head) {
+        const int ld = head_small_ldact(*head_in);
+        const int groups = zf_wide_shape(f0, t.max_graph_nodes_hint) && kq0 == 1 ? 4 : 2;
+        if (ld > 0 && head_in->nlin >= 2 && head_in->dims[0] == num_pools * h1 && (size_t)(groups + 2) * 16 * ld * 4 <= (size_t)cap * ldh * 4) {
+            head_dev = head_dev_in;
+            head_ldact = ld;
+        }
+    }
     hipError_t rc = hipErrorNotSupported;
     auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
@@ -1122,7 +1159,7 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, f0, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_graph, t.tile_edge, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, t.num_edges, w0, b0, h0, w1, w1f, b1, h1,
-                           p0, p1, p2, num_pools, pooled
+                           p0, p1, p2, num_pools, pooled, head_dev, head_out, head_ldact
 #ifdef GNNB_ZF_ABLATE
                            , zf_dbg_span_slot(), getenv("GNNB_ZF_DBG") ? atoi(getenv("GNNB_ZF_DBG")) : 0
 #endif
@@ -1152,6 +1189,8 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
 #else
     GNNB_DISPATCH_ACT(act, go_q)
 #endif
+    if (rc == hipSuccess && head_fused)
+        *head_fused = head_dev != nullptr;
     return rc;
 }
 #ifdef GNNB_ZF_ABLATE

@@ -1006,6 +1006,60 @@ def test_full_size_config2_fused_path(dev):
         runtime.set_option("zf_shape", 2)
 
 
+@pytest.mark.parametrize("fin,h0,h1,pools,mlp_layers,act,shape", [(11, 128, 128, ("add", "mean", "max"), 2, "relu", 2), (11, 128, 128, ("add", "mean", "max"), 2, "relu", 0),
+                                                                  (9, 64, 32, ("max",), 4, "tanh", 2), (20, 128, 64, ("mean", "add"), 0, "gelu", 2),
+                                                                  (16, 32, 128, ("add", "mean", "max"), 3, "sigmoid", 2)])
+def test_mlp_head_inside_the_gcn_stack_kernel(dev, fin, h0, h1, pools, mlp_layers, act, shape):
+    """`zf_head` 1 (round 5, opt-in): k_gcn2_zf runs the MLP head on the graphs each workgroup pooled -- conv stack + pooling +
+    head in ONE launch, as the reference's top does (model.cpp.jinja:737-765) -- against the default (head as its own launch
+    beside the next batch's stack kernel: measured faster) and the oracle.  Both kernel shapes; a batch whose
+    workgroups own between 0 and ~40 graphs (runs of one-node and empty graphs), a large segment behind the stack (its
+    graphs keep the separate readout), heads of one layer (not fused: same results)."""
+    # (mlp_layers = hidden layers of the head: 0 is a single Linear, which the kernel leaves to the separate readout)
+    model = make_model("gcn", in_dim=fin, hidden=h0, layers=2, out_dim=h1, act=act, pools=pools, task_out=5, seed=fin + h1,
+                       mlp_layers=mlp_layers, mlp_act=act)
+    rng = np.random.default_rng(fin)
+    base = synthetic.make_batch("qm9", 700, seed=8)
+    one = lambda: (rng.uniform(-1, 1, (1, fin)).astype(np.float32), np.zeros((0, 2), np.int32))
+    empty = (np.zeros((0, fin), np.float32), np.zeros((0, 2), np.int32))
+
+    def regraph(g):
+        x, e = base.graph(g)
+        return rng.uniform(-1, 1, (x.shape[0], fin)).astype(np.float32), e
+
+    graphs = [empty] + [regraph(g) for g in range(300)] + [one() for _ in range(90)] + [empty] * 5 + [regraph(g) for g in range(300, 700)] + [empty]
+    batch = pack_graphs(graphs)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    outs = {}
+    try:
+        runtime.set_option("zf_shape", shape)
+        for head in (1, 0):
+            runtime.set_option("zf_head", head)
+            cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)
+            outs[head] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            cm.check()
+            assert cm.last_path() == "stack_zf"
+            again = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            assert np.array_equal(outs[head], again)
+        # a large segment behind the stack: its graphs take the separate readout, the rest the in-kernel one
+        runtime.set_option("zf_head", 1)
+        big = [(rng.uniform(-1, 1, (120, fin)).astype(np.float32), np.stack([np.arange(119), np.arange(1, 120)], 1).astype(np.int32)) for _ in range(3)]
+        from gnnbuilder_amd.batching import order_large_last
+        b2, order, seg = order_large_last(pack_graphs(graphs[:200] + big + graphs[200:400]), 29)
+        ref2 = O.forward_batched(model.spec(), canon(model), b2.x, b2.coo, b2.node_ptr, b2.edge_ptr)
+        cm = runtime.CompiledModel.from_model(model, b2.num_graphs, b2.num_nodes, b2.num_edges, max_graph_nodes=29)
+        cm.set_large_segment(*seg)
+        got2 = cm.forward(*to_dev(b2, dev)).cpu().numpy()
+        cm.check()
+        assert np.abs(got2 - ref2).max() < TOL * max(1.0, float(np.abs(ref2).max()))
+    finally:
+        runtime.set_option("zf_head", 0)
+        runtime.set_option("zf_shape", 2)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(outs[1] - ref).max() < TOL * scale and np.abs(outs[0] - ref).max() < TOL * scale
+    assert np.abs(outs[1] - outs[0]).max() < 2e-5 * scale
+
+
 @pytest.mark.parametrize("conv,promise", [("gcn", 29), ("gcn", 0), ("sage", 0)])
 def test_forward_is_hip_graph_capturable(dev, conv, promise):
     """gnnb_forward_batched does no allocation and no synchronisation, so a caller can capture it
