@@ -94,6 +94,8 @@ struct Options {
     int pna_fold_lin;    // 1 = PNA's `lin` folded into its post-NN at upload: one 13F-wide GEMM per layer (default); 0 = two GEMMs
     int pna_classes;     // 1 = PNA under a max_degree promise <= 15: rows sorted by degree, 5F-wide GEMM with per-class weights (default)
     int fold_skip;       // 1 = GraphSAGE: a middle layer's skip connection folded into the root weights (Wr + I) instead of read as an operand (default)
+    int pna_pagg;        // 1 = a full-width PNA layer under the degree promise + the max_graph_nodes promise: pre-NN product and aggregate in
+                         //     one kernel, p never in HBM (k_pna_pagg; default); 0 = GEMM + k_aggregate_ring<PNA>
     int zf_head;         // 1 = k_gcn2_zf runs the MLP head on the graphs it pooled (conv stack + pooling + head in one launch; default)
     int agg_form;        // gather-aggregate kernel: 0 = LDS ring (k_aggregate_ring), 1 = register gather (k_aggregate_rg: no LDS, no
                          // barrier; widths 64 / 128 / 256, kinds GCN / SUM / MEAN / SIMPLE / PNA; anything else falls back to the ring),
@@ -111,6 +113,9 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s);
+// PNA: out [N, 4F] = max | min | mean | std over every node's sources of p_j = Wb x_j, p kept on chip (k_pna.hip); no destination
+// term (the degree-class form).  hipErrorNotSupported (nothing launched) -> p GEMM + launch_aggregate(GNNB_AGG_PNA)
+hipError_t launch_pna_pagg(const BatchTables &t, const float *x, int F, const float *wb, int ldw, float *out, hipStream_t s);
 // the register-gather form (k_aggregate_rg.hip); hipErrorNotSupported (nothing launched) -> the ring form
 hipError_t launch_aggregate_rg(const BatchTables &t, int kind, const float *x, const float *selfq, float *out, int width,
                                float eps, hipStream_t s);

@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_ZF_HEAD", 0),
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_PNA_PAGG", 1), env_int("GNNB_ZF_HEAD", 0),
                         env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1)};
     return o;
 }
@@ -251,6 +251,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_nt_store = value;
     else if (!strcmp(name, "agg_balance") && value >= 0 && value <= 1)
         o.agg_balance = value;
+    else if (!strcmp(name, "pna_pagg") && value >= 0 && value <= 1)
+        o.pna_pagg = value;
     else if (!strcmp(name, "zf_head") && value >= 0 && value <= 1)
         o.zf_head = value;
     else if (!strcmp(name, "agg_form") && value >= 0 && value <= 2)
@@ -1257,10 +1259,22 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
                                  ws->deg_delta == model->desc.pna_delta && fo > 32;
             if (!classes && (rc = linear1(R(cur, fi), fi, fi, p[0], 2 * fi, p[1], nullptr, Rw(q, fi), M, fi, GNNB_ACT_NONE, stream)))
                 return rc;
-            if ((rc = linear1(R(cur, fi), fi, fi, p[0] + fi, 2 * fi, nullptr, nullptr, Rw(pp, fi), M, fi, GNNB_ACT_NONE, stream)))
-                return rc;
-            if ((rc = aggregate(GNNB_AGG_PNA, pp, classes ? nullptr : q, ws->agg, fi, 0.f)))
-                return rc;
+            // the source half p = x . Wb^T and its aggregate: in one kernel, p on chip, where the degree-class form (no destination
+            // term) and the max_graph_nodes promise (whole graphs in a stage) allow; else GEMM -> [N, F] -> aggregate
+            bool pagg = false;
+            if (classes) {
+                hipError_t he = launch_pna_pagg(ws->t, cur, fi, p[0] + fi, 2 * fi, ws->agg, (hipStream_t)stream);
+                if (he == hipSuccess)
+                    pagg = true;
+                else if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "PNA product + aggregate launch failed: %s", hipGetErrorString(he));
+            }
+            if (!pagg) {
+                if ((rc = linear1(R(cur, fi), fi, fi, p[0] + fi, 2 * fi, nullptr, nullptr, Rw(pp, fi), M, fi, GNNB_ACT_NONE, stream)))
+                    return rc;
+                if ((rc = aggregate(GNNB_AGG_PNA, pp, classes ? nullptr : q, ws->agg, fi, 0.f)))
+                    return rc;
+            }
             // [x | A | amp.A | att.A] . Wpost^T without materialising the 13F concat
             gnnb_gemm_seg segs[4] = {{R(cur, fi), nullptr, fi, fi},
                                      {R(ws->agg, 4 * fi), nullptr, 4 * fi, 4 * fi},

@@ -1,0 +1,287 @@
+// k_pna.hip -- a full-width PNA layer's pre-NN product and its four-way aggregate in ONE kernel: the per-node messages
+// p = x . Wb^T never go to HBM (round 5)
+// Part of libgnnb_hip.so (hand-written gfx950 / CDNA4 kernels of the GNNBuilder hot path); wavefront = 64 lanes.
+//
+// Reference: pna_conv (gnn_builder_lib.h:1891-2157) -- per EDGE h_ij = W_pre [x_i || x_j] + b (`linear`, :1807), then
+// pna_conv_agg (:1750-1834) max | min | mean | std over a node's messages.  Here W_pre [x_i || x_j] = Wa x_i + Wb x_j: the
+// source half p_j = Wb x_j is a per-NODE product, and under a max_degree promise the destination
+// half is folded into the post-NN's class weights, so a layer's aggregate is
+//     A_i = [max | min | mean | std]_j (Wb x_j)        (PyG's std: SURVEY finding 5).
+// Rounds 2-4 ran it as a GEMM that wrote p [N, F] (k_linear_wlds) and an aggregate kernel that read it back
+// (k_aggregate_ring<PNA>): 52 + 65 us and 150 MB of p traffic per layer at BASELINE config 4.  This kernel keeps p on chip,
+// in the shape of the conv-stack kernels:
+//   DMA   the x rows + node records + CSR slice of a stage of WHOLE graphs (<= 64 rows) -> LDS, two buffers, one row per
+//         LDS-DMA instruction so that rows are PADDED (conflict-free MFMA fragment reads)
+//   M     P = X . Wb^T on v_mfma_f32_16x16x4_f32 with the operands swapped (a lane ends with four consecutive columns of a
+//         row), every wave holding its 16-column slice of Wb in registers; P stays in the accumulators across one barrier
+//   PW    P -> LDS, OVER X (nobody reads X any more)
+//   AG    per destination row (a lane group of F / 4 lanes, float4 each): the four statistics of its sources' P rows, read
+//         from LDS in CSR order, -> out [N, 4F] with non-temporal 16-B stores (whole 512-B pieces per row and statistic)
+// Bound: the 4F-wide output stores (302 MB at config 4).  Needs the max_graph_nodes promise (a graph must fit a stage: no
+// p row exists outside the chip) -- without it, and for the general form with its per-destination term, the layer keeps the
+// two-kernel route.  Same statistics in the same order as k_aggregate_ring<PNA>; the product's summation order is the MFMA's.
+#include "gnnb_stack.h"
+
+namespace gnnb {
+
+static constexpr int PA_NW = 8, PA_WG = PA_NW * 64, PA_CAP = 64, PA_ECAP = 512;
+
+struct PaStage {
+    int ok, nb, rows, e0, ne, next_t;
+};
+
+template <int KQ>
+__global__ __launch_bounds__(PA_WG, 2) void k_pna_pagg(const float *__restrict__ x, const int4 *__restrict__ node_rec,
+                                                       const int32_t *__restrict__ col, const int32_t *__restrict__ tile_first,
+                                                       const int32_t *__restrict__ tile_edge, int num_tiles, int N, int E,
+                                                       const float *__restrict__ Wb, int ldw, float *__restrict__ out)
+{
+    constexpr int F = 16 * KQ, LDX = F + 4;             // padded row (floats)
+    constexpr int G = F / 4;                            // lanes per row (float4 each)
+    constexpr int GLOG2 = G == 32 ? 5 : (G == 16 ? 4 : 3), RPI = 64 / G; // rows per wave instruction
+    constexpr int CSL = KQ == 8 ? 3 : (KQ == 4 ? 2 : 1); // log2(column slices of 16)
+    constexpr int NRG = PA_NW >> CSL;                   // row groups: wave w owns slice w & (2^CSL - 1) for the units rg, rg + NRG, ...
+    constexpr int NU = (PA_CAP / 16 + NRG - 1) / NRG;   // units a wave can own
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    // ---- LDS carve: two buffers {x rows, padded -> P | node records | CSR slice}
+    constexpr int xs_b = PA_CAP * LDX * 4, rec_o = xs_b, col_o = rec_o + PA_CAP * 32, in_b = col_o + PA_ECAP * 4;
+
+    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
+    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    if (t1 <= t0)
+        return;
+    // window of the tile table in registers: lane l holds tile t0 + l (the launcher keeps runs below 64 tiles)
+    // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
+    const int ti = min(t0 + min(lane, t1 - t0), num_tiles);
+    const int tf = min(max(tile_first[ti], 0), N), te = min(max(tile_edge[ti], 0), E);
+
+    // the longest run of whole tiles from tile `ts` that fits a stage; its CSR slice is staged when it fits (else rows of
+    // degree > 4 read `col` from global memory)
+    auto plan = [&](int ts) {
+        PaStage st;
+        st.ok = ts < t1 ? 1 : 0;
+        st.nb = st.rows = st.e0 = st.ne = 0;
+        st.next_t = ts;
+        if (!st.ok)
+            return st;
+        const int rel = ts - t0;
+        const int nb = __builtin_amdgcn_readlane(tf, rel), e0 = __builtin_amdgcn_readlane(te, rel);
+        const unsigned long long fit = __ballot(lane > rel && lane <= t1 - t0 && tf - nb <= PA_CAP);
+        st.nb = nb;
+        st.e0 = e0;
+        int endl = rel + 1; // (nothing fits: the next tile alone, cut to the stage -- only if the max_graph_nodes promise is broken)
+        if (fit) {
+            const unsigned long long nofit = ~fit & (~0ull << (rel + 1));
+            endl = nofit ? __builtin_ctzll(nofit) - 1 : 63 - __builtin_clzll(fit);
+        }
+        st.rows = min(max(__builtin_amdgcn_readlane(tf, endl) - nb, 0), PA_CAP);
+        st.ne = max(__builtin_amdgcn_readlane(te, endl) - e0, 0);
+        st.next_t = t0 + endl;
+        return st;
+    };
+    int vm = 0; // vector-memory instructions this wave has issued (DMA + stores): counted waits (VM operations retire in order)
+    auto issue = [&](const PaStage &st, int bb) {
+        if (!st.ok || st.rows <= 0)
+            return;
+        char *base = smem + (size_t)bb * in_b;
+        // one row per instruction (G active lanes): the LDS side of an LDS-DMA is contiguous per instruction, and the rows are padded
+        for (int r = wave; r < st.rows; r += PA_NW, vm++)
+            if (lane < G)
+                dma16_to_lds_u(x + (size_t)(st.nb + r) * F + lane * 4, base + (size_t)r * LDX * 4);
+        const char *grec = reinterpret_cast<const char *>(node_rec + 2 * (size_t)st.nb);
+        const int rbytes = st.rows * 32;
+        for (int c = ((wave + 2) & (PA_NW - 1)) * 1024; c < rbytes; c += PA_NW * 1024, vm++)
+            if (c + lane * 16 < rbytes)
+                dma16_to_lds_u(grec + c + lane * 16, base + rec_o + c);
+        if (st.ne <= PA_ECAP)
+            for (int c = ((wave + 4) & (PA_NW - 1)) * 64; c < st.ne; c += PA_NW * 64, vm++)
+                if (c + lane < st.ne)
+                    dma4_to_lds_u(col + st.e0 + c + lane, base + col_o + (size_t)c * 4);
+    };
+
+    PaStage cur = plan(t0);
+    issue(cur, 0);
+    int mark_cur = vm;
+
+    // ---- the wave's 16-column slice of Wb -> registers: k step t of block q multiplies input column 16 q + 4 lg + t
+    const int cs = wave & ((1 << CSL) - 1), rg = wave >> CSL;
+    float wr[KQ * 4];
+    {
+        const float *wrow = Wb + (size_t)(cs * 16 + li) * ldw + 4 * lg;
+#pragma unroll
+        for (int q = 0; q < KQ; q++) {
+            const float4 v = *reinterpret_cast<const float4 *>(wrow + 16 * q);
+            wr[q * 4 + 0] = v.x;
+            wr[q * 4 + 1] = v.y;
+            wr[q * 4 + 2] = v.z;
+            wr[q * 4 + 3] = v.w;
+        }
+    }
+    // (tracked loads: finished HERE, or their first use inside the stage loop is guarded by a full vmcnt(0) -- k_stack.hip)
+#pragma unroll
+    for (int q = 0; q < KQ * 4; q++)
+        asm volatile("" : "+v"(wr[q]));
+
+    int b = 0;
+    while (cur.ok) {
+        const int rows = cur.rows, nb = cur.nb;
+        char *base = smem + (size_t)b * in_b;
+        float *XP = reinterpret_cast<float *>(base);
+        // ---- the stage's inputs have landed (own share; then everybody's), and everybody is done with the other buffer
+        vmcnt_wait_n(min(vm - mark_cur, 63));
+        g2_barrier();
+        const PaStage nxt = plan(cur.next_t);
+        issue(nxt, b ^ 1);
+        const int mark_nxt = vm;
+
+        // ---- M: P = X . Wb^T for the wave's slice and units, kept in the accumulators
+        const int units = (rows + 15) >> 4;
+        f32x4 acc[NU];
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NU; k++) {
+            const int u = rg + k * NRG;
+            if (u < units) { // (wave-uniform)
+                const float *ap = XP + (u * 16 + li) * LDX + 4 * lg;
+                float4 a4[KQ];
+#pragma unroll
+                for (int q = 0; q < KQ; q++)
+                    a4[q] = *reinterpret_cast<const float4 *>(ap + 16 * q);
+#pragma unroll
+                for (int q = 0; q < KQ; q++) {
+                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + 0], a4[q].x, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + 1], a4[q].y, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + 2], a4[q].z, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + 3], a4[q].w, acc[k], 0, 0, 0);
+                }
+            }
+        }
+        g2_barrier(); // everybody has read X
+        // ---- PW: P over X (lane (li, lg): columns 16 cs + 4 lg .. + 3 of row 16 u + li)
+#pragma unroll
+        for (int k = 0; k < NU; k++) {
+            const int u = rg + k * NRG;
+            if (u < units)
+                *reinterpret_cast<float4 *>(XP + (u * 16 + li) * LDX + cs * 16 + 4 * lg) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+        }
+        g2_barrier(); // P complete
+
+        // ---- AG: max | min | mean | std over every row's sources, CSR order (k_aggregate_ring<PNA>'s AggAcc, no destination term)
+        {
+            typedef Vf<4> V;
+            const int4 *srec = reinterpret_cast<const int4 *>(base + rec_o);
+            const int32_t *scol = reinterpret_cast<const int32_t *>(base + col_o);
+            const bool col_lds = cur.ne <= PA_ECAP;
+            const int e0 = cur.e0;
+            const int grp = lane >> GLOG2, gl = lane & (G - 1);
+            const float *Pl = XP + gl * 4;
+            for (int rb = wave * RPI; rb < rows; rb += PA_NW * RPI) { // (two passes per iteration: measured, nothing)
+                const int i = rb + grp;
+                const bool active = i < rows;
+                const int ic = active ? i : rb; // (lane groups past the stage re-read the pass's first row; their stores are predicated)
+                const int4 r0 = srec[2 * ic], r1 = srec[2 * ic + 1];
+                const int deg = r0.y;
+                const int jl[4] = {r0.z - nb, r0.w - nb, r1.x - nb, r1.y - nb}; // unused slots alias the row itself
+                V h[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    h[q] = V::load(Pl + min(max(jl[q], 0), PA_CAP - 1) * LDX);
+                V vmx = V::splat(0.0f), vmn = vmx, s1 = vmx, s2 = vmx;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (deg > q) {
+                        if (q == 0) {
+                            vmx = h[q];
+                            vmn = h[q];
+                        } else {
+                            vmx = vmax(vmx, h[q]);
+                            vmn = vmin(vmn, h[q]);
+                        }
+                        s1 = vadd(s1, h[q]);
+                        s2 = vadd(s2, vmul(h[q], h[q]));
+                    }
+                }
+                if (deg > 4) { // the rest of the CSR row (two loops: a select between an LDS and a global pointer becomes a flat load)
+                    auto more = [&](int j) {
+                        const V hv = V::load(Pl + min(max(j, 0), PA_CAP - 1) * LDX);
+                        vmx = vmax(vmx, hv);
+                        vmn = vmin(vmn, hv);
+                        s1 = vadd(s1, hv);
+                        s2 = vadd(s2, vmul(hv, hv));
+                    };
+                    if (col_lds) {
+                        for (int k = r0.x + 4; k < r0.x + deg; k++)
+                            more(scol[min(max(k - e0, 0), PA_ECAP - 1)] - nb);
+                    } else {
+                        for (int k = r0.x + 4; k < r0.x + deg; k++)
+                            more(col[k] - nb);
+                    }
+                }
+                V mean = V::splat(0.0f), sd = V::splat(0.0f);
+                if (deg > 0) {
+                    // (one reciprocal per row instead of eight divisions: <= 1 ulp from sum / count, as the ring form's MEAN kind;
+                    // the four statistics' finalisation was a third of the phase's vector instructions)
+                    const V inv = V::splat(1.0f / (float)deg);
+                    mean = vmul(s1, inv);
+                    sd = pyg_std(vmul(s2, inv), mean);
+                }
+                vm += 4; // (the pass's first row exists: every one of its four store instructions has an active lane)
+                if (active) {
+                    float *o = out + (size_t)(nb + i) * (4 * F) + gl * 4;
+                    agg_store<true>(vmx, o);
+                    agg_store<true>(vmn, o + F);
+                    agg_store<true>(mean, o + 2 * F);
+                    agg_store<true>(sd, o + 3 * F);
+                }
+            }
+        }
+        // (the 16-B stores are COUNTED in `vm` like the DMA: the wait at the top of the next stage must leave them in flight)
+        cur = nxt;
+        mark_cur = mark_nxt;
+        b ^= 1;
+    }
+}
+
+// hipErrorNotSupported (nothing launched): the caller runs the p GEMM + k_aggregate_ring<PNA>
+hipError_t launch_pna_pagg(const BatchTables &t, const float *x, int F, const float *wb, int ldw, float *out, hipStream_t s)
+{
+    if (t.num_nodes <= 0)
+        return hipSuccess;
+    if (!options().pna_pagg || !(F == 128 || F == 64 || F == 32) || t.tile_lo != 0)
+        return hipErrorNotSupported;
+    // whole graphs must fit a stage (validated on the device by graph prep: flag 8)
+    if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > PA_CAP)
+        return hipErrorNotSupported;
+    if ((((uintptr_t)x | (uintptr_t)wb | (uintptr_t)out) & 15) || (ldw & 3))
+        return hipErrorNotSupported;
+    const size_t lds = 2 * ((size_t)PA_CAP * (F + 4) * 4 + PA_CAP * 32 + PA_ECAP * 4);
+    const int cus = device_cu_count();
+    long long grid = std::min<long long>(2LL * cus, t.num_tiles);
+    if (grid < 1)
+        grid = 1;
+    if ((t.num_tiles + grid - 1) / grid > 62) // a workgroup keeps its run of the tile table in one register per lane
+        grid = (t.num_tiles + 61) / 62;
+    hipError_t rc = hipErrorNotSupported;
+    auto go = [&](auto qtag) {
+        constexpr int KQ = decltype(qtag)::value;
+        auto kern = k_pna_pagg<KQ>;
+        if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess)
+            return;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PA_WG), lds, s, x, t.node_rec, t.col, t.tile_first, t.tile_edge, t.num_tiles,
+                           t.num_nodes, t.num_edges, wb, ldw, out);
+        rc = hipGetLastError();
+    };
+    if (F == 128)
+        go(IntTag<8>{});
+    else if (F == 64)
+        go(IntTag<4>{});
+    else
+        go(IntTag<2>{});
+    return rc;
+}
+
+} // namespace gnnb

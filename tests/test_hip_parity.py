@@ -1665,6 +1665,56 @@ def test_register_gather_aggregate_matches_the_ring(dev, width):
         runtime.set_option("agg_form", 0)
 
 
+@pytest.mark.parametrize("hidden,out,layers,fin", [(128, 128, 3, 11), (64, 128, 3, 64), (32, 64, 2, 32), (128, 64, 4, 128)])
+def test_pna_product_and_aggregate_in_one_kernel(dev, hidden, out, layers, fin):
+    """k_pna_pagg (round 5): a full-width PNA layer's source-half product p = x . Wb^T and its max | min | mean | std aggregate
+    in one kernel -- whole graphs staged in LDS, p never in HBM -- under the degree promise (no destination term) + the
+    max_graph_nodes promise (a graph must fit a 64-row stage).  Against the two-kernel route (pna_pagg = 0: GEMM -> [N, F] ->
+    k_aggregate_ring<PNA>), the general form and the oracle, every graph.  Batch: molecules, isolated nodes, a star of degree
+    13 (the CSR tail), empty graphs, one-node graphs, a graph of exactly the promised size; widths 128 / 64 / 32; a promise
+    beyond the stage (57 + 7 > 64) keeps the two-kernel route with the same numbers."""
+    model = make_model("pna", in_dim=fin, hidden=hidden, out_dim=out, layers=layers, act="relu", pools=("add", "mean", "max"), task_out=2, seed=hidden + layers + fin)
+    base = synthetic.make_batch("qm9", 500, seed=19)
+    rng = np.random.default_rng(fin + hidden)
+    empty = (np.zeros((0, fin), np.float32), np.zeros((0, 2), np.int32))
+
+    def regraph(g):
+        x, e = base.graph(g)
+        return rng.uniform(-1, 1, (x.shape[0], fin)).astype(np.float32), e
+
+    lone = (rng.uniform(-1, 1, (3, fin)).astype(np.float32), np.zeros((0, 2), np.int32))
+    one = (rng.uniform(-1, 1, (1, fin)).astype(np.float32), np.zeros((0, 2), np.int32))
+    star = (rng.uniform(-1, 1, (14, fin)).astype(np.float32), np.array([[i, 0] for i in range(1, 14)] + [[0, i] for i in range(1, 14)], np.int32))
+    ring = np.stack([np.arange(40), (np.arange(40) + 1) % 40], 1)
+    big = (rng.uniform(-1, 1, (40, fin)).astype(np.float32), np.concatenate([ring, ring[:, ::-1]]).astype(np.int32))
+    graphs = [empty, star] + [regraph(g) for g in range(250)] + [lone, one, one, big, empty] + [regraph(g) for g in range(250, 500)] + [star, empty]
+    batch = pack_graphs(graphs)
+    maxdeg = int(np.bincount(batch.coo[:, 1]).max())
+    maxn = int(np.diff(batch.node_ptr).max())
+    assert maxdeg == 13 and maxn == 40
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    outs = {}
+    try:
+        for name, pagg, promise_n, promise_d in (("one_kernel", 1, maxn, maxdeg), ("two_kernels", 0, maxn, maxdeg), ("beyond_stage", 1, 58, maxdeg), ("general", 1, maxn, 0)):
+            runtime.set_option("pna_pagg", pagg)
+            cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise_n)
+            cm.set_max_degree(promise_d)
+            outs[name] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            cm.check()
+            assert cm.last_path() == "layerwise"
+            if name == "one_kernel":
+                assert np.array_equal(outs[name], cm.forward(*to_dev(batch, dev)).cpu().numpy())
+    finally:
+        runtime.set_option("pna_pagg", 1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for k, v in outs.items():
+        assert np.isfinite(v).all() and np.abs(v - ref).max() < TOL * scale, k
+    assert np.abs(outs["one_kernel"] - outs["two_kernels"]).max() < 2e-5 * scale
+    assert np.array_equal(outs["two_kernels"], outs["beyond_stage"])
+    if hidden == 128 and fin != 128:
+        assert not np.array_equal(outs["one_kernel"], outs["two_kernels"])  # (the new kernel is what ran: another summation order)
+
+
 def test_pna_degree_promise_with_an_empty_batch(dev):
     """A PNA workspace with a max_degree promise and a batch WITHOUT nodes (graph prep allows it): no class tables are written
     for such a batch, so the forward must not take the class GEMM over stale tables (round-4 advisor finding).  Every graph's
