@@ -199,6 +199,45 @@ def measure_segmented_gemm(w, N, dev, iters=50, pna_classes=False):
                 frac=flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, shape=f"M={N} K={K} N={d}", what=what)
 
 
+def measure_pna_product_aggregate(cm, batch_dev, width, dev, iters=100):
+    """k_pna_pagg (PNA under both promises: the source-half product p = x . Wb^T and its max | min | mean | std aggregate in one
+    kernel, p on chip) on the prepared batch: HIP events on the launch stream, buffers rotating over > 256 MiB.  Algorithmic HBM
+    bytes: x read once + the four output matrices written once + node records + CSR + tile tables; algorithmic flops 2 N w^2."""
+    import torch
+    from gnnbuilder_amd import runtime
+
+    x, coo, nptr, eptr = batch_dev
+    N, E, B = int(x.shape[0]), int(coo.shape[0]), int(nptr.numel()) - 1
+    cm.graph_prep(coo, nptr, eptr, N)
+    per_pair = 4 * width * N * 5
+    nbuf = max(2, int(np.ceil(320 * 2**20 / per_pair)) + 1)
+    ins = [torch.rand(N, width, device=dev) * 2 - 1 for _ in range(nbuf)]
+    outs = [torch.empty(N, 4 * width, device=dev) for _ in range(nbuf)]
+    wpre = (torch.rand(width, 2 * width, device=dev) - 0.5) / width ** 0.5
+    wb = wpre[:, width:]
+    try:
+        for i in range(nbuf):
+            cm.pna_product_aggregate(ins[i], wb, out=outs[i])
+    except runtime.GnnbError:
+        return None
+    tm = runtime.HipTimer()
+    torch.cuda.synchronize()
+    tm.start()
+    for i in range(iters):
+        cm.pna_product_aggregate(ins[i % nbuf], wb, out=outs[i % nbuf])
+    tm.stop()
+    us = tm.elapsed_ms() * 1e3 / iters
+    alg_bytes = 4 * width * N * 5 + 32 * N + 4 * E + 8 * (N // 8 + 1) + 4 * (B + 1)
+    flops = 2.0 * N * width * width
+    return {"kernel": "k_pna_pagg<%d> (PNA pre-NN source half + max|min|mean|std aggregate in one kernel, p on chip; width %d)" % (width // 16, width),
+            "bound": "hbm", "achieved": alg_bytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_flops_per_launch": flops, "us_per_launch": us,
+            "note": "what the timed step runs instead of a p GEMM + k_aggregate_ring<PNA> on its full-width layers (max_degree + "
+                    "max_graph_nodes promises); bound by its 4w-wide output stores; launches from Python (the kernel is ~90 us, the launch "
+                    "cost overlaps); HIP events on the launch stream"}
+
+
 def pmc_traffic(kind, workload, alg_bytes):
     """HBM bytes per launch of kernel `kind` AT THIS WORKLOAD from the latest committed rocprofv3 PMC passes
     (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/profile_r.sh -> profiles/<round>_<workload>_<kind>_pmc.json).
@@ -892,9 +931,14 @@ def main():
                 "traffic": pmc_traffic("aggregate_%s" % wkind, args.workload, ab),
                 "in_pipeline_l3_resident": ag.get("l3_resident"), "extra_read_bytes": ag.get("extra_read_bytes", 0),
                 "destination_term": bool(wkind == "pna" and not max_degree),
+                "in_timed_step": not (wkind == "pna" and max_degree and cm.last_path() == "layerwise" and max_graph + 7 <= 64),
                 "note": "algorithmic bytes per SURVEY 8(d): 4 w N (1 + k_out) + CSR + graph ptr; PNA WITHOUT a max_degree promise "
                         "reads its per-destination term q [N, w] on top (extra_read_bytes, not counted); with the promise -- "
                         "what the timed step runs -- the aggregate takes no destination term"}
+        if w["conv"] == "pna" and max_degree:
+            pa = measure_pna_product_aggregate(cm, dev_batches[0], w["hidden"], dev)
+            if pa is not None:
+                gather["pna_product_aggregate"] = pa
         fused = measure_fused_stack(cm, dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w.get("out_dim", w["hidden"]), len(w["pools"])),
                                     conv=w["conv"], layers=w["layers"], seg=segs[0]) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
         upd = dict(kernel="k_linear_wlds (fp32 MFMA, weights in LDS), full-width layer update", bound="mfma", peak=FP32_MFMA_PEAK_TFLOPS,

@@ -957,6 +957,21 @@ int gnnb_aggregate_edges(gnnb_workspace *ws, const float *x_dev, const float *ed
     return GNNB_OK;
 }
 
+int gnnb_pna_product_aggregate(gnnb_workspace *ws, const float *x_dev, const float *wb_dev, int ldw, float *out_dev, int width,
+                               void *stream)
+{
+    if (!ws || !ws->prepared)
+        return fail(GNNB_ERR_INVALID, "gnnb_pna_product_aggregate needs a prepared batch (gnnb_graph_prep)");
+    if (!x_dev || !wb_dev || !out_dev || width < 1 || ldw < width)
+        return fail(GNNB_ERR_INVALID, "bad argument to gnnb_pna_product_aggregate");
+    hipError_t he = launch_pna_pagg(ws->t, x_dev, width, wb_dev, ldw, out_dev, (hipStream_t)stream);
+    if (he == hipErrorNotSupported)
+        return fail(GNNB_ERR_INVALID, "gnnb_pna_product_aggregate takes widths 128 / 64 / 32, 16-byte aligned operands and a workspace "
+                                      "whose max_graph_nodes promise fits a 64-row stage (promise + tile rows - 1 <= 64)");
+    GNNB_HIP_TRY(he);
+    return GNNB_OK;
+}
+
 int gnnb_aggregate(gnnb_workspace *ws, int agg_kind, const float *x_dev, const float *self_dev,
                    float *out_dev, int width, float eps, void *stream)
 {
@@ -966,8 +981,7 @@ int gnnb_aggregate(gnnb_workspace *ws, int agg_kind, const float *x_dev, const f
         return fail(GNNB_ERR_INVALID, "bad argument to gnnb_aggregate");
     if (agg_kind < GNNB_AGG_GCN || agg_kind > GNNB_AGG_COPY)
         return fail(GNNB_ERR_INVALID, "unknown aggregate kind %d", agg_kind);
-    if (agg_kind == GNNB_AGG_PNA && !self_dev)
-        return fail(GNNB_ERR_INVALID, "PNA aggregate needs the per-destination term");
+    // (PNA with self_dev == NULL: no destination term -- the statistics of p_j alone, what the degree-class form aggregates)
     if (ws->t.num_nodes == 0)
         return GNNB_OK;
     if (agg_kind == GNNB_AGG_GCN) {

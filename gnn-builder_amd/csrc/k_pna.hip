@@ -17,7 +17,9 @@
 //   PW    P -> LDS, OVER X (nobody reads X any more)
 //   AG    per destination row (a lane group of F / 4 lanes, float4 each): the four statistics of its sources' P rows, read
 //         from LDS in CSR order, -> out [N, 4F] with non-temporal 16-B stores (whole 512-B pieces per row and statistic)
-// Bound: the 4F-wide output stores (302 MB at config 4).  Needs the max_graph_nodes promise (a graph must fit a stage: no
+// Bound: vector + matrix issue (solo at config 4: 102 us; the product alone is 31 us at the fp32 MFMA peak, the aggregate phase
+// ~200 vector instructions per pair of rows, and the two add on the shared issue port; the stores are 19 us of it: DESIGN 3.8).
+// Needs the max_graph_nodes promise (a graph must fit a stage: no
 // p row exists outside the chip) -- without it, and for the general form with its per-destination term, the layer keeps the
 // two-kernel route.  Same statistics in the same order as k_aggregate_ring<PNA>; the product's summation order is the MFMA's.
 #include "gnnb_stack.h"
@@ -227,7 +229,17 @@ __global__ __launch_bounds__(PA_WG, 2) void k_pna_pagg(const float *__restrict__
                     // the four statistics' finalisation was a third of the phase's vector instructions)
                     const V inv = V::splat(1.0f / (float)deg);
                     mean = vmul(s1, inv);
-                    sd = pyg_std(vmul(s2, inv), mean);
+                    // PyG's std with the hardware square root (v_sqrt_f32, 1 ulp: the IEEE sqrtf expands to a dozen instructions per
+                    // component, a fifth of this phase -- which is bound by vector issue: ablations in DESIGN 3.8)
+                    const V m2 = vmul(s2, inv);
+                    auto sd1 = [](float q2, float m) {
+                        float var = q2 - m * m;
+                        var = var < 1e-5f ? 1e-5f : var;
+                        // (the mask `std <= sqrt(1e-5)` is taken on the variance: a 1-ulp square root of the clamp value itself could land
+                        // above the threshold and leave 3.2e-3 where PyG has 0)
+                        return var <= 1e-5f ? 0.0f : __builtin_amdgcn_sqrtf(var);
+                    };
+                    sd.v = make_float4(sd1(m2.v.x, mean.v.x), sd1(m2.v.y, mean.v.y), sd1(m2.v.z, mean.v.z), sd1(m2.v.w, mean.v.w));
                 }
                 vm += 4; // (the pass's first row exists: every one of its four store instructions has an active lane)
                 if (active) {

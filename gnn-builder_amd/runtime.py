@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
     "gnnb_malloc", "gnnb_free", "gnnb_memcpy_h2d", "gnnb_memcpy_d2h", "gnnb_set_option",
     "gnnb_aggregate_timed", "gnnb_linear_timed", "gnnb_gcn_stack_timed",
-    "gnnb_aggregate_edges", "gnnb_edge_index_table_to_host", "gnnb_debug_stream_k_guard",
+    "gnnb_aggregate_edges", "gnnb_edge_index_table_to_host", "gnnb_debug_stream_k_guard", "gnnb_pna_product_aggregate",
 ]
 
 
@@ -148,6 +148,7 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
         lib.gnnb_aggregate_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         lib.gnnb_edge_index_table_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.gnnb_debug_stream_k_guard.argtypes = [C.c_void_p, C.c_void_p]
+        lib.gnnb_pna_product_aggregate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         lib.gnnb_gcn_stack_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                              C.POINTER(C.c_float)]
         _lib = lib
@@ -411,6 +412,24 @@ class CompiledModel:
         _check(self.lib.gnnb_aggregate(self._ws, AGG[kind], _dptr(x),
                                        _dptr(self_term) if self_term is not None else None, _dptr(out), w,
                                        float(eps), _stream_ptr(stream)))
+        return out
+
+    def pna_product_aggregate(self, x, wb, out=None, stream=None):
+        """``max | min | mean | std`` over every node's sources of ``p_j = wb @ x_j`` in one kernel (``k_pna_pagg``); ``wb``:
+        [width, ldw] view of the x_j half of the pre-NN weight (``W_pre[:, width:]``: a strided view is fine, the row stride is
+        passed on).  Needs the workspace's ``max_graph_nodes`` promise (<= 57 with the default node tiles)."""
+        import torch
+        _require(x, "x", torch.float32, 2)
+        w = int(x.shape[1])
+        if int(x.shape[0]) != self._N:
+            raise GnnbError(f"x has {int(x.shape[0])} rows, the prepared batch has {self._N} nodes")
+        if wb.dtype != torch.float32 or wb.dim() != 2 or tuple(wb.shape) != (w, w) or wb.stride(1) != 1 or wb.device != x.device:
+            raise GnnbError(f"wb must be a [{w}, {w}] float32 view with unit column stride on {x.device}")
+        if out is None:
+            out = torch.empty((x.shape[0], 4 * w), dtype=torch.float32, device=x.device)
+        else:
+            _require(out, "out", torch.float32, 2, 4 * w)
+        _check(self.lib.gnnb_pna_product_aggregate(self._ws, _dptr(x), wb.data_ptr(), int(wb.stride(0)), _dptr(out), w, _stream_ptr(stream)))
         return out
 
     def edge_index_table_to_host(self, stream=None) -> np.ndarray:

@@ -243,10 +243,21 @@ typedef enum gnnb_agg {
     GNNB_AGG_COPY = 6  /* out = x: the kernel's launch shape and bytes with no gather (calibration of the roofline) */
 } gnnb_agg;
 /* Gather-aggregate over the prepared batch.  x_dev [N,width]; out_dev [N,width]
- * ([N,4*width] for PNA).  self_dev: PNA only, the per-destination term q [N,width]
+ * ([N,4*width] for PNA).  self_dev: PNA only, the per-destination term q [N,width] (NULL: none -- the statistics of p_j alone,
+ * what the degree-class form of gnnb_workspace_set_max_degree aggregates)
  * (NULL otherwise).  eps: GIN's epsilon (SUM only). */
 int gnnb_aggregate(gnnb_workspace *ws, int agg_kind, const float *x_dev, const float *self_dev,
                    float *out_dev, int width, float eps, void *stream);
+
+/* PNA's source-half pre-NN product and its aggregate in one kernel (round 5): out [N, 4*width] = max | min | mean | std over
+ * every node's sources j of p_j = Wb x_j, Wb [width, ldw] row-major = the x_j half of pre_nns.0.0.weight (columns width ..
+ * 2 width - 1: pass weight + width, ldw = 2 width) -- the reference's per-edge `linear` (gnn_builder_lib.h:1807) split per
+ * node, + pna_conv_agg (:1750-1834) without a destination term (the degree-class form folds that term into the post-NN's
+ * weights).  p never goes to HBM: whole graphs are staged in LDS, so the workspace needs a max_graph_nodes promise that fits
+ * a 64-row stage; widths 128 / 64 / 32.  The forward takes this route by itself (option pna_pagg); this entry exists for
+ * measurements and tests. */
+int gnnb_pna_product_aggregate(gnnb_workspace *ws, const float *x_dev, const float *wb_dev, int ldw, float *out_dev, int width,
+                               void *stream);
 
 /* GINE aggregate (gine_conv_agg + the self term of gine_conv, gnn_builder_lib.h:1555-1742):
  *   out_i = (1 + eps) x_i + sum_{j->i} relu(x_j + edge_term[e]),  e = the COO row of the edge j->i.

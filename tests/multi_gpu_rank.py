@@ -50,7 +50,8 @@ def main():
     if rank == 0:
         print(json.dumps({"graphs": c[0].item(), "rccl_ranks": int(round(c[1].item())), "nodes": c[2].item(),
                           "max_err": e[0].item(), "max_nodes_per_rank": e[1].item(), "path": cm.last_path(),
-                          "global_graphs": glob.num_graphs, "global_nodes": glob.num_nodes}))
+                          "global_graphs": glob.num_graphs, "global_nodes": glob.num_nodes,
+                          "largest_graph": int(np.diff(glob.node_ptr).max())}))
 
 
 if __name__ == "__main__":

@@ -95,7 +95,7 @@ def test_two_ranks_over_rccl_match_the_oracle(conv, shape, graphs):
     r = json.loads([l for l in outs[0][0].splitlines() if l.strip().startswith("{")][-1])
     assert r["rccl_ranks"] == 2 and r["graphs"] == r["global_graphs"] == graphs and r["nodes"] == r["global_nodes"]
     assert r["max_err"] < TOL
-    assert r["max_nodes_per_rank"] <= r["global_nodes"] / 2 + 222  # node-balanced up to one graph
+    assert r["max_nodes_per_rank"] <= r["global_nodes"] / 2 + r["largest_graph"]  # node-balanced up to one graph (the batch's largest)
     if conv in ("gcn", "gin"):
         assert r["path"].startswith("stack")
 

@@ -18,7 +18,7 @@ OUT=$R/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 WL=${@:-c2 c3 c3t c4 c5 ref6_gcn ref6_gin ref6_sage ref6_pna}
 for w in $WL; do
-  extra=""   # (round 4: every tracked line keeps its cpu_baseline -- the reference's C++ library on one host core)
+  extra="--no-other-configs"   # (every tracked line keeps its cpu_baseline; the brief c3 / c4 / c5 legs of the default line would mix their kernels into the c2 table)
   python3 bench.py --workload $w --steps 100 $extra > "$OUT/plain_$w.log" 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_$w" -o bench -- python3 bench.py --workload $w --steps 100 $extra > "$OUT/bench_$w.log" 2>&1
   case $w in ref6_*) continue;; esac   # (the published-model workloads: the line and the kernel table only)
