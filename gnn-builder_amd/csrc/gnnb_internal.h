@@ -94,6 +94,8 @@ struct Options {
     int pna_fold_lin;    // 1 = PNA's `lin` folded into its post-NN at upload: one 13F-wide GEMM per layer (default); 0 = two GEMMs
     int pna_classes;     // 1 = PNA under a max_degree promise <= 15: rows sorted by degree, 5F-wide GEMM with per-class weights (default)
     int fold_skip;       // 1 = GraphSAGE: a middle layer's skip connection folded into the root weights (Wr + I) instead of read as an operand (default)
+    int sage_first_mean; // 1 = GraphSAGE: the narrow first layer also forms the NEXT layer's mean aggregate from its output rows while they
+                         //     are in LDS (k_sage_first_mean; needs the max_graph_nodes promise; default); 0 = k_conv_first + aggregate kernel
     int pna_pagg;        // 1 = a full-width PNA layer under the degree promise + the max_graph_nodes promise: pre-NN product and aggregate in
                          //     one kernel, p never in HBM (k_pna_pagg; default); 0 = GEMM + k_aggregate_ring<PNA>
     int zf_head;         // 1 = k_gcn2_zf runs the MLP head on the graphs it pooled (conv stack + pooling + head in one launch; default)
@@ -113,6 +115,10 @@ hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const 
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s);
+// GraphSAGE's narrow first layer (k_conv_first's [mean | x] form) + the next layer's mean aggregate of its output rows, one kernel
+// (k_first_mean.hip): y [N, Nout] and mean_out [N, Nout].  hipErrorNotSupported (nothing launched) -> launch_conv_first + aggregate
+hipError_t launch_sage_first_mean(const BatchTables &t, const float *x, int F, const float *w, int ldw, const float *bias, float *y,
+                                  float *mean_out, int Nout, int act, hipStream_t s);
 // PNA: out [N, 4F] = max | min | mean | std over every node's sources of p_j = Wb x_j, p kept on chip (k_pna.hip); no destination
 // term (the degree-class form).  hipErrorNotSupported (nothing launched) -> p GEMM + launch_aggregate(GNNB_AGG_PNA)
 hipError_t launch_pna_pagg(const BatchTables &t, const float *x, int F, const float *wb, int ldw, float *out, hipStream_t s);

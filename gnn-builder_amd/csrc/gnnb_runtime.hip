@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_PNA_PAGG", 1), env_int("GNNB_ZF_HEAD", 0),
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_SAGE_FIRST_MEAN", 1), env_int("GNNB_PNA_PAGG", 1), env_int("GNNB_ZF_HEAD", 0),
                         env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1)};
     return o;
 }
@@ -251,6 +251,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_nt_store = value;
     else if (!strcmp(name, "agg_balance") && value >= 0 && value <= 1)
         o.agg_balance = value;
+    else if (!strcmp(name, "sage_first_mean") && value >= 0 && value <= 1)
+        o.sage_first_mean = value;
     else if (!strcmp(name, "pna_pagg") && value >= 0 && value <= 1)
         o.pna_pagg = value;
     else if (!strcmp(name, "zf_head") && value >= 0 && value <= 1)
@@ -1167,6 +1169,7 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
     const bool whole = row_lo == 0;
     const float *cur = x_dev;
     int which = 0;
+    bool mean_ready = false; // GraphSAGE: ws->agg already holds mean_j of the current layer's input rows (k_sage_first_mean)
     for (int l = 0; l < d.num_layers; l++) {
         const LayerDims ld = layer_dims(d, l);
         const int fi = ld.fin, fo = ld.fout;
@@ -1217,6 +1220,17 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
             break;
         }
         case GNNB_CONV_SAGE: {
+            if (whole && options().fuse_narrow && 2 * fi <= 32 && l + 1 < d.num_layers && skip == nullptr && !fpx) {
+                // narrow input AND a layer behind it: the stage's output rows stay in LDS and the next layer's mean aggregate is
+                // taken from there -- its aggregate kernel (a full read and write of [N, fo]) is not run
+                hipError_t he = launch_sage_first_mean(ws->t, cur, fi, p[0], 2 * fi, p[1], nxt, ws->agg, fo, d.activation, (hipStream_t)stream);
+                if (he == hipSuccess) {
+                    mean_ready = true;
+                    break;
+                }
+                if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "first-layer + mean launch failed: %s", hipGetErrorString(he));
+            }
             if (whole && options().fuse_narrow && 2 * fi <= 32) {
                 // narrow input: [mean_j x_j | x_i] is produced inside the GEMM's A stage (K = 2 F_in)
                 hipError_t he = launch_conv_gather(ws->t, GNNB_AGG_MEAN, 0.f, cur, fi, 2 * fi, p[0], 2 * fi, p[1], skip, nxt,
@@ -1226,8 +1240,9 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
                 if (he != hipErrorNotSupported)
                     return fail(GNNB_ERR_HIP, "fused narrow conv launch failed: %s", hipGetErrorString(he));
             }
-            if ((rc = aggregate(GNNB_AGG_MEAN, cur, nullptr, ws->agg, fi, 0.f)))
+            if (!mean_ready && (rc = aggregate(GNNB_AGG_MEAN, cur, nullptr, ws->agg, fi, 0.f)))
                 return rc;
+            mean_ready = false;
             gnnb_gemm_seg segs[2] = {{R(ws->agg, fi), nullptr, fi, fi}, {R(cur, fi), nullptr, fi, fi}};
             // the LAST layer of a whole-batch run: global pooling in the GEMM's epilogue -- its [N, out] output is never
             // written and the separate pooling pass (a full read of it) disappears (reference: compute_gnn_head's last

@@ -1715,6 +1715,49 @@ def test_pna_product_and_aggregate_in_one_kernel(dev, hidden, out, layers, fin):
         assert not np.array_equal(outs["one_kernel"], outs["two_kernels"])  # (the new kernel is what ran: another summation order)
 
 
+@pytest.mark.parametrize("fin,hidden,out,layers,act", [(9, 256, 256, 2, "relu"), (16, 128, 64, 3, "tanh"), (4, 64, 64, 2, "gelu"), (11, 256, 128, 4, "sigmoid")])
+def test_sage_first_layer_forms_the_next_layers_mean(dev, fin, hidden, out, layers, act):
+    """k_sage_first_mean (round 5): GraphSAGE's narrow first layer with the stage's output rows kept in LDS, from which the NEXT
+    layer's mean aggregate is taken -- out and mean leave the chip once each, the aggregate kernel of layer 1 is not run.  Needs
+    the max_graph_nodes promise (<= 49).  Against the two-kernel route (`sage_first_mean` 0: bit-identical -- the same sums in
+    the same order) and the oracle, every graph; batch with isolated nodes, a hub of degree 30 (CSR tail), empty and one-node
+    graphs, a 49-node ring; a promise beyond the stage keeps the old route."""
+    model = make_model("sage", in_dim=fin, hidden=hidden, out_dim=out, layers=layers, act=act, pools=("add", "mean", "max"), task_out=3, seed=fin + hidden)
+    rng = np.random.default_rng(fin)
+    base = synthetic.make_batch("molhiv", 400, seed=13)
+    empty = (np.zeros((0, fin), np.float32), np.zeros((0, 2), np.int32))
+
+    def regraph(g):
+        x, e = base.graph(g)
+        return rng.uniform(-1, 1, (x.shape[0], fin)).astype(np.float32), e
+
+    one = (rng.uniform(-1, 1, (1, fin)).astype(np.float32), np.zeros((0, 2), np.int32))
+    lone = (rng.uniform(-1, 1, (4, fin)).astype(np.float32), np.array([[0, 1]], np.int32))
+    star = (rng.uniform(-1, 1, (31, fin)).astype(np.float32), np.array([[i, 0] for i in range(1, 31)] + [[0, i] for i in range(1, 31)], np.int32))
+    ring = np.stack([np.arange(49), (np.arange(49) + 1) % 49], 1)
+    big = (rng.uniform(-1, 1, (49, fin)).astype(np.float32), np.concatenate([ring, ring[:, ::-1]]).astype(np.int32))
+    graphs = [empty, star] + [regraph(g) for g in range(200)] + [one, lone, big, empty, empty] + [regraph(g) for g in range(200, 400)] + [one]
+    batch = pack_graphs(graphs)
+    maxn = int(np.diff(batch.node_ptr).max())
+    assert maxn == 49
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    outs = {}
+    try:
+        for name, on, promise in (("one_kernel", 1, maxn), ("two_kernels", 0, maxn), ("beyond_stage", 1, 50), ("no_promise", 1, 0)):
+            runtime.set_option("sage_first_mean", on)
+            cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise)
+            outs[name] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            cm.check()
+            assert cm.last_path() == "layerwise"
+    finally:
+        runtime.set_option("sage_first_mean", 1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for k, v in outs.items():
+        assert np.isfinite(v).all() and np.abs(v - ref).max() < TOL * scale, k
+    for k in ("two_kernels", "beyond_stage", "no_promise"):
+        assert np.array_equal(outs["one_kernel"], outs[k]), k
+
+
 def test_pna_degree_promise_with_an_empty_batch(dev):
     """A PNA workspace with a max_degree promise and a batch WITHOUT nodes (graph prep allows it): no class tables are written
     for such a batch, so the forward must not take the class GEMM over stale tables (round-4 advisor finding).  Every graph's
