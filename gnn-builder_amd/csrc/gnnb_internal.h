@@ -96,6 +96,8 @@ struct Options {
     int fold_skip;       // 1 = GraphSAGE: a middle layer's skip connection folded into the root weights (Wr + I) instead of read as an operand (default)
     int sage_first_mean; // 1 = GraphSAGE: the narrow first layer also forms the NEXT layer's mean aggregate from its output rows while they
                          //     are in LDS (k_sage_first_mean; needs the max_graph_nodes promise; default); 0 = k_conv_first + aggregate kernel
+    int pna_first;       // 1 = a PNA layer with a narrow input (F <= 12: the first) as ONE kernel -- pre-NN, aggregate, scalers, post-NN --
+                         //     when the max_graph_nodes promise lets whole graphs be staged (k_pna_first; default); 0 = four launches
     int pna_pagg;        // 1 = a full-width PNA layer under the degree promise + the max_graph_nodes promise: pre-NN product and aggregate in
                          //     one kernel, p never in HBM (k_pna_pagg; default); 0 = GEMM + k_aggregate_ring<PNA>
     int zf_head;         // 1 = k_gcn2_zf runs the MLP head on the graphs it pooled (conv stack + pooling + head in one launch; default)
@@ -119,6 +121,12 @@ hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, cons
 // (k_first_mean.hip): y [N, Nout] and mean_out [N, Nout].  hipErrorNotSupported (nothing launched) -> launch_conv_first + aggregate
 hipError_t launch_sage_first_mean(const BatchTables &t, const float *x, int F, const float *w, int ldw, const float *bias, float *y,
                                   float *mean_out, int Nout, int act, hipStream_t s);
+// A narrow-input PNA layer in one kernel (k_pna_first.hip): y = act([x | A | amp A | att A] . w^T + bias) with A = the four
+// statistics of W_pre [x_i || x_j] + b_pre over every node's sources; wpre [F][2F], w [Nout][ldw >= 13 F] (post-NN with `lin`
+// folded in); t.amp / t.att must have been prepared with the model's delta.  hipErrorNotSupported (nothing launched) -> the
+// layer-by-layer kernels
+hipError_t launch_pna_first(const BatchTables &t, const float *x, int F, const float *wpre, const float *bpre, const float *w, int ldw,
+                            const float *bias, float *y, int Nout, int act, hipStream_t s);
 // PNA: out [N, 4F] = max | min | mean | std over every node's sources of p_j = Wb x_j, p kept on chip (k_pna.hip); no destination
 // term (the degree-class form).  hipErrorNotSupported (nothing launched) -> p GEMM + launch_aggregate(GNNB_AGG_PNA)
 hipError_t launch_pna_pagg(const BatchTables &t, const float *x, int F, const float *wb, int ldw, float *out, hipStream_t s);

@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_SAGE_FIRST_MEAN", 1), env_int("GNNB_PNA_PAGG", 1), env_int("GNNB_ZF_HEAD", 0),
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_SAGE_FIRST_MEAN", 1), env_int("GNNB_PNA_FIRST", 1), env_int("GNNB_PNA_PAGG", 1), env_int("GNNB_ZF_HEAD", 0),
                         env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1)};
     return o;
 }
@@ -180,6 +180,7 @@ struct gnnb_workspace {
     int deg_max_tiles = 0;
     bool deg_ready = false;
     float deg_delta = 0.0f;
+    float prep_delta = 0.0f; // the delta the prepared batch's amp / att tables were computed with (PNA workspaces; 0: none)
     int last_path = GNNB_PATH_NONE; // which kernels the last forward on this workspace ran (gnnb_workspace_last_path)
     // "large segment" of the NEXT batches (gnnb_workspace_set_large_segment): graphs [large_g, B) -- nodes from large_n,
     // edges from large_e -- are exempt from the max_graph_nodes promise and run layer by layer; -1 = no such segment
@@ -253,6 +254,8 @@ int gnnb_set_option(const char *name, int value)
         o.agg_balance = value;
     else if (!strcmp(name, "sage_first_mean") && value >= 0 && value <= 1)
         o.sage_first_mean = value;
+    else if (!strcmp(name, "pna_first") && value >= 0 && value <= 1)
+        o.pna_first = value;
     else if (!strcmp(name, "pna_pagg") && value >= 0 && value <= 1)
         o.pna_pagg = value;
     else if (!strcmp(name, "zf_head") && value >= 0 && value <= 1)
@@ -835,6 +838,7 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     GNNB_HIP_TRY(launch_graph_prep(coo_dev, node_ptr_dev, edge_ptr_dev, t, prep_delta, drop_self,
                                    (hipStream_t)stream));
     ws->prepared = true;
+    ws->prep_delta = prep_delta > 0.0f ? prep_delta : 0.0f;
     ws->gcoef_ready = false;
     // PNA under a degree promise: the rows sorted into degree classes, right behind the tables on the prep stream
     ws->deg_ready = false;
@@ -1280,6 +1284,14 @@ static int run_conv_layers(const gnnb_model *model, gnnb_workspace *ws, const fl
             break;
         }
         case GNNB_CONV_PNA: {
+            // a narrow input (the first layer): the whole layer in one kernel, whole graphs staged in LDS (k_pna_first.hip)
+            if (whole && fi <= 12 && skip == nullptr && !fpx && p.size() >= 8 && options().pna_fold_lin && ws->prep_delta == d.pna_delta) {
+                hipError_t he = launch_pna_first(ws->t, cur, fi, p[0], p[1], p[6], 13 * fi, p[7], nxt, fo, d.activation, (hipStream_t)stream);
+                if (he == hipSuccess)
+                    break;
+                if (he != hipErrorNotSupported)
+                    return fail(GNNB_ERR_HIP, "narrow PNA layer launch failed: %s", hipGetErrorString(he));
+            }
             // h_ij = Wpre [x_i || x_j] + b  ==  (Wpre[:, :F] x_i + b) + Wpre[:, F:] x_j
             float *q = ws->tmp0, *pp = ws->tmp1;
             // degree-class form (gnnb_workspace_set_max_degree; decided here: it folds the destination's pre-NN term into x's

@@ -1695,6 +1695,7 @@ def test_pna_product_and_aggregate_in_one_kernel(dev, hidden, out, layers, fin):
     ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
     outs = {}
     try:
+        runtime.set_option("pna_first", 0)  # (the narrow first layer's own one-kernel form has its test below: only pna_pagg varies here)
         for name, pagg, promise_n, promise_d in (("one_kernel", 1, maxn, maxdeg), ("two_kernels", 0, maxn, maxdeg), ("beyond_stage", 1, 58, maxdeg), ("general", 1, maxn, 0)):
             runtime.set_option("pna_pagg", pagg)
             cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise_n)
@@ -1706,6 +1707,7 @@ def test_pna_product_and_aggregate_in_one_kernel(dev, hidden, out, layers, fin):
                 assert np.array_equal(outs[name], cm.forward(*to_dev(batch, dev)).cpu().numpy())
     finally:
         runtime.set_option("pna_pagg", 1)
+        runtime.set_option("pna_first", 1)
     scale = max(1.0, float(np.abs(ref).max()))
     for k, v in outs.items():
         assert np.isfinite(v).all() and np.abs(v - ref).max() < TOL * scale, k
@@ -1756,6 +1758,59 @@ def test_sage_first_layer_forms_the_next_layers_mean(dev, fin, hidden, out, laye
         assert np.isfinite(v).all() and np.abs(v - ref).max() < TOL * scale, k
     for k in ("two_kernels", "beyond_stage", "no_promise"):
         assert np.array_equal(outs["one_kernel"], outs[k]), k
+
+
+@pytest.mark.parametrize("fin,hidden,out,layers,act,delta", [(11, 128, 128, 3, "relu", 1.0), (9, 128, 64, 2, "tanh", 2.5), (12, 64, 64, 2, "gelu", 1.0),
+                                                             (10, 128, 128, 1, "sigmoid", 0.7), (11, 64, 128, 2, "relu", 1.0)])
+def test_narrow_pna_layer_in_one_kernel(dev, fin, hidden, out, layers, act, delta):
+    """k_pna_first (round 5): a PNA layer with a narrow input (the first) as ONE kernel -- pre-NN per node, the four statistics with
+    the destination term, degree scalers, the 13F-wide lin-folded post-NN product on the matrix cores -- with whole graphs
+    staged in LDS (max_graph_nodes promise).  Against the layer-by-layer kernels (`pna_first` 0), with and without the degree
+    promise, and the oracle, every graph; isolated nodes (degree 0: the scalers of degree 1, all statistics 0), a hub of degree
+    13 (the CSR tail), empty / one-node graphs, a 57-node ring (the largest graph a stage takes with 8-row tiles), delta != 1,
+    hidden 64 (first layer 9 / 12 -> 64)."""
+    model = make_model("pna", in_dim=fin, hidden=hidden, out_dim=out, layers=layers, act=act, pools=("add", "mean", "max"), task_out=2, seed=fin + hidden + layers)
+    for conv in model.gnn_convs:  # (GNNModel never passes delta: reference models.py:546-548; set it on the layers)
+        conv.delta_scaler = delta
+        conv.conv.aggr_module.avg_deg_log = torch.Tensor([delta])
+    rng = np.random.default_rng(fin * 7)
+    base = synthetic.make_batch("qm9", 400, seed=23)
+    empty = (np.zeros((0, fin), np.float32), np.zeros((0, 2), np.int32))
+
+    def regraph(g):
+        x, e = base.graph(g)
+        return rng.uniform(-1, 1, (x.shape[0], fin)).astype(np.float32), e
+
+    one = (rng.uniform(-1, 1, (1, fin)).astype(np.float32), np.zeros((0, 2), np.int32))
+    lone = (rng.uniform(-1, 1, (3, fin)).astype(np.float32), np.zeros((0, 2), np.int32))
+    star = (rng.uniform(-1, 1, (14, fin)).astype(np.float32), np.array([[i, 0] for i in range(1, 14)] + [[0, i] for i in range(1, 14)], np.int32))
+    ring = np.stack([np.arange(57), (np.arange(57) + 1) % 57], 1)
+    big = (rng.uniform(-1, 1, (57, fin)).astype(np.float32), np.concatenate([ring, ring[:, ::-1]]).astype(np.int32))
+    graphs = [empty, star] + [regraph(g) for g in range(200)] + [one, lone, big, empty] + [regraph(g) for g in range(200, 400)] + [star, one]
+    batch = pack_graphs(graphs)
+    maxn, maxdeg = int(np.diff(batch.node_ptr).max()), int(np.bincount(batch.coo[:, 1]).max())
+    assert maxn == 57 and maxdeg == 13
+    assert abs(model.spec()["pna_delta"] - delta) < 1e-6
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    outs = {}
+    try:
+        for name, on, promise_n, promise_d in (("one_kernel", 1, maxn, 0), ("layer_by_layer", 0, maxn, 0), ("one_kernel_classes", 1, maxn, maxdeg),
+                                               ("layer_by_layer_classes", 0, maxn, maxdeg), ("beyond_stage", 1, 58, 0)):
+            runtime.set_option("pna_first", on)
+            cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise_n)
+            cm.set_max_degree(promise_d)
+            outs[name] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            cm.check()
+            if name == "one_kernel":
+                assert np.array_equal(outs[name], cm.forward(*to_dev(batch, dev)).cpu().numpy())
+    finally:
+        runtime.set_option("pna_first", 1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for k, v in outs.items():
+        assert np.isfinite(v).all() and np.abs(v - ref).max() < TOL * scale, k
+    assert np.abs(outs["one_kernel"] - outs["layer_by_layer"]).max() < 3e-5 * scale
+    assert np.array_equal(outs["layer_by_layer"], outs["beyond_stage"])
+    assert not np.array_equal(outs["one_kernel"], outs["layer_by_layer"])  # (the new kernel is what ran)
 
 
 def test_pna_degree_promise_with_an_empty_batch(dev):
