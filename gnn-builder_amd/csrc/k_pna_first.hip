@@ -27,7 +27,7 @@ struct PfStage {
 };
 
 template <int ACT, int KQ, int CSL>
-__global__ __launch_bounds__(PF_WG, 2) void k_pna_first(const float *__restrict__ x, int F, const int4 *__restrict__ node_rec,
+__global__ __launch_bounds__(PF_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pna_first(const float *__restrict__ x, int F, const int4 *__restrict__ node_rec,
                                                         const int32_t *__restrict__ col, const float *__restrict__ amp,
                                                         const float *__restrict__ att, const int32_t *__restrict__ tile_first,
                                                         const int32_t *__restrict__ tile_edge, int num_tiles, int N, int E,
@@ -171,11 +171,23 @@ __global__ __launch_bounds__(PF_WG, 2) void k_pna_first(const float *__restrict_
         {
             const int l8 = tid & 7;
             for (int i = tid >> 3; i < rows; i += PF_WG / 8) {
+                // (the row and a weight row as straight-line batches of LDS reads: as a loop over a run-time F every product waited
+                // for its own two reads -- 33 dependent round trips per lane and stage)
+                float xr[12];
+#pragma unroll
+                for (int f = 0; f < 12; f++)
+                    xr[f] = xs[i * F + (f < F ? f : 0)];
                 for (int o = l8; o < F2; o += 8) {
                     const int r = o < F ? o : o - F, c0 = o < F ? 0 : F;
+                    const float *wrow = SW + r * F2 + c0;
+                    float wv[12];
+#pragma unroll
+                    for (int f = 0; f < 12; f++)
+                        wv[f] = wrow[f < F ? f : 0];
                     float s = o < F ? SW[F * F2 + o] : 0.0f;
-                    for (int f = 0; f < F; f++)
-                        s += SW[r * F2 + c0 + f] * xs[i * F + f];
+#pragma unroll
+                    for (int f = 0; f < 12; f++)
+                        s += f < F ? wv[f] * xr[f] : 0.0f;
                     PQ[i * LDP + o] = s;
                 }
             }
@@ -245,21 +257,38 @@ __global__ __launch_bounds__(PF_WG, 2) void k_pna_first(const float *__restrict_
 #pragma unroll
         for (int uu = 0; uu < UPW; uu++)
             acc[uu] = (f32x4){bq.x, bq.y, bq.z, bq.w};
+        // (units in PAIRS: two independent accumulator chains, the next k block's fragments of both requested before the current
+        // block's MFMAs -- as one chain per unit with its fragment read in front of every four MFMAs the phase ran at 55 % of the
+        // matrix rate: 64 of the kernel's 108 us)
 #pragma unroll
-        for (int uu = 0; uu < UPW; uu++) {
-            const int u = rg + uu * NRG;
-            if (u < units) { // (wave-uniform)
-                const float *ap = A0 + (u * 16 + li) * LD0 + 4 * lg;
+        for (int uu = 0; uu < UPW; uu += 2) {
+            const int uA = rg + uu * NRG, uB = rg + (uu + 1) * NRG;
+            const bool onB = uu + 1 < UPW && uB < units; // (wave-uniform)
+            if (uA < units) {
+                const float *apA = A0 + (uA * 16 + li) * LD0 + 4 * lg;
+                const float *apB = onB ? A0 + (uB * 16 + li) * LD0 + 4 * lg : apA;
+                float4 a0 = *reinterpret_cast<const float4 *>(apA), a1 = *reinterpret_cast<const float4 *>(apB);
 #pragma unroll
                 for (int q = 0; q < KQ; q++) {
-                    const float4 a4 = *reinterpret_cast<const float4 *>(ap + 16 * q);
+                    float4 n0 = a0, n1 = a1;
+                    if (q + 1 < KQ) {
+                        n0 = *reinterpret_cast<const float4 *>(apA + 16 * (q + 1));
+                        n1 = *reinterpret_cast<const float4 *>(apB + 16 * (q + 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         if (q * 4 + t >= nsteps) // (wave-uniform: this k step holds no column)
                             break;
-                        const float av = t == 0 ? a4.x : (t == 1 ? a4.y : (t == 2 ? a4.z : a4.w));
-                        acc[uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + t], av, acc[uu], 0, 0, 0);
+                        const float av0 = t == 0 ? a0.x : (t == 1 ? a0.y : (t == 2 ? a0.z : a0.w));
+                        const float av1 = t == 0 ? a1.x : (t == 1 ? a1.y : (t == 2 ? a1.z : a1.w));
+                        acc[uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + t], av0, acc[uu], 0, 0, 0);
+                        if (uu + 1 < UPW && onB)
+                            acc[uu + 1 < UPW ? uu + 1 : uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q * 4 + t], av1, acc[uu + 1 < UPW ? uu + 1 : uu], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    a0 = n0;
+                    a1 = n1;
                 }
             }
         }
