@@ -16,7 +16,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 OUT=$R/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
-WL=${@:-c2 c3 c3t c4 c5 ref6_gcn ref6_gin ref6_sage ref6_pna}
+WL=${@:-c2 c3 c4 c5}
 for w in $WL; do
   extra="--no-other-configs"   # (every tracked line keeps its cpu_baseline; the brief c3 / c4 / c5 legs of the default line would mix their kernels into the c2 table)
   python3 bench.py --workload $w --steps 100 $extra > "$OUT/plain_$w.log" 2>&1
