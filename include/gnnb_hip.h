@@ -348,15 +348,27 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *                                workgroup, 176-row stages; 2 (default) = 1 wherever it exists (input widths <= 16)
  *   gemm_tail_split (default 2)  the last, partial round of tiles of the large-K GEMM (k_linear_dma): 2 = for K >= 1024 cut
  *                                along K into equal runs over all resident workgroups, parts added up in run order by the last
- *                                workgroup at each tile (stream-K: one summation order per shape, not the unsplit one; 64 MB
- *                                of scratch per (device, stream), allocated at the first such launch on a stream that is not
- *                                being captured -- warm up before capturing a graph), row slices otherwise; 1 = row slices
- *                                (bit-identical to 0); 0 = whole tiles
+ *                                workgroup at each tile (stream-K: one summation order per shape, not the unsplit one; its 64 MB
+ *                                of scratch belong to the workspace whose forward launches the GEMM -- the stand-alone
+ *                                gnnb_linear keeps one per (device, stream) and takes row slices while that stream is being
+ *                                captured), row slices otherwise; 1 = row slices (bit-identical to 0); 0 = whole tiles
  *   pna_fold_lin (default 1)     PNA: `lin` folded into the post-NN at upload (W' = W_lin W_post, formed in double): one 13F-wide
  *                                GEMM per layer with skip + activation (+ the last layer's pooling) in its epilogue; 0 = the
  *                                reference's two products.  Off under the fixed-point emulation
  *   pna_classes (default 1)      PNA under a max_degree promise (gnnb_workspace_set_max_degree): the degree-class form; 0 = the
  *                                general 13 F-wide form
+ *   pna_pagg (default 1)         PNA under both promises (max_degree: no destination term; max_graph_nodes: whole graphs fit a 64-row
+ *                                stage): a full-width layer's source-half product and its aggregate in one kernel, the per-node
+ *                                messages never in HBM (k_pna_pagg); 0 = GEMM + aggregate kernel
+ *   pna_first (default 1)        PNA with the max_graph_nodes promise: a narrow-input layer (F <= 12: the first) as ONE kernel --
+ *                                pre-NN, statistics, scalers, 13F-wide post-NN (k_pna_first); 0 = layer-by-layer kernels
+ *   sage_first_mean (default 1)  GraphSAGE with the max_graph_nodes promise (<= 49): the narrow first layer keeps its output rows in
+ *                                LDS and forms the next layer's mean aggregate there (k_sage_first_mean); 0 = k_conv_first + the
+ *                                aggregate kernel (bit-identical)
+ *   zf_head (default 0)          the 2-layer GCN stack kernel also runs the MLP head on the graphs it pooled (one launch for conv
+ *                                stack + pooling + head): measured slower than the separate readout
+ *   agg_form (default 0)         gather-aggregate kernel: 0 = LDS ring, 1 = barrier-free register gather (k_aggregate_rg) wherever
+ *                                it exists, 2 = that form for PNA only; agg_rg_r / agg_rg_wgs / agg_rg_flags shape its launch
  *   fold_skip (default 1)        GraphSAGE: a middle layer's skip connection (y = conv(x) + x) as + I on the root weights -- x is an
  *                                operand of the layer's GEMM anyway -- instead of a second read of x in the epilogue (PNA's folded
  *                                forms always carry it); 0 = the skip operand
