@@ -5,8 +5,9 @@ GCN / GIN without a promise -- against the oracle on one GPU.
     python tests/fuzz_layerwise.py [cases] [seed]      (lives under tests/: it uses the oracle, which is test infrastructure)
 Random model shapes (depth 1..4, hidden 16 / 32 / 64 / 128 / 256, out any multiple of 4 up to hidden, F_in 1..32, activation,
 skip, pool order), random batches (molecule-like graphs + empty graphs, isolated nodes, self loops, duplicate edges, hubs,
-a few graphs of 100-400 nodes), PNA with and without a max_degree promise, every option combination of fuse_pool / pna_fold_lin / first_ring / gemm_tail_split drawn
-per case.  Prints the worst error; exits non-zero on a mismatch."""
+a few graphs of 100-400 nodes), PNA with and without a max_degree promise, every option combination of fuse_pool / pna_fold_lin / first_ring / gemm_tail_split
+/ pna_pagg / pna_first / sage_first_mean drawn per case; half of the GraphSAGE / PNA cases keep every graph within 20 / 49 / 57 nodes and
+set the max_graph_nodes promise (round 5: the LDS-staged kernels k_sage_first_mean, k_pna_pagg, k_pna_first need it).  Prints the worst error; exits non-zero on a mismatch."""
 import sys
 from pathlib import Path
 
@@ -25,7 +26,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
 worst = 0.0
-OPTS = {"fuse_pool": 1, "pna_fold_lin": 1, "first_ring": 1, "gemm_tail_split": 2}
+OPTS = {"fuse_pool": 1, "pna_fold_lin": 1, "first_ring": 1, "gemm_tail_split": 2, "pna_pagg": 1, "pna_first": 1, "sage_first_mean": 1}
 try:
     for it in range(cases):
         conv = str(rng.choice(["sage", "pna", "sage", "pna", "gcn", "gin"]))
@@ -33,6 +34,10 @@ try:
         h = int(rng.choice([16, 32, 64, 128, 256] if conv != "pna" else [16, 32, 64, 128]))
         out = h if (conv == "gin" or rng.integers(0, 2)) else 4 * int(rng.integers(1, h // 4 + 1))
         fin = int(rng.integers(1, 33))
+        if conv == "pna" and rng.integers(0, 2):
+            fin = int(rng.integers(8, 13))  # (the widths k_pna_first takes)
+        small = conv in ("sage", "pna") and bool(rng.integers(0, 2))  # every graph within a stage: the promise can be made
+        nmax = int(rng.choice([20, 49, 57])) if small else 60
         act = str(rng.choice(["relu", "gelu", "sigmoid", "tanh"]))
         skip = bool(rng.integers(0, 2))
         pools = tuple(rng.permutation(["add", "mean", "max"])[: int(rng.integers(1, 4))])
@@ -43,7 +48,7 @@ try:
         graphs = []
         for g in range(B):
             r = rng.integers(0, 40)
-            n = 0 if r == 0 else (int(rng.integers(100, 400)) if r == 1 and g % 7 == 0 else int(np.clip(rng.normal(mean_n, mean_n / 3), 1, 60)))
+            n = 0 if r == 0 else (int(rng.integers(100, 400)) if r == 1 and g % 7 == 0 and not small else int(np.clip(rng.normal(mean_n, mean_n / 3), 1, nmax)))
             e = int(rng.integers(0, 3 * n + 1)) if n else 0
             coo = np.stack([rng.integers(0, max(n, 1), e), rng.integers(0, max(n, 1), e)], 1).astype(np.int32) if e else np.zeros((0, 2), np.int32)
             if n and rng.integers(0, 30) == 0 and it % 3 == 0:   # a hub: many edges into one node (a third of the cases)
@@ -57,7 +62,8 @@ try:
         for k, v in opts.items():
             runtime.set_option(k, v)
         ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
-        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1))
+        promise_n = int(np.diff(batch.node_ptr).max()) if small else 0
+        cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise_n)
         maxdeg = int(np.bincount(batch.coo[:, 1]).max()) if batch.num_edges else 0
         promise = 0
         if conv == "pna" and 0 < maxdeg <= 15 and rng.integers(0, 4) != 0:
@@ -70,7 +76,7 @@ try:
         err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
         worst = max(worst, err)
         tag = (f"{conv} L={L} h={h} out={out} F={fin} {act} skip={int(skip)} pools={'/'.join(pools)} B={B} N={batch.num_nodes} "
-               f"opts={opts} maxdeg={maxdeg} promise={promise} path={cm.last_path()}")
+               f"opts={opts} maxdeg={maxdeg} promise={promise} max_graph_nodes={promise_n} path={cm.last_path()}")
         if not err < 1e-4 or not np.array_equal(got, again):
             print(f"FAIL case {it}: {tag}: err={err:.3e} repeatable={np.array_equal(got, again)}")
             sys.exit(1)

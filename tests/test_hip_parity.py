@@ -1813,6 +1813,44 @@ def test_narrow_pna_layer_in_one_kernel(dev, fin, hidden, out, layers, act, delt
     assert not np.array_equal(outs["one_kernel"], outs["layer_by_layer"])  # (the new kernel is what ran)
 
 
+@pytest.mark.parametrize("conv,fin,hidden", [("pna", 11, 128), ("sage", 9, 256), ("pna", 10, 64)])
+def test_lds_staged_layers_on_dense_graphs(dev, conv, fin, hidden):
+    """The LDS-staged layer kernels of round 5 (k_pna_first, k_pna_pagg, k_sage_first_mean) stage a slice of the CSR `col` array
+    for rows of degree > 4 -- 448 / 512 entries per stage.  Cliques of 12 nodes (132 directed edges, degree 11) put 600+ edges
+    into a stage: the slice does not fit and those rows read `col` from global memory instead.  Every graph against the oracle
+    and against the layer-by-layer kernels."""
+    model = make_model(conv, in_dim=fin, hidden=hidden, layers=3, act="relu", pools=("add", "mean", "max"), task_out=2, seed=fin)
+    rng = np.random.default_rng(hidden)
+    clique = np.array([[i, j] for i in range(12) for j in range(12) if i != j], np.int32)
+    base = synthetic.make_batch("qm9", 60, seed=3)
+    graphs = []
+    for g in range(60):
+        graphs.append((rng.uniform(-1, 1, (12, fin)).astype(np.float32), clique))
+        x, e = base.graph(g)
+        graphs.append((rng.uniform(-1, 1, (x.shape[0], fin)).astype(np.float32), e))
+    batch = pack_graphs(graphs)
+    maxn, maxdeg = int(np.diff(batch.node_ptr).max()), int(np.bincount(batch.coo[:, 1]).max())
+    assert maxdeg == 11
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    outs = {}
+    names = ("pna_first", "pna_pagg", "sage_first_mean")
+    try:
+        for on in (1, 0):
+            for n in names:
+                runtime.set_option(n, on)
+            cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=maxn)
+            if conv == "pna":
+                cm.set_max_degree(maxdeg)
+            outs[on] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            cm.check()
+    finally:
+        for n in names:
+            runtime.set_option(n, 1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(outs[1] - ref).max() < TOL * scale and np.abs(outs[0] - ref).max() < TOL * scale
+    assert np.abs(outs[1] - outs[0]).max() < 3e-5 * scale and not (conv == "pna" and np.array_equal(outs[1], outs[0]))
+
+
 def test_pna_degree_promise_with_an_empty_batch(dev):
     """A PNA workspace with a max_degree promise and a batch WITHOUT nodes (graph prep allows it): no class tables are written
     for such a batch, so the forward must not take the class GEMM over stale tables (round-4 advisor finding).  Every graph's
