@@ -31,6 +31,10 @@ struct BatchTables {
                          //       = floor(b N / n), start row / first CSR slot / index of the graph that row belongs to}; written
                          //       by graph prep when agg_cut_n > 0 (a power of two: the ring kernel's grid on this device)
     int32_t agg_cut_n;
+    int32_t *stage_cut;  // [stage_cut_n + 1] tile ranges of the conv-stack kernels' workgroups as WHOLE stages of the batch's global
+                         //       greedy stage list (graph prep, round 5): workgroup b walks tiles [stage_cut[b], stage_cut[b + 1]) -- every
+                         //       workgroup the same number of stages (+- 1), no ragged last stage; valid when stage_cut_n > 0 (= the grid)
+    int32_t stage_cut_n, stage_cut_cap;
     int32_t max_graph_nodes_hint; // caller's promise (0 = unknown); validated on device by prep
     int32_t promise_graphs;       // ... for graphs [0, promise_graphs) (the rest: the caller's "large segment")
     int32_t large_n, large_e;     // node / edge offset the caller named for graph promise_graphs (-1: no large segment);
@@ -100,6 +104,9 @@ struct Options {
                          //     when the max_graph_nodes promise lets whole graphs be staged (k_pna_first; default); 0 = four launches
     int pna_pagg;        // 1 = a full-width PNA layer under the degree promise + the max_graph_nodes promise: pre-NN product and aggregate in
                          //     one kernel, p never in HBM (k_pna_pagg; default); 0 = GEMM + k_aggregate_ring<PNA>
+    int stage_cut;       // 1 = k_gcn2_fused's workgroups take whole stages of the batch's global greedy stage list (graph prep plans the
+                         //     cuts: k_stage_cut -- the kernel alone 232 -> 215 us at BASELINE config 3, but the planner's latency costs the
+                         //     three-stream pipeline more than that: opt-in); 0 = equal tile counts (default)
     int zf_head;         // 1 = k_gcn2_zf runs the MLP head on the graphs it pooled (conv stack + pooling + head in one launch; default)
     int agg_form;        // gather-aggregate kernel: 0 = LDS ring (k_aggregate_ring), 1 = register gather (k_aggregate_rg: no LDS, no
                          // barrier; widths 64 / 128 / 256, kinds GCN / SUM / MEAN / SIMPLE / PNA; anything else falls back to the ring),
@@ -239,6 +246,12 @@ struct G2Deep {
     float eps = 0.0f;
 };
 long gcn2_fused_tile_capacity();
+int gcn2_fused_grid(int num_tiles);       // workgroups k_gcn2_fused launches for that many node tiles (CUs x 2, at most one per tile)
+int gcn2_fused_tile_window();             // tiles a workgroup's run may span (its tile-table window in LDS)
+// the conv-stack kernels' runs as whole stages of the global greedy stage list (k_plan.hip): cut [G + 2] (cut[G + 1] = valid)
+int stage_cut_levels(int max_tiles);
+hipError_t launch_stage_cut(const int32_t *tile_first, int num_tiles, int num_nodes, int cap, int G, int tcap, int32_t *scratch,
+                            int32_t *cut, hipStream_t s);
 hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                              int h0, const float *w1, const float *b1, int h1, int act,
                              const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const G2Deep &deep = G2Deep{});

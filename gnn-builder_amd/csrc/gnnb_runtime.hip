@@ -60,7 +60,7 @@ Options &options()
                         env_int("GNNB_FUSE_NARROW", 1), env_int("GNNB_FIRST_RING", 1),    env_int("GNNB_FUSE_ZF", 1),   env_int("GNNB_LARGE_FORK", 2), env_int("GNNB_ZF_SHAPE", 2),
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
-                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_SAGE_FIRST_MEAN", 1), env_int("GNNB_PNA_FIRST", 1), env_int("GNNB_PNA_PAGG", 1), env_int("GNNB_ZF_HEAD", 0),
+                        env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_SAGE_FIRST_MEAN", 1), env_int("GNNB_PNA_FIRST", 1), env_int("GNNB_PNA_PAGG", 1), env_int("GNNB_STAGE_CUT", 0), env_int("GNNB_ZF_HEAD", 0),
                         env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1)};
     return o;
 }
@@ -180,6 +180,7 @@ struct gnnb_workspace {
     int deg_max_tiles = 0;
     bool deg_ready = false;
     float deg_delta = 0.0f;
+    int32_t *plan_scratch = nullptr; // k_stage_cut's binary-lifting tables (GCN / GIN workspaces: stage_cut_levels x (max tiles + 1) ints)
     float prep_delta = 0.0f; // the delta the prepared batch's amp / att tables were computed with (PNA workspaces; 0: none)
     int last_path = GNNB_PATH_NONE; // which kernels the last forward on this workspace ran (gnnb_workspace_last_path)
     // "large segment" of the NEXT batches (gnnb_workspace_set_large_segment): graphs [large_g, B) -- nodes from large_n,
@@ -258,6 +259,8 @@ int gnnb_set_option(const char *name, int value)
         o.pna_first = value;
     else if (!strcmp(name, "pna_pagg") && value >= 0 && value <= 1)
         o.pna_pagg = value;
+    else if (!strcmp(name, "stage_cut") && value >= 0 && value <= 1)
+        o.stage_cut = value;
     else if (!strcmp(name, "zf_head") && value >= 0 && value <= 1)
         o.zf_head = value;
     else if (!strcmp(name, "agg_form") && value >= 0 && value <= 2)
@@ -640,7 +643,9 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     const bool pool_epi = (d.conv_type == GNNB_CONV_SAGE || d.conv_type == GNNB_CONV_PNA) && d.num_layers >= 1 && d.fpx_w <= 0;
     const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_eid = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
                  o_att = carve(N * 4), o_gcoef = carve(N * 16), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_gptr = carve((B + 1) * 4),
-                 o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4), o_cut = carve((4096 + 1) * 16),
+                 o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4), o_cut = carve((4096 + 1) * 16), o_scut = carve((1024 + 2) * 4),
+                 o_plan = carve((d.conv_type == GNNB_CONV_GCN || d.conv_type == GNNB_CONV_GIN) && d.num_layers >= 2
+                                    ? (size_t)stage_cut_levels((int)max_tiles) * (max_tiles + 1) * 4 : 0),
                  o_dwork = carve(d.conv_type == GNNB_CONV_PNA ? 1024 * 16 * 4 : 0),
                  o_dperm = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 128 * 4 : 0),
                  o_dcls = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 4 : 0),
@@ -672,6 +677,10 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->t.err = (int32_t *)(b + o_err);
     ws->t.agg_cut = (int4 *)(b + o_cut);
     ws->t.agg_cut_n = 0;
+    ws->t.stage_cut = (int32_t *)(b + o_scut);
+    ws->t.stage_cut_n = 0;
+    ws->t.stage_cut_cap = 1024;
+    ws->plan_scratch = ((d.conv_type == GNNB_CONV_GCN || d.conv_type == GNNB_CONV_GIN) && d.num_layers >= 2) ? (int32_t *)(b + o_plan) : nullptr;
     ws->t.node_graph = pool_epi ? (int32_t *)(b + o_ngraph) : nullptr;
     if (d.conv_type == GNNB_CONV_PNA) {
         ws->deg_work = (int32_t *)(b + o_dwork);
@@ -763,6 +772,8 @@ int gnnb_workspace_set_max_degree(gnnb_workspace *ws, int d)
     return GNNB_OK;
 }
 
+static BatchTables small_segment(const gnnb_workspace *ws);
+
 // ---------------------------------------------------------------------------------------
 int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *node_ptr_dev,
                     const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges,
@@ -839,6 +850,21 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
                                    (hipStream_t)stream));
     ws->prepared = true;
     ws->prep_delta = prep_delta > 0.0f ? prep_delta : 0.0f;
+    // the conv-stack kernel's workgroup runs as whole stages of the global greedy stage list (k_plan.hip), right behind the tables
+    // on the prep stream: for the batches that k_gcn2_fused takes (GIN stacks, GCN stacks deeper than two layers, the bf16x6 mode)
+    t.stage_cut_n = 0;
+    if (options().stage_cut && options().fuse_gcn2 && ws->plan_scratch && ws->max_graph_nodes > 0 && ws->desc.fpx_w <= 0 && num_nodes > 0) {
+        const bool zf_route = ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && options().fuse_zf;
+        const bool bf6 = !zf_route && options().math && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2;
+        const int cap = bf6 ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
+        const BatchTables ts = small_segment(ws);
+        const int grid = gcn2_fused_grid(ts.num_tiles);
+        if (!zf_route && ws->max_graph_nodes + t.tile_rows - 1 <= cap && grid <= t.stage_cut_cap && ts.num_tiles > 0) {
+            GNNB_HIP_TRY(launch_stage_cut(t.tile_first, ts.num_tiles, ts.num_nodes, cap, grid, gcn2_fused_tile_window(), ws->plan_scratch,
+                                          t.stage_cut, (hipStream_t)stream));
+            t.stage_cut_n = grid;
+        }
+    }
     ws->gcoef_ready = false;
     // PNA under a degree promise: the rows sorted into degree classes, right behind the tables on the prep stream
     ws->deg_ready = false;

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ b1,
     int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled, int nl,
     const float *__restrict__ Wmid, const float *__restrict__ bmid, long mid_stride, long bmid_stride, int skip,
-    float gin_eps)
+    float gin_eps, const int32_t *__restrict__ stage_cut)
 {
     const int h1out = h1; // the width of the pooled rows (GIN: the model's out_dim <= hidden; the products run hidden-wide)
     if (GIN) {
@@ -226,8 +226,14 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     int32_t *stile = reinterpret_cast<int32_t *>(REC + 3 * G2_CAP);
     int32_t *sgraph = stile + (G2_TCAP + 1);
 
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    // the workgroup's run of node tiles: whole stages of the batch's global greedy stage list when graph prep made the cut
+    // table for this grid (every workgroup the same number of stages +- 1, none ragged: round 5), else equal tile counts
+    int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
+    int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    if (stage_cut && stage_cut[gridDim.x + 1] == 1) { // (clamped: a flagged batch's table may hold anything; the run must stay in range and below the LDS window)
+        t0 = min(max(stage_cut[blockIdx.x], 0), num_tiles);
+        t1 = min(max(stage_cut[blockIdx.x + 1], t0), min(num_tiles, t0 + G2_TCAP - 1));
+    }
     if (t1 <= t0)
         return;
     // (clamped: the tables of a malformed batch may hold stale entries; a flagged batch must still stay in range)
@@ -815,6 +821,13 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 
 // node tiles the fused stack can walk in one launch: every resident workgroup keeps its run of the tile table in LDS
 // (graph prep coarsens the tiles of very large batches against this, so that they stay on the fused path)
+int gcn2_fused_tile_window() { return G2_TCAP - 1; }
+int gcn2_fused_grid(int num_tiles)
+{
+    const long long g = std::min<long long>(2LL * device_cu_count(), num_tiles);
+    return (int)std::max<long long>(g, 1);
+}
+
 long gcn2_fused_tile_capacity()
 {
     int devid = 0, cus = 256;
@@ -887,9 +900,11 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
             rc = hipErrorNotSupported;
             return;
         }
+        // (graph prep's stage cuts, when they were made for exactly this grid)
+        const int32_t *cut = (t.stage_cut && t.stage_cut_n == (int)grid) ? t.stage_cut : nullptr;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_WG), lds, s, x, f0, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_graph, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, w0, b0, h0, w1, b1, h1, p0, p1, p2,
-                           num_pools, pooled, deep.nl, deep.wmid, deep.bmid, deep.mid_stride, deep.bmid_stride, deep.skip, deep.eps);
+                           num_pools, pooled, deep.nl, deep.wmid, deep.bmid, deep.mid_stride, deep.bmid_stride, deep.skip, deep.eps, cut);
         rc = hipGetLastError();
     };
     auto go = [&](auto atag, auto q0tag, auto q1tag) {

@@ -1851,6 +1851,37 @@ def test_lds_staged_layers_on_dense_graphs(dev, conv, fin, hidden):
     assert np.abs(outs[1] - outs[0]).max() < 3e-5 * scale and not (conv == "pna" and np.array_equal(outs[1], outs[0]))
 
 
+@pytest.mark.parametrize("conv,layers,nbatch,promise", [("gin", 3, 4096, 47), ("gcn", 4, 1500, 47), ("gin", 2, 300, 29), ("gin", 3, 40, 47)])
+def test_stack_workgroups_take_whole_stages_of_the_global_stage_list(dev, conv, layers, nbatch, promise):
+    """`stage_cut` 1 (round 5, opt-in): graph prep plans the conv-stack kernel's workgroup runs as whole stages of the batch's
+    global greedy stage list (k_stage_cut: binary lifting over the stage chain) instead of equal tile counts.  Same graphs, same
+    per-graph arithmetic: against `stage_cut` 0 and the oracle on sampled graphs; batches with more and with fewer stages than
+    workgroups, a large segment behind the stack."""
+    model = make_model(conv, in_dim=9, hidden=128, layers=layers, out_dim=128, act="relu", pools=("add", "mean", "max"), task_out=2, seed=layers)
+    batch = synthetic.make_batch("molhiv" if promise == 47 else "qm9", nbatch, seed=17)
+    if promise == 29:
+        rng = np.random.default_rng(1)
+        batch = pack_graphs([(rng.uniform(-1, 1, (batch.graph(g)[0].shape[0], 9)).astype(np.float32), batch.graph(g)[1]) for g in range(nbatch)])
+    assert int(np.diff(batch.node_ptr).max()) <= promise
+    outs = {}
+    try:
+        for on in (1, 0):
+            runtime.set_option("stage_cut", on)
+            cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=promise)
+            outs[on] = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+            cm.check()
+            assert cm.last_path() == "stack"
+            assert np.array_equal(outs[on], cm.forward(*to_dev(batch, dev)).cpu().numpy())
+    finally:
+        runtime.set_option("stage_cut", 0)
+    idx = np.unique(np.concatenate([[0, nbatch - 1], np.random.default_rng(2).choice(nbatch, min(nbatch, 200), replace=False)]))
+    sub = pack_graphs([batch.graph(int(g)) for g in idx])
+    ref = O.forward_batched(model.spec(), canon(model), sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(outs[1][idx] - ref).max() < TOL * scale
+    assert np.abs(outs[1] - outs[0]).max() < 2e-5 * scale
+
+
 def test_pna_degree_promise_with_an_empty_batch(dev):
     """A PNA workspace with a max_degree promise and a batch WITHOUT nodes (graph prep allows it): no class tables are written
     for such a batch, so the forward must not take the class GEMM over stale tables (round-4 advisor finding).  Every graph's
