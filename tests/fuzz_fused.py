@@ -44,6 +44,9 @@ for it in range(cases):
             c.conv.eps.fill_(eps)
     promise = int(rng.integers(4, 170 if ZF else 62))
     shape = int(rng.integers(0, 3))
+    # (round 5) the opt-in forms drawn per case: the stage-cut planner of k_gcn2_fused, the MLP head inside k_gcn2_zf
+    runtime.set_option("stage_cut", int(rng.integers(0, 2)))
+    runtime.set_option("zf_head", int(rng.integers(0, 2)))
     if ZF:
         runtime.set_option("zf_shape", shape)
         if shape == 0 or fin > 16:
@@ -84,4 +87,6 @@ for it in range(cases):
     if it % 10 == 0:
         print(f"case {it}: {tag}: err {err:.2e}", flush=True)
     cm.close()
+runtime.set_option("stage_cut", 0)
+runtime.set_option("zf_head", 0)
 print(f"{cases} cases, worst relative error {worst:.3e}")
