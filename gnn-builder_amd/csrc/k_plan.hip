@@ -12,14 +12,13 @@
 //   S         = stages of the chain from tile 0 (greedy descent over the levels)
 //   cut[b]    = the (b S / G)-th stage boundary = a walk over the set bits of that rank;  cut[G + 1] = 1 when every run fits the
 //               kernel's tile-table window (else the kernel keeps its equal tile counts)
-// ONE workgroup.  MEASURED (round 5, BASELINE config 3): the stack kernel alone 232 -> 215 us per launch (0.47 -> 0.51 of the fp32
-// MFMA peak), one prepared forward on one stream 241 -> 222 us -- but the three-stream PIPELINE 206 -> 236-246 us per step, whatever
-// the planner's shape: tables in global memory and sixteen waves (~35 us alone), four waves (fit the free 32-register wave slot
-// beside the stack kernel, and then crawl: ~230 us co-resident, 286 us per step), or every table in LDS (~10 us alone, but it
-// needs a whole free CU, which the queued stack kernels of the other batches take first: 245 us per step).  A launch between
-// graph prep and the stack kernel of every batch is on the pipeline's critical path, and there consecutive stack kernels
-// already fill each other's ragged ends (206 us per step against a 232-us kernel).  Hence OFF by default (`stage_cut`); it pays
-// where forwards run one at a time.  Reference: none (the reference runs one graph per call).
+// ONE workgroup.  MEASURED (round 5, BASELINE config 3: 13 k tiles of 8 rows): the stack kernel alone 232 -> 215 us per launch
+// (0.47 -> 0.51 of the fp32 MFMA peak), one prepared forward on one stream 240 -> 222 us -- but the three-stream PIPELINE only
+// 202.0 -> 197.7 us per step with the cuts prepared for free (consecutive stack kernels already fill each other's ragged ends),
+// and 203.5 -> 213 us with this launch between graph prep and the stack kernel (47 us alone in the LDS form below, 24-45 us with
+// the tables in global memory; the first LDS form took 127 us alone -- found in the pipeline's kernel trace, not where it was
+// written).  Hence OFF by default (`stage_cut`); it pays where forwards run one at a time.
+// Reference: none (the reference runs one graph per call).
 #include "gnnb_device.h"
 
 namespace gnnb {
@@ -100,103 +99,130 @@ __global__ __launch_bounds__(PL_WG) void k_stage_cut(const int32_t *__restrict__
         cut[G + 1] = sOk;
 }
 
-// The same plan with every table in LDS (<= 16383 tiles: 64 KB of tile starts -- a 32-KB rank table takes their place behind
-// level 0 -- and one 32-KB level, doubled in place through registers): a round costs ~1 k cycles instead of two global round trips.  No level is kept: powers of one function
-// commute, so "the tile 2^k stages behind a chain tile is a chain tile of rank + 2^k" can be applied level by level, LOW to high --
-// every round doubles the marked prefix of the chain (a tile marked in mid-round only marks further chain tiles with their true
-// ranks: the races are benign) -- and when the levels are exhausted every chain tile knows its rank: S = the end's rank, and the
-// chain tile of rank r is the start of every workgroup b with floor(b S / G) = r.  ~10 us; it needs a free CU (128 KB of LDS),
-// which the stack kernel of the batch before releases as its first workgroups end -- where the next stack kernel could not have
-// started earlier either.
+// The same plan with every table in LDS (<= 16383 tiles; 6 bytes per tile slot: 4 of tile starts -- the 16-bit rank table takes
+// their place behind level 0 -- and 2 of one level, doubled in place through registers).  No level is kept: powers of one
+// function commute, so "the tile 2^k stages behind a chain tile is a chain tile of rank + 2^k" can be applied level by level, LOW
+// to high -- every round doubles the marked prefix of the chain (a tile marked in mid-round only marks further chain tiles with
+// their true ranks: the races are benign) -- and when the levels are exhausted every chain tile knows its rank: S = the end's
+// rank, and the chain tile of rank r is the start of every workgroup b with floor(b S / G) = r.
 static constexpr int PLDS_MAX_TILES = 16383;
+// TPT = tiles per thread (a compile-time bound keeps every per-thread table in registers and its LDS reads independent)
+template <int TPT>
 __global__ __launch_bounds__(PL_WG) void k_stage_cut_lds(const int32_t *__restrict__ tile_first, int nt, int N, int cap, int G, int tcap,
                                                          int32_t *__restrict__ cut)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int sOk, sMax;
     const int tid = threadIdx.x;
-    int32_t *stf = reinterpret_cast<int32_t *>(smem);                      // [nt + 1] tile starts (level 0 only)
-    uint16_t *A = reinterpret_cast<uint16_t *>(smem + 64 * 1024);          // [nt + 1] level k: the tile 2^k stages behind t
-    uint16_t *R = reinterpret_cast<uint16_t *>(smem);                      // [nt + 1] rank of a chain tile, 0xffff = not (yet) known
-    for (int t = tid; t <= nt; t += PL_WG)
-        stf[t] = min(max(tile_first[t], 0), N);
+    int32_t *stf = reinterpret_cast<int32_t *>(smem);                                  // [nt + 1] tile starts (level 0 only)
+    uint16_t *a = reinterpret_cast<uint16_t *>(smem + (size_t)TPT * PL_WG * 4);        // [nt + 1] level k: the tile 2^k stages behind t
+    uint16_t *R = reinterpret_cast<uint16_t *>(smem);                                  // [nt + 1] rank of a chain tile, 0xffff = not (yet) known
+    {
+        int v[TPT];
+#pragma unroll
+        for (int c = 0; c < TPT; c++) {
+            const int t = tid + c * PL_WG;
+            v[c] = t <= nt ? tile_first[t] : 0;
+        }
+#pragma unroll
+        for (int c = 0; c < TPT; c++) {
+            const int t = tid + c * PL_WG;
+            if (t <= nt)
+                stf[t] = min(max(v[c], 0), N);
+        }
+    }
     if (tid == 0) {
         sOk = 1;
         sMax = 0;
     }
     __syncthreads();
-    for (int t = tid; t <= nt; t += PL_WG) {
-        int nx = nt;
-        if (t < nt) {
-            const int nb = stf[t];
-            int lo = t + 1, hi = min(nt, t + 63);
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (stf[mid] - nb <= cap)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            nx = lo;
+    {
+        // level 0: the greedy end of a stage that begins at t (k_gcn2_fused's `plan`): TPT binary searches side by side
+        int lo[TPT], hi[TPT], nb[TPT];
+#pragma unroll
+        for (int c = 0; c < TPT; c++) {
+            const int t = min(tid + c * PL_WG, nt);
+            nb[c] = stf[t];
+            lo[c] = min(t + 1, nt);
+            hi[c] = min(nt, t + 63);
         }
-        A[t] = (uint16_t)nx;
-    }
-    __syncthreads(); // (the tile starts are dead: the ranks take their place)
-    for (int t = tid; t <= nt; t += PL_WG)
-        R[t] = t == 0 ? 0 : 0xffff;
-    __syncthreads();
-    uint16_t *a = A;
-    for (int k = 0; k < 16; k++) {
-        // ranks: a chain tile of rank r < 2^k hands rank r + 2^k to the tile 2^k stages behind it
-        for (int t = tid; t < nt; t += PL_WG) {
-            const int r = R[t];
-            if (r != 0xffff) {
-                const int j = a[t];
-                const int rj = r + (1 << k);
-                if (j < nt && rj < 0xffff) // (the end is the jump's saturation value: it takes no rank from here)
-                    R[j] = (uint16_t)rj;   // (several writers, one value: every path to a chain tile has the same length)
+        for (int step = 0; step < 6; step++) {
+#pragma unroll
+            for (int c = 0; c < TPT; c++) {
+                const int mid = (lo[c] + hi[c] + 1) >> 1;
+                const bool fits = stf[mid] - nb[c] <= cap;
+                lo[c] = lo[c] < hi[c] && fits ? mid : lo[c];
+                hi[c] = lo[c] < hi[c] && !fits ? mid - 1 : hi[c];
             }
+        }
+        __syncthreads(); // (the tile starts are dead: the ranks take their place)
+#pragma unroll
+        for (int c = 0; c < TPT; c++) {
+            const int t = tid + c * PL_WG;
+            if (t <= nt) {
+                a[t] = (uint16_t)lo[c];
+                R[t] = t == 0 ? 0 : 0xffff;
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < 16; k++) {
+        // ranks: a chain tile of rank r < 2^k hands rank r + 2^k to the tile 2^k stages behind it; and the next level's
+        // values are READ (a is only read in this phase) ...
+        int nx[TPT];
+#pragma unroll
+        for (int c = 0; c < TPT; c++) {
+            const int t = min(tid + c * PL_WG, nt);
+            const int j = a[t];
+            const int r = R[t];
+            nx[c] = a[j];
+            const int rj = r + (1 << k);
+            if (r != 0xffff && j < nt && t < nt && rj < 0xffff) // (the end is the jump's saturation value: it takes no rank from here)
+                R[j] = (uint16_t)rj;                           // (several writers, one value: every path to a chain tile has the same length)
         }
         const bool done = a[0] >= nt; // (workgroup-uniform) 2^k stages from tile 0 pass the end: every chain tile is ranked after this round
+        __syncthreads();
         if (done)
             break;
-        // the next level, doubled IN PLACE in two half-steps through registers (a second level buffer would be 32 KB more)
-        __syncthreads();
-        uint16_t nxt[(PLDS_MAX_TILES + 1 + PL_WG - 1) / PL_WG];
-        int c = 0;
-        for (int t = tid; t <= nt; t += PL_WG, c++)
-            nxt[c] = a[a[t]];
-        __syncthreads();
-        c = 0;
-        for (int t = tid; t <= nt; t += PL_WG, c++)
-            a[t] = nxt[c];
+        // ... and written IN PLACE behind the barrier (a second level buffer would be another 2 (nt + 1) bytes)
+#pragma unroll
+        for (int c = 0; c < TPT; c++) {
+            const int t = tid + c * PL_WG;
+            if (t <= nt)
+                a[t] = (uint16_t)nx[c];
+        }
         __syncthreads();
     }
-    __syncthreads();
     // the number of stages = the last chain tile's rank + 1
     {
         int m = 0;
-        for (int t = tid; t < nt; t += PL_WG) {
-            const int r = R[t];
+#pragma unroll
+        for (int c = 0; c < TPT; c++) {
+            const int t = tid + c * PL_WG;
+            const int r = t < nt ? (int)R[t] : 0xffff;
             if (r != 0xffff)
                 m = max(m, r + 1);
         }
-        if (m > 0)
+        for (int o = 32; o; o >>= 1)
+            m = max(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0 && m > 0)
             atomicMax(&sMax, m);
     }
     __syncthreads();
-    const int S = sMax;
-    if (S <= 0 || S >= 0xfff0) { // (no chain, or one too long for the 16-bit ranks: no cuts)
+    const unsigned S = (unsigned)sMax;
+    if (S == 0 || S >= 0xfff0u) { // (no chain, or one too long for the 16-bit ranks: no cuts)
         if (tid == 0)
             cut[G + 1] = 0;
         return;
     }
-    // ---- the cuts: the chain tile of rank r starts every workgroup b with floor(b S / G) = r
-    for (int t = tid; t < nt; t += PL_WG) {
-        const int r = R[t];
-        if (r == 0xffff)
+    // ---- the cuts: the chain tile of rank r starts every workgroup b with floor(b S / G) = r   (r G, b S < 2^26: 32-bit)
+#pragma unroll
+    for (int c = 0; c < TPT; c++) {
+        const int t = tid + c * PL_WG;
+        const unsigned r = t < nt ? (unsigned)R[t] : 0xffffu;
+        if (r == 0xffffu)
             continue;
-        for (long long bb = ((long long)r * G + S - 1) / S; bb < G && (bb * S) / G == r; bb++)
+        for (unsigned bb = (r * (unsigned)G + S - 1) / S; bb < (unsigned)G && (bb * S) / (unsigned)G == r; bb++)
             cut[bb] = t;
     }
     __syncthreads();
@@ -226,13 +252,26 @@ hipError_t launch_stage_cut(const int32_t *tile_first, int num_tiles, int num_no
 {
     if (num_tiles <= 0 || G <= 0)
         return hipSuccess;
-    if (num_tiles <= PLDS_MAX_TILES) { // every table in LDS
-        const size_t lds = 96 * 1024;
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_stage_cut_lds), lds);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_stage_cut_lds, dim3(1), dim3(PL_WG), lds, s, tile_first, num_tiles, num_nodes, cap, G, tcap, cut);
-            return hipGetLastError();
-        }
+    if (num_tiles <= PLDS_MAX_TILES) { // every table in LDS: 6 bytes per tile slot
+        hipError_t e = hipErrorNotSupported;
+        auto go = [&](auto tag) {
+            constexpr int TPT = decltype(tag)::value;
+            const size_t lds = (size_t)TPT * PL_WG * 6;
+            auto kern = k_stage_cut_lds<TPT>;
+            e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+            if (e != hipSuccess)
+                return;
+            hipLaunchKernelGGL(kern, dim3(1), dim3(PL_WG), lds, s, tile_first, num_tiles, num_nodes, cap, G, tcap, cut);
+            e = hipGetLastError();
+        };
+        if (num_tiles < 4 * PL_WG)
+            go(IntTag<4>{});
+        else if (num_tiles < 8 * PL_WG)
+            go(IntTag<8>{});
+        else
+            go(IntTag<16>{});
+        if (e == hipSuccess)
+            return e;
     }
     hipLaunchKernelGGL(k_stage_cut, dim3(1), dim3(PL_WG), 0, s, tile_first, num_tiles, num_nodes, cap, G, tcap, scratch,
                        stage_cut_levels(num_tiles), cut);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One bench-like timed region (sync, K steps on S streams, sync), a few times, for a rocprofv3 --kernel-trace timeline.
-usage: region_trace.py [K] [streams]"""
+usage: region_trace.py [K] [streams] [workload]"""
 import sys
 import time
 from pathlib import Path
@@ -15,7 +15,7 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 runtime.load_library(require_gpu=True)
 dev = torch.device("cuda", 0)
-w = bench.WORKLOADS["c2"]
+w = bench.WORKLOADS[sys.argv[3] if len(sys.argv) > 3 else "c2"]
 model = bench.build_model(w)
 batches = [synthetic.make_batch(w["shape"], w["batch"], seed=i) for i in range(8)]
 segs = [None] * 8
