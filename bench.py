@@ -532,6 +532,22 @@ def other_config_leg(name, dev, nstreams, budget_s=1.0):
            "value_min": graphs / max(times), "value_max": graphs / min(times),
            "path": path, "max_graph_nodes_promise": max_graph, "max_degree_promise": max_degree or None,
            "batches_in_flight": nstreams, "csr_build_in_timed_region": True}
+    if w["conv"] in ("sage", "pna"):
+        # the opt-in math mode on the layer-by-layer GEMMs that dominate these two (never `value`: see opt_in_math_bf16x6 above)
+        from gnnbuilder_amd import runtime
+        runtime.set_option("math", 1)
+        try:
+            for i in range(len(batches)):
+                pipe.step(i)
+            pipe.check()
+            t2 = [region(k) for _ in range(3)]
+        finally:
+            runtime.set_option("math", 0)
+        e2 = float(np.median(t2))
+        res["opt_in_math_bf16x6"] = {"value": graphs / e2, "unit": "graphs/s", "ms_per_step": e2 / k * 1e3, "repeats": 3,
+                                     "note": "gnnb_set_option(\"math\", 1): the layer-by-layer GEMMs as 6 bf16 MFMA products on an exact "
+                                             "hi/mid/lo split of both operands, fp32 accumulate (fp32-equivalent: per GEMM no worse than 2x "
+                                             "the fp32-MFMA kernel's error + 1e-7 against a float64 product); NOT `value`"}
     if w["conv"] in ("gcn", "gin"):
         fused = measure_fused_stack(cm, pipe.dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w.get("out_dim", w["hidden"]), len(w["pools"])),
                                     iters=50, conv=w["conv"], layers=w["layers"])

@@ -28,6 +28,9 @@ for w, name in NAMES:
     else:
         o = others[w]
         dv = f"**{fmt(o['value'])}**, {o['ms_per_step'] * 1e3:.1f} µs"
+        m = o.get("opt_in_math_bf16x6")
+        if m:
+            dv += f" (opt-in bf16x6 GEMMs, not `value`: {fmt(m['value'])}, {m['ms_per_step'] * 1e3:.1f} µs)"
     kern = re.sub(r" \(.*", "", r["kernel"])
     solo = f"`{kern}` {r['us_per_launch']:.1f} µs = {r['achieved']:.1f} TFLOP/s = **{r['frac']:.3f}**"
     ip = r.get("in_pipeline")
