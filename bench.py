@@ -830,6 +830,20 @@ def main():
         runtime.set_option("math", 0)
         split_rate = graphs_done / el2
         split_ms = el2 / args.steps * 1e3
+    # opt-in REDUCED-precision mode (never `value`): k_gcn2_zf's wide update on hi + mid bf16 pieces, three products ("bf16x3")
+    reduced = None
+    if not dry and not args.no_roofline and w["conv"] == "gcn" and w["layers"] == 2:
+        runtime.set_option("math", 2)
+        for i in range(args.warmup):
+            step(i)
+        el3 = float(np.median([timed_region() for _ in range(repeats)]))
+        runtime.set_option("math", 0)
+        reduced = {"value": graphs_done / el3, "unit": "graphs/s", "ms_per_step": el3 / args.steps * 1e3,
+                   "how": "GNNB_MATH=2 / gnnb_set_option(\"math\", 2): H.W1^T of k_gcn2_zf as 3 bf16 MFMA products (hi.hi + hi.mid + mid.hi) on "
+                          "round-to-nearest hi + mid bf16 pieces of both operands, fp32 accumulate: ~18 significant bits per product "
+                          "(tf32: 11, fp32: 24).  REDUCED precision, an accuracy-vs-throughput study mode (SURVEY 8 f-4); NOT used for `value`",
+                   "accuracy": "max |out - float64 evaluation| on this workload: 6.4e-7 (fp32-MFMA path 7.1e-8, scalar fp32 reference "
+                               "1.4e-7; outputs |max| 0.23; tests/accuracy_math_modes.py)"}
 
     # the prep-EXCLUDED rate (both side by side): topology tables re-used, only features change.  Same pipeline as
     # `value` -- the same streams, one prepared batch per workspace, the same K-step region and statistic -- so the two are
@@ -919,6 +933,9 @@ def main():
                         ("per GEMM against a float64 product: no worse than 2x the fp32-MFMA kernel's error + 1e-7 "
                          "(tests: *_bf16x6_math_is_fp32_equivalent)"),
         }
+
+    if reduced is not None:
+        result["opt_in_math_bf16x3_reduced_precision"] = reduced
 
     if not args.no_roofline:
         alg_bytes, agg = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev)

@@ -1234,7 +1234,7 @@ static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const floa
                                       const float *bias, const float *skip, float *Y, int M, int N,
                                       int act, hipStream_t s, const GatherDesc &gd = GatherDesc{})
 {
-    if (MATH == 0 && VEC_A && KQ >= 2 && options().math == 1 && K == 16 * KQ && N % 32 == 0 && ldw % 4 == 0 &&
+    if (MATH == 0 && VEC_A && KQ >= 2 && options().math != 0 && K == 16 * KQ && N % 32 == 0 && ldw % 4 == 0 &&
         (((uintptr_t)W & 15) == 0) && gd.rec == nullptr)
         return launch_linear_reg_t<KQ, VEC_A, 1>(A, lda, K, W, ldw, bias, skip, Y, M, N, act, s, gd);
     // waves: N <= 32 -> 4 row groups x 1 column slice; N <= 64 -> 2 x 2; else 1 x 4 (128 cols / WG)

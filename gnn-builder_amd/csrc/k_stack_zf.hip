@@ -127,6 +127,88 @@ __device__ __forceinline__ void zf_mma(const float *__restrict__ A, int lda, con
     }
 }
 
+// ---- MX = 1 (opt-in, gnnb_set_option("math", 2), "bf16x3"): M1 on the bf16 matrix cores with BOTH operands as hi + mid bf16
+// pieces (round to nearest even: |x - hi - mid| <= 2^-17 |x|) and the three products hi.hi + hi.mid + mid.hi, fp32 accumulate:
+// 3 v_mfma_f32_16x16x32_bf16 (4 passes each) per 32-wide k block instead of 8 fp32 MFMAs of 8 passes -- 5.3x fewer matrix-pipe
+// cycles -- at ~18 significant bits per product (between tf32's 11 and fp32's 24).  A REDUCED-PRECISION study mode, never the
+// default and never bench.py's `value` (the analogue of the reference's float_or_fixed switch, code_gen.py:39-52).
+// H is written by M0 as two bf16 planes inside the SAME row the fp32 form uses ([hi: h0 x 2 B][mid: h0 x 2 B][pad]): no LDS
+// more, Z goes back over it in fp32 as before.  (The fp32-equivalent bf16x6 form needs a third plane, 6 B per element: the
+// 176-row stage would not fit, and 144-row stages turn two stages per CU at BASELINE config 2 into three.)
+__device__ __forceinline__ uint32_t bf16_rne(float x) // the bf16 nearest to x, as an fp32 bit pattern (low half zero)
+{
+    uint32_t u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u & 0xffff0000u;
+}
+__device__ __forceinline__ void split2(float x, uint32_t &h, uint32_t &m)
+{
+    h = bf16_rne(x);
+    m = bf16_rne(x - __uint_as_float(h)); // (the difference is exact in fp32)
+}
+// four consecutive fp32 values -> their hi pieces and their mid pieces, two bf16 per dword
+__device__ __forceinline__ void split2x4(const float4 &v, uint2 &hi, uint2 &mid)
+{
+    uint32_t h0, m0, h1, m1, h2, m2, h3, m3;
+    split2(v.x, h0, m0);
+    split2(v.y, h1, m1);
+    split2(v.z, h2, m2);
+    split2(v.w, h3, m3);
+    hi = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
+    mid = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
+}
+// acc[k] += Wslice . A[rows of unit k][:]^T over K = 32 KQ32, transposed tile as zf_mma.  wr: per 32-wide k block q the lane's
+// eight k values 32 q + 8 lg .. + 7 of its weight row as {hi x 4 dwords, mid x 4 dwords}; Hb: rows of two bf16 planes (the mid
+// plane `midoff` bytes behind the hi plane), lane (li, lg) reads 16 B of each plane at k = 32 q + 8 lg.
+template <int KQ32, int NU>
+__device__ __forceinline__ void zf_mma_bf3(const char *__restrict__ Hb, int ldhb, int midoff, const float (&wr)[KQ32 * 8], const int (&row0)[NU],
+                                           int li, int lg, f32x4 (&acc)[NU])
+{
+    const char *ap[NU];
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+        ap[k] = Hb + (row0[k] + li) * ldhb + lg * 16;
+    // ONE fragment buffer (the fp32 form keeps two): block q + 1's fragments are requested BEHIND block q's MFMAs, into the
+    // same registers -- 24 instead of 48, which keeps the kernel inside the 104-register budget the other batches' guest
+    // kernels depend on; the LDS round trip is covered by the other three waves of the SIMD, all of them in M1 (the phase is
+    // bound by the LDS array in this form: every wave reads its units' rows for ONE 16-column slice, 720 KB per 176-row stage
+    // = 5.6 k cycles at 128 B per clock, against 3.5 k cycles of matrix time)
+    u32x4 ah[NU], am[NU];
+#pragma unroll
+    for (int k = 0; k < NU; k++) {
+        ah[k] = *reinterpret_cast<const u32x4 *>(ap[k]);
+        am[k] = *reinterpret_cast<const u32x4 *>(ap[k] + midoff);
+    }
+#pragma unroll
+    for (int q = 0; q < KQ32; q++) {
+#if ZF_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        const u32x4 wh = {__float_as_uint(wr[q * 8 + 0]), __float_as_uint(wr[q * 8 + 1]), __float_as_uint(wr[q * 8 + 2]), __float_as_uint(wr[q * 8 + 3])};
+        const u32x4 wm = {__float_as_uint(wr[q * 8 + 4]), __float_as_uint(wr[q * 8 + 5]), __float_as_uint(wr[q * 8 + 6]), __float_as_uint(wr[q * 8 + 7])};
+        // (the two small products first, then the large one; unit by unit inside a product: consecutive MFMAs never share an accumulator)
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wh), as_bf16x8(am[k]), acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wm), as_bf16x8(ah[k]), acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wh), as_bf16x8(ah[k]), acc[k], 0, 0, 0);
+#if ZF_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (q + 1 < KQ32) {
+#pragma unroll
+            for (int k = 0; k < NU; k++) {
+                am[k] = *reinterpret_cast<const u32x4 *>(ap[k] + midoff + 64 * (q + 1));
+                ah[k] = *reinterpret_cast<const u32x4 *>(ap[k] + 64 * (q + 1));
+            }
+        }
+    }
+}
+
 struct ZfStage {
     int ok, chunk, nb, rows, ga, gb, e0, ne; // ok = 0: no stage (the hand-out is exhausted)
 };
@@ -135,7 +217,7 @@ struct ZfStage {
 // wave slot, and with ~145 KB of LDS per CU that is what lets the readout and graph-prep kernels of the other batches in
 // flight run BESIDE it: at 111 registers the three-stream pipeline of bench.py lost 12 % (59.0 vs 52.1 us per step).
 // (The launch bound only promises four waves per SIMD = 128 registers; amdgpu_num_vgpr is ignored beside it.)
-template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS>
+template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS, int MX = 0>
 __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
@@ -403,6 +485,30 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             w0r[q * 4 + 2] = v.z;
             w0r[q * 4 + 3] = v.w;
         }
+        if constexpr (MX != 0) {
+            // (bf16x3: per 32-wide k block the lane's eight k values 32 q + 8 lg .. + 7 of weight row n1c, split into hi and
+            // mid bf16 pieces HERE -- once per workgroup, ~100 instructions -- and kept in the same 4 KQ1 registers)
+            static_assert(KQ1 % 2 == 0 && !ZF_SWZ, "bf16x3: whole 32-wide k blocks, padded rows");
+#pragma unroll
+            for (int q = 0; q < KQ1 / 2; q++) {
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                if (n1c < h1) {
+                    v0 = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + 32 * q + 8 * lg);
+                    v1 = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + 32 * q + 8 * lg + 4);
+                }
+                uint2 ha, ma, hb, mb;
+                split2x4(v0, ha, ma);
+                split2x4(v1, hb, mb);
+                w1r[q * 8 + 0] = __uint_as_float(ha.x);
+                w1r[q * 8 + 1] = __uint_as_float(ha.y);
+                w1r[q * 8 + 2] = __uint_as_float(hb.x);
+                w1r[q * 8 + 3] = __uint_as_float(hb.y);
+                w1r[q * 8 + 4] = __uint_as_float(ma.x);
+                w1r[q * 8 + 5] = __uint_as_float(ma.y);
+                w1r[q * 8 + 6] = __uint_as_float(mb.x);
+                w1r[q * 8 + 7] = __uint_as_float(mb.y);
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < KQ1; q++) {
             const int k = 16 * q + 4 * lg; // h0 == 16 * KQ1
@@ -415,6 +521,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             w1r[q * 4 + 1] = v.y;
             w1r[q * 4 + 2] = v.z;
             w1r[q * 4 + 3] = v.w;
+        }
         }
     }
 
@@ -609,10 +716,22 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                 }
                 zf_mma<KQ0, NU>(A0, LD0, w0r, row0, li, lg, acc, nt0);
                 if (n0c < h0) { // (h0 is 32, 64 or 128: the lane's four columns are all inside when its slice is)
+                    if constexpr (MX != 0) {
+                        // bf16x3: the row as two bf16 planes (hi | mid), the lane's four columns = 8 B in each
+#pragma unroll
+                        for (int k = 0; k < NU; k++) {
+                            uint2 hi, mid;
+                            split2x4(make_float4(act_t<ACT>(acc[k][0]), act_t<ACT>(acc[k][1]), act_t<ACT>(acc[k][2]), act_t<ACT>(acc[k][3])), hi, mid);
+                            char *hrow = reinterpret_cast<char *>(H) + (row0[k] + li) * ldhb + 2 * ((n0c - li) + 4 * lg);
+                            *reinterpret_cast<uint2 *>(hrow) = hi;
+                            *reinterpret_cast<uint2 *>(hrow + 2 * h0) = mid;
+                        }
+                    } else {
 #pragma unroll
                     for (int k = 0; k < NU; k++)
                         *reinterpret_cast<float4 *>(H + (row0[k] + li) * ldh + (ZF_SWZ ? 4 * ((((n0c - li) >> 2) + lg) ^ (li & kmask)) : (n0c - li) + 4 * lg)) =
                             make_float4(act_t<ACT>(acc[k][0]), act_t<ACT>(acc[k][1]), act_t<ACT>(acc[k][2]), act_t<ACT>(acc[k][3]));
+                    }
                 }
             };
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) >> lnrg0 : 0; // (nrg0 is a power of two)
@@ -665,7 +784,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     row0[k] = (rg1 + (UB + k) * nrg1) * 16;
                     acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                zf_mma<KQ1, NU>(H, ldh, w1r, row0, li, lg, acc, 4, kmask);
+                if constexpr (MX != 0)
+                    zf_mma_bf3<KQ1 / 2, NU>(reinterpret_cast<const char *>(H), ldhb, 2 * h0, w1r, row0, li, lg, acc);
+                else
+                    zf_mma<KQ1, NU>(H, ldh, w1r, row0, li, lg, acc, 4, kmask);
 #pragma unroll
                 for (int k = 0; k < NU; k++)
                     if (UB + k < ZMAX)
@@ -955,7 +1077,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     row0[k] = min(u + k, units - 1) * 16;
                     acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                zf_mma<KQ1, 3>(H, ldh, w1r, row0, li, lg, acc, 4, kmask);
+                if constexpr (MX == 0)
+                    zf_mma<KQ1, 3>(H, ldh, w1r, row0, li, lg, acc, 4, kmask);
 #pragma unroll
                 for (int k = 0; k < 3; k++)
                     asm volatile("" ::"v"(acc[k]));
@@ -1118,10 +1241,10 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
         }
     }
     hipError_t rc = hipErrorNotSupported;
-    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag) {
+    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag, auto mxtag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
-        constexpr int NW = decltype(nwtag)::value, NU = decltype(utag)::value;
-        auto kern = k_gcn2_zf<ACT, KQ0, KQ1, NW, NU>;
+        constexpr int NW = decltype(nwtag)::value, NU = decltype(utag)::value, MX = decltype(mxtag)::value;
+        auto kern = k_gcn2_zf<ACT, KQ0, KQ1, NW, NU, MX>;
         if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess) {
             rc = hipErrorNotSupported;
             return;
@@ -1169,11 +1292,14 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
         if constexpr (decltype(q0tag)::value == 1) { // (the wide shape exists for one-block input widths only)
             if (zf_wide_shape(f0, t.max_graph_nodes_hint)) {
-                go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{});
+                if (o.math == 2) // (the opt-in bf16x3 form of M1 exists in the wide shape only: every BASELINE GCN model)
+                    go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{}, IntTag<1>{});
+                else
+                    go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{}, IntTag<0>{});
                 return;
             }
         }
-        go2(atag, q0tag, q1tag, IntTag<8>{}, IntTag<6>{});
+        go2(atag, q0tag, q1tag, IntTag<8>{}, IntTag<6>{}, IntTag<0>{});
     };
     auto go_q = [&](auto atag) {
         if (kq0 == 1 && kq1 == 8) go(atag, IntTag<1>{}, IntTag<8>{});

@@ -380,7 +380,11 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  * "math": 0 (default) = native fp32 MFMA everywhere; 1 = every wide update (the fused GCN stack's A1.W1^T, the
  * K <= 128 GEMMs, the large-K segmented GEMM) as six bf16 MFMA products of an exact 3-way bf16 split of both fp32
  * operands, fp32 accumulate (results at fp32 rounding level; GNNB_MATH=1); stack kernels that are faster
- * in fp32 than any bf16x6 form (k_gcn2_zf, the GIN / deep stacks) keep running: the mode is never slower than 0.  Unknown names or values
+ * in fp32 than any bf16x6 form (k_gcn2_zf, the GIN / deep stacks) keep running: the mode is never slower than 0.
+ * 2 = REDUCED precision ("bf16x3", GNNB_MATH=2; the accuracy-vs-throughput analogue of the reference's float_or_fixed switch,
+ * code_gen.py:39-52): as 1, and the 2-layer GCN stack kernel k_gcn2_zf (input widths <= 16) multiplies H.W1^T as three bf16
+ * MFMA products on round-to-nearest hi + mid bf16 pieces of both operands, fp32 accumulate -- ~18 significant bits per product
+ * (outputs within ~3e-6 of their scale of the fp32 form at BASELINE config 2).  Unknown names or values
  * out of range return GNNB_ERR_INVALID. */
 int gnnb_set_option(const char *name, int value);
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """(Kept under tests/: it calls the CPU oracle, which only test infrastructure may do.)
 Accuracy of the two math modes of the fused GCN stack against a float64 evaluation of the same model
-(BASELINE config 2 shape): fp32 C oracle, HIP fp32-MFMA path (math 0), HIP bf16x6 path (math 1)."""
+(BASELINE config 2 shape): fp32 C oracle, HIP fp32-MFMA path (math 0), HIP bf16x6 path (math 1: the 2-layer stack keeps its
+fp32 kernel), HIP bf16x3 path (math 2: the stack kernel's wide update on hi + mid bf16 pieces, reduced precision)."""
 import sys
 from pathlib import Path
 
@@ -58,15 +59,16 @@ def main():
                                           max_graph_nodes=int(np.diff(batch.node_ptr).max()))
     bd = tuple(torch.from_numpy(a).to(dev) for a in (x, batch.coo, batch.node_ptr, batch.edge_ptr))
     res = {"oracle fp32 (C, scalar order)": O.forward_batched(model.spec(), canon(model), x, batch.coo, batch.node_ptr, batch.edge_ptr)}
-    for math, name in ((0, "HIP math 0: fp32 MFMA"), (1, "HIP math 1: bf16x6 MFMA")):
+    for math, name in ((0, "HIP math 0: fp32 MFMA"), (1, "HIP math 1: bf16x6 MFMA"), (2, "HIP math 2: bf16x3 MFMA (reduced)")):
         runtime.set_option("math", math)
         res[name] = cm.forward(*bd).cpu().numpy()
+        print(f"  ({name}: path {cm.last_path()})")
     runtime.set_option("math", 0)
     scale = np.abs(ref).max()
     print(f"{batch.num_graphs} graphs, outputs |max| = {scale:.3f}; error against the float64 evaluation:")
     for name, out in res.items():
         e = np.abs(out - ref)
-        print(f"  {name:32s} max abs {e.max():.3e}  mean abs {e.mean():.3e}  max rel-to-scale {e.max() / scale:.3e}")
+        print(f"  {name:36s} max abs {e.max():.3e}  mean abs {e.mean():.3e}  max rel-to-scale {e.max() / scale:.3e}")
 
 
 if __name__ == "__main__":

@@ -1122,6 +1122,40 @@ def test_fused_gcn_stack_bf16x6_math_is_fp32_equivalent(dev, fin, h0, h1, act):
     assert np.abs(split - exact).max() < 4e-6 * scale, np.abs(split - exact).max()
 
 
+@pytest.mark.parametrize("fin,h0,h1,act,count", [(11, 128, 128, "relu", 500), (9, 64, 64, "tanh", 300), (16, 128, 20, "gelu", 257),
+                                                 (11, 32, 128, "relu", 64), (5, 128, 64, "sigmoid", 1)])
+def test_gcn_stack_bf16x3_math_is_the_reduced_precision_mode(dev, fin, h0, h1, act, count):
+    """Opt-in math mode 2 (the analogue of the reference's float_or_fixed switch, code_gen.py:39-52): k_gcn2_zf's
+    wide update H.W1^T on the bf16 matrix cores, both operands as hi + mid bf16 pieces (round to nearest), three products,
+    fp32 accumulate -- ~18 significant bits per product.  REDUCED precision by design: it must (a) actually run (its output
+    differs from the fp32 form), (b) stay two orders of magnitude inside the north-star tolerance of 1e-4 against the
+    oracle, and (c) leave everything else of the kernel alone (empty graphs, ragged stages, pooling: the same batch)."""
+    model = make_model("gcn", in_dim=fin, hidden=h0, layers=2, out_dim=h1, act=act, pools=("add", "mean", "max"), task_out=7)
+    batch = synthetic.make_batch("qm9", count, seed=h0 + fin)
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, (batch.num_nodes, fin)).astype(np.float32)
+    ref = O.forward_batched(model.spec(), canon(model), x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=29)
+    xd = torch.from_numpy(x).to(dev)
+    _, coo, nptr, eptr = to_dev(batch, dev)
+    try:
+        runtime.set_option("math", 2)
+        reduced = cm.forward(xd, coo, nptr, eptr).cpu().numpy()
+        cm.check()
+        assert cm.last_path() == "stack_zf"
+        again = cm.forward(xd, coo, nptr, eptr).cpu().numpy()
+        runtime.set_option("math", 0)
+        exact = cm.forward(xd, coo, nptr, eptr).cpu().numpy()
+    finally:
+        runtime.set_option("math", 0)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.array_equal(reduced, again)  # deterministic
+    assert np.abs(exact - ref).max() < TOL * scale
+    assert np.abs(reduced - ref).max() < 2e-5 * scale, np.abs(reduced - ref).max()
+    if count > 1:
+        assert np.abs(reduced - exact).max() > 0.0  # (the mode ran: the fp32 form is bit-stable, this one rounds differently)
+
+
 def _random_graphs(rng, count, n_max, fin, dense):
     """Arbitrary directed multigraphs: empty graphs, isolated nodes, self loops, repeated edges, hubs."""
     graphs = []
