@@ -157,6 +157,13 @@ __device__ __forceinline__ void split2x4(const float4 &v, uint2 &hi, uint2 &mid)
     hi = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
     mid = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
 }
+// Bank conflicts: this form of M1 is bound by the LDS array, so its fragment reads must be conflict-free.  A ds_read_b128 is
+// served in four groups of sixteen lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, the same + 32); with rows 33 slots of
+// 16 B apart lane (li, lg) of the plain layout reads slot li + lg (mod 16), and rows {12..15} at chunk lg meet rows {4..11} at
+// chunk lg + 1.  The 16-B chunks of rows 4..11 (mod 16) are therefore stored with the lowest bit of their index flipped
+// (key 1): the four groups then read slots {0-3, 12-15} u {4-11}, {5-12} u {1-4, 13-16}, {2-5, 14-17} u {6-13},
+// {7-14} u {3-6, 15-18} -- sixteen different ones each.  The key is a per-lane constant on both sides (M0 writes 8 B of a chunk).
+__device__ __forceinline__ int zf_bf_key(int li) { return ((li + 4) >> 3) & 1; }
 // acc[k] += Wslice . A[rows of unit k][:]^T over K = 32 KQ32, transposed tile as zf_mma.  wr: per 32-wide k block q the lane's
 // eight k values 32 q + 8 lg .. + 7 of its weight row as {hi x 4 dwords, mid x 4 dwords}; Hb: rows of two bf16 planes (the mid
 // plane `midoff` bytes behind the hi plane), lane (li, lg) reads 16 B of each plane at k = 32 q + 8 lg.
@@ -165,9 +172,13 @@ __device__ __forceinline__ void zf_mma_bf3(const char *__restrict__ Hb, int ldhb
                                            int li, int lg, f32x4 (&acc)[NU])
 {
     const char *ap[NU];
+    {
+        int lane_off = li * ldhb + (lg ^ zf_bf_key(li)) * 16;
+        asm volatile("" : "+v"(lane_off)); // (opaque: left alone the compiler keeps the pieces of this sum live through the MFMA loop)
 #pragma unroll
-    for (int k = 0; k < NU; k++)
-        ap[k] = Hb + (row0[k] + li) * ldhb + lg * 16;
+        for (int k = 0; k < NU; k++)
+            ap[k] = Hb + row0[k] * ldhb + lane_off;
+    }
     // ONE fragment buffer (the fp32 form keeps two): block q + 1's fragments are requested BEHIND block q's MFMAs, into the
     // same registers -- 24 instead of 48, which keeps the kernel inside the 104-register budget the other batches' guest
     // kernels depend on; the LDS round trip is covered by the other three waves of the SIMD, all of them in M1 (the phase is
@@ -722,7 +733,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                         for (int k = 0; k < NU; k++) {
                             uint2 hi, mid;
                             split2x4(make_float4(act_t<ACT>(acc[k][0]), act_t<ACT>(acc[k][1]), act_t<ACT>(acc[k][2]), act_t<ACT>(acc[k][3])), hi, mid);
-                            char *hrow = reinterpret_cast<char *>(H) + (row0[k] + li) * ldhb + 2 * ((n0c - li) + 4 * lg);
+                            // (columns (n0c - li) + 4 lg .. + 3 = bytes 32 slice + 8 lg of the plane: chunk 2 slice + (lg >> 1), keyed)
+                            char *hrow = reinterpret_cast<char *>(H) + (row0[k] + li) * ldhb + 2 * (n0c - li) + 16 * ((lg >> 1) ^ zf_bf_key(li)) + 8 * (lg & 1);
                             *reinterpret_cast<uint2 *>(hrow) = hi;
                             *reinterpret_cast<uint2 *>(hrow + 2 * h0) = mid;
                         }
