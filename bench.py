@@ -833,17 +833,19 @@ def main():
     # opt-in REDUCED-precision mode (never `value`): k_gcn2_zf's wide update on hi + mid bf16 pieces, three products ("bf16x3")
     reduced = None
     if not dry and not args.no_roofline and w["conv"] == "gcn" and w["layers"] == 2:
-        runtime.set_option("math", 2)
-        for i in range(args.warmup):
-            step(i)
-        el3 = float(np.median([timed_region() for _ in range(repeats)]))
-        runtime.set_option("math", 0)
-        reduced = {"value": graphs_done / el3, "unit": "graphs/s", "ms_per_step": el3 / args.steps * 1e3,
-                   "how": "GNNB_MATH=2 / gnnb_set_option(\"math\", 2): H.W1^T of k_gcn2_zf as 3 bf16 MFMA products (hi.hi + hi.mid + mid.hi) on "
-                          "round-to-nearest hi + mid bf16 pieces of both operands, fp32 accumulate: ~18 significant bits per product "
-                          "(tf32: 11, fp32: 24).  REDUCED precision, an accuracy-vs-throughput study mode (SURVEY 8 f-4); NOT used for `value`",
-                   "accuracy": "max |out - float64 evaluation| on this workload: 6.4e-7 (fp32-MFMA path 7.1e-8, scalar fp32 reference "
-                               "1.4e-7; outputs |max| 0.23; tests/accuracy_math_modes.py)"}
+        reduced = {"how": "gnnb_set_option(\"math\", 2 | 3) / GNNB_MATH: H.W1^T of k_gcn2_zf as 3 MFMA products (hi.hi + hi.mid + mid.hi) on round-to-nearest "
+                          "hi + mid 16-bit pieces of both operands, fp32 accumulate.  2 = bf16 pieces: ~18 significant bits per product, fp32's "
+                          "range; 3 = fp16 pieces: ~22 bits, fp16's RANGE (|values| < 65504, pieces below 6e-8 lost).  REDUCED precision, "
+                          "accuracy-vs-throughput study modes (SURVEY 8 f-4); NOT used for `value`",
+                   "accuracy": "max |out - float64 evaluation| on BASELINE config 2 (outputs |max| 0.23): bf16x3 6.3e-7, f16x3 7.5e-8; fp32-MFMA path "
+                               "7.1e-8, scalar fp32 reference 1.4e-7 (tests/accuracy_math_modes.py)"}
+        for mode, key in ((2, "bf16x3"), (3, "f16x3")):
+            runtime.set_option("math", mode)
+            for i in range(args.warmup):
+                step(i)
+            el3 = float(np.median([timed_region() for _ in range(repeats)]))
+            runtime.set_option("math", 0)
+            reduced[key] = {"value": graphs_done / el3, "unit": "graphs/s", "ms_per_step": el3 / args.steps * 1e3}
 
     # the prep-EXCLUDED rate (both side by side): topology tables re-used, only features change.  Same pipeline as
     # `value` -- the same streams, one prepared batch per workspace, the same K-step region and statistic -- so the two are
@@ -935,7 +937,7 @@ def main():
         }
 
     if reduced is not None:
-        result["opt_in_math_bf16x3_reduced_precision"] = reduced
+        result["opt_in_math_reduced_precision"] = reduced
 
     if not args.no_roofline:
         alg_bytes, agg = measure_aggregate_roofline(cm, dev_batches[0], w["hidden"], dev)

@@ -390,5 +390,39 @@ __device__ __forceinline__ void split3x8(const float4 &f0, const float4 &f1, u32
     }
 }
 
+// ---- fp16 pieces ("f16x3"): x = hi + mid + e with hi = fp16(x), mid = fp16(x - hi) (round to nearest even, the difference is
+// exact in fp32): 11 + 11 significant bits, |e| <= 2^-22 |x| -- but fp16's range (|x| < 65504; pieces below 6e-8 are lost)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_f16(_Float16 a, _Float16 b)
+{
+    union {
+        f16x2 h;
+        uint32_t u;
+    } c;
+    c.h = (f16x2){a, b};
+    return c.u;
+}
+// eight consecutive fp32 values -> their hi and mid fp16 pieces as the 16-B operands of a x16 / x32 f16 MFMA
+__device__ __forceinline__ void split2x8_f16(const float4 &f0, const float4 &f1, u32x4 &h, u32x4 &m)
+{
+    const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const _Float16 h0 = (_Float16)v[2 * i], h1 = (_Float16)v[2 * i + 1];
+        h[i] = pack_f16(h0, h1);
+        m[i] = pack_f16((_Float16)(v[2 * i] - (float)h0), (_Float16)(v[2 * i + 1] - (float)h1));
+    }
+}
+__device__ __forceinline__ f16x8 as_f16x8(u32x4 v)
+{
+    union {
+        u32x4 u;
+        f16x8 h;
+    } c;
+    c.u = v;
+    return c.h;
+}
+
 
 } // namespace gnnb

@@ -291,7 +291,7 @@ int gnnb_set_option(const char *name, int value)
         o.head_split = value;
     else if (!strcmp(name, "head_small") && value >= 0 && value <= 1)
         o.head_small = value;
-    else if (!strcmp(name, "math") && value >= 0 && value <= 2)
+    else if (!strcmp(name, "math") && value >= 0 && value <= 3)
         o.math = value;
     else if (!strcmp(name, "gemm_variant") && value >= 0 && value <= 1)
         o.gemm_variant = value;

@@ -507,7 +507,43 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             s[mi] = sc[sgm][mi];
                         scaled = g.rs[sgm] != nullptr;
                     }
-                if (MATH) {
+                if (MATH == 2) {
+                    // "f16x3" (opt-in, REDUCED precision: math 3): hi + mid fp16 pieces of both operands, three products
+                    // (mid.hi, hi.mid, hi.hi) per 16-wide k block -- half the MFMAs and less than half the split work of the
+                    // bf16x6 form, ~22 significant bits per product, fp16's range (gnnb_device.h)
+#pragma unroll
+                    for (int kb2 = 0; kb2 < BK / 16; kb2++) {
+                        u32x4 ah[MC > 0 ? MC : 1], am[MC > 0 ? MC : 1], wh[NT], wm[NT];
+                        const int piece = 4 * kb2 + 2 * lh;
+#pragma unroll
+                        for (int mi = 0; mi < MC; mi++) {
+                            const int r = rbase + mi * 32 + li;
+                            float4 f0 = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
+                            float4 f1 = *reinterpret_cast<const float4 *>(a + r * BK + (((piece + 1) ^ (r & 7)) << 2));
+                            if (scaled) {
+                                f0.x *= s[mi], f0.y *= s[mi], f0.z *= s[mi], f0.w *= s[mi];
+                                f1.x *= s[mi], f1.y *= s[mi], f1.z *= s[mi], f1.w *= s[mi];
+                            }
+                            split2x8_f16(f0, f1, ah[mi], am[mi]);
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < NT; ni++) {
+                            const int r = wcol + ni * 32 + li;
+                            const float4 f0 = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
+                            const float4 f1 = *reinterpret_cast<const float4 *>(b + r * BK + (((piece + 1) ^ (r & 7)) << 2));
+                            split2x8_f16(f0, f1, wh[ni], wm[ni]);
+                        }
+                        issue_part(ic, 2 * kb2);
+                        issue_part(ic, 2 * kb2 + 1);
+#define GNNB_DMA_F3(WP, AP)                                                                                        \
+    _Pragma("unroll") for (int mi = 0; mi < MC; mi++) _Pragma("unroll") for (int ni = 0; ni < NT; ni++)             \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(WP[ni]), as_f16x8(AP[mi]), acc[mi][ni], 0, 0, 0);
+                        GNNB_DMA_F3(wm, ah)
+                        GNNB_DMA_F3(wh, am)
+                        GNNB_DMA_F3(wh, ah)
+#undef GNNB_DMA_F3
+                    }
+                } else if (MATH) {
                     // lane (li, lh) of a 32x32x16 bf16 MFMA holds k = 8 lh .. + 7 of row / column li for both operands:
                     // two 16-B pieces per fragment and k block
 #pragma unroll
@@ -1770,9 +1806,12 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             const size_t lds = (size_t)DNBUF * DBUF_B + 16; // (+ the stream-K arrival flag)
             {
                 const int mode = pep ? 1 : (rcp ? 2 : 0);
-                const void *fn = mode == 1 ? (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, 1>) : reinterpret_cast<const void *>(k_linear_dma<0, 1>))
-                                 : mode == 2 ? (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, 2>) : reinterpret_cast<const void *>(k_linear_dma<0, 2>))
-                                             : (options().math ? reinterpret_cast<const void *>(k_linear_dma<1, 0>) : reinterpret_cast<const void *>(k_linear_dma<0, 0>));
+                const int mv = options().math == 3 ? 2 : (options().math ? 1 : 0);
+                const void *fns[3][3] = {
+                    {reinterpret_cast<const void *>(k_linear_dma<0, 0>), reinterpret_cast<const void *>(k_linear_dma<0, 1>), reinterpret_cast<const void *>(k_linear_dma<0, 2>)},
+                    {reinterpret_cast<const void *>(k_linear_dma<1, 0>), reinterpret_cast<const void *>(k_linear_dma<1, 1>), reinterpret_cast<const void *>(k_linear_dma<1, 2>)},
+                    {reinterpret_cast<const void *>(k_linear_dma<2, 0>), reinterpret_cast<const void *>(k_linear_dma<2, 1>), reinterpret_cast<const void *>(k_linear_dma<2, 2>)}};
+                const void *fn = fns[mv][mode];
                 hipError_t e = ensure_dynamic_lds(fn, lds);
                 if (e != hipSuccess)
                     return e;
@@ -1808,7 +1847,14 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
 #define GNNB_DMA_LAUNCH(MATHV, MODEV)                                                                                    \
     hipLaunchKernelGGL((k_linear_dma<MATHV, MODEV>), dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, \
                        tn, split_from, split, pe, sk, rc)
-            if (options().math) {
+            if (options().math == 3) { // (f16x3: opt-in, reduced precision)
+                if (pep)
+                    GNNB_DMA_LAUNCH(2, 1);
+                else if (rcp)
+                    GNNB_DMA_LAUNCH(2, 2);
+                else
+                    GNNB_DMA_LAUNCH(2, 0);
+            } else if (options().math) {
                 if (pep)
                     GNNB_DMA_LAUNCH(1, 1);
                 else if (rcp)

@@ -146,16 +146,46 @@ __device__ __forceinline__ void split2(float x, uint32_t &h, uint32_t &m)
     h = bf16_rne(x);
     m = bf16_rne(x - __uint_as_float(h)); // (the difference is exact in fp32)
 }
-// four consecutive fp32 values -> their hi pieces and their mid pieces, two bf16 per dword
+// MX = 2 ("f16x3"): the same with fp16 pieces (v_cvt_f16_f32 rounds to nearest even; x - hi is exact in fp32): 11 + 11 significant
+// bits, |x - hi - mid| <= 2^-22 |x| -- sixteen times closer than the bf16 pieces at the same cost -- but fp16's RANGE: values of
+// 65520 and above become inf, and pieces below 6e-8 are lost (an absolute floor of 3e-8 per operand element).
+// four consecutive fp32 values -> their hi pieces and their mid pieces, two 16-bit pieces per dword
+template <int MX>
 __device__ __forceinline__ void split2x4(const float4 &v, uint2 &hi, uint2 &mid)
 {
-    uint32_t h0, m0, h1, m1, h2, m2, h3, m3;
-    split2(v.x, h0, m0);
-    split2(v.y, h1, m1);
-    split2(v.z, h2, m2);
-    split2(v.w, h3, m3);
-    hi = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
-    mid = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
+    if constexpr (MX == 2) {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        _Float16 h[4], m[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            h[i] = (_Float16)x[i];
+            m[i] = (_Float16)(x[i] - (float)h[i]);
+        }
+        hi = make_uint2(pack_f16(h[0], h[1]), pack_f16(h[2], h[3]));
+        mid = make_uint2(pack_f16(m[0], m[1]), pack_f16(m[2], m[3]));
+    } else {
+        uint32_t h0, m0, h1, m1, h2, m2, h3, m3;
+        split2(v.x, h0, m0);
+        split2(v.y, h1, m1);
+        split2(v.z, h2, m2);
+        split2(v.w, h3, m3);
+        hi = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
+        mid = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
+    }
+}
+template <int MX>
+__device__ __forceinline__ f32x4 mfma_16x3(u32x4 a, u32x4 b, f32x4 c)
+{
+    if constexpr (MX == 2) {
+        union {
+            u32x4 u;
+            f16x8 h;
+        } ca, cb;
+        ca.u = a;
+        cb.u = b;
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(ca.h, cb.h, c, 0, 0, 0);
+    } else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
 }
 // Bank conflicts: this form of M1 is bound by the LDS array, so its fragment reads must be conflict-free.  A ds_read_b128 is
 // served in four groups of sixteen lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, the same + 32); with rows 33 slots of
@@ -167,7 +197,7 @@ __device__ __forceinline__ int zf_bf_key(int li) { return ((li + 4) >> 3) & 1; }
 // acc[k] += Wslice . A[rows of unit k][:]^T over K = 32 KQ32, transposed tile as zf_mma.  wr: per 32-wide k block q the lane's
 // eight k values 32 q + 8 lg .. + 7 of its weight row as {hi x 4 dwords, mid x 4 dwords}; Hb: rows of two bf16 planes (the mid
 // plane `midoff` bytes behind the hi plane), lane (li, lg) reads 16 B of each plane at k = 32 q + 8 lg.
-template <int KQ32, int NU>
+template <int MX, int KQ32, int NU>
 __device__ __forceinline__ void zf_mma_bf3(const char *__restrict__ Hb, int ldhb, int midoff, const float (&wr)[KQ32 * 8], const int (&row0)[NU],
                                            int li, int lg, f32x4 (&acc)[NU])
 {
@@ -200,13 +230,13 @@ __device__ __forceinline__ void zf_mma_bf3(const char *__restrict__ Hb, int ldhb
         // (the two small products first, then the large one; unit by unit inside a product: consecutive MFMAs never share an accumulator)
 #pragma unroll
         for (int k = 0; k < NU; k++)
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wh), as_bf16x8(am[k]), acc[k], 0, 0, 0);
+            acc[k] = mfma_16x3<MX>(wh, am[k], acc[k]);
 #pragma unroll
         for (int k = 0; k < NU; k++)
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wm), as_bf16x8(ah[k]), acc[k], 0, 0, 0);
+            acc[k] = mfma_16x3<MX>(wm, ah[k], acc[k]);
 #pragma unroll
         for (int k = 0; k < NU; k++)
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wh), as_bf16x8(ah[k]), acc[k], 0, 0, 0);
+            acc[k] = mfma_16x3<MX>(wh, ah[k], acc[k]);
 #if ZF_PIN
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -508,8 +538,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     v1 = *reinterpret_cast<const float4 *>(W1 + (size_t)n1c * h0 + 32 * q + 8 * lg + 4);
                 }
                 uint2 ha, ma, hb, mb;
-                split2x4(v0, ha, ma);
-                split2x4(v1, hb, mb);
+                split2x4<MX>(v0, ha, ma);
+                split2x4<MX>(v1, hb, mb);
                 w1r[q * 8 + 0] = __uint_as_float(ha.x);
                 w1r[q * 8 + 1] = __uint_as_float(ha.y);
                 w1r[q * 8 + 2] = __uint_as_float(hb.x);
@@ -732,7 +762,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #pragma unroll
                         for (int k = 0; k < NU; k++) {
                             uint2 hi, mid;
-                            split2x4(make_float4(act_t<ACT>(acc[k][0]), act_t<ACT>(acc[k][1]), act_t<ACT>(acc[k][2]), act_t<ACT>(acc[k][3])), hi, mid);
+                            split2x4<MX>(make_float4(act_t<ACT>(acc[k][0]), act_t<ACT>(acc[k][1]), act_t<ACT>(acc[k][2]), act_t<ACT>(acc[k][3])), hi, mid);
                             // (columns (n0c - li) + 4 lg .. + 3 = bytes 32 slice + 8 lg of the plane: chunk 2 slice + (lg >> 1), keyed)
                             char *hrow = reinterpret_cast<char *>(H) + (row0[k] + li) * ldhb + 2 * (n0c - li) + 16 * ((lg >> 1) ^ zf_bf_key(li)) + 8 * (lg & 1);
                             *reinterpret_cast<uint2 *>(hrow) = hi;
@@ -797,7 +827,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 if constexpr (MX != 0)
-                    zf_mma_bf3<KQ1 / 2, NU>(reinterpret_cast<const char *>(H), ldhb, 2 * h0, w1r, row0, li, lg, acc);
+                    zf_mma_bf3<MX, KQ1 / 2, NU>(reinterpret_cast<const char *>(H), ldhb, 2 * h0, w1r, row0, li, lg, acc);
                 else
                     zf_mma<KQ1, NU>(H, ldh, w1r, row0, li, lg, acc, 4, kmask);
 #pragma unroll
@@ -1304,8 +1334,10 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
         if constexpr (decltype(q0tag)::value == 1) { // (the wide shape exists for one-block input widths only)
             if (zf_wide_shape(f0, t.max_graph_nodes_hint)) {
-                if (o.math == 2) // (the opt-in bf16x3 form of M1 exists in the wide shape only: every BASELINE GCN model)
+                if (o.math == 2) // (the opt-in bf16x3 / f16x3 forms of M1 exist in the wide shape only: every BASELINE GCN model)
                     go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{}, IntTag<1>{});
+                else if (o.math == 3)
+                    go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{}, IntTag<2>{});
                 else
                     go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{}, IntTag<0>{});
                 return;

@@ -59,7 +59,7 @@ def main():
                                           max_graph_nodes=int(np.diff(batch.node_ptr).max()))
     bd = tuple(torch.from_numpy(a).to(dev) for a in (x, batch.coo, batch.node_ptr, batch.edge_ptr))
     res = {"oracle fp32 (C, scalar order)": O.forward_batched(model.spec(), canon(model), x, batch.coo, batch.node_ptr, batch.edge_ptr)}
-    for math, name in ((0, "HIP math 0: fp32 MFMA"), (1, "HIP math 1: bf16x6 MFMA"), (2, "HIP math 2: bf16x3 MFMA (reduced)")):
+    for math, name in ((0, "HIP math 0: fp32 MFMA"), (1, "HIP math 1: bf16x6 MFMA"), (2, "HIP math 2: bf16x3 MFMA (reduced)"), (3, "HIP math 3: f16x3 MFMA (reduced)")):
         runtime.set_option("math", math)
         res[name] = cm.forward(*bd).cpu().numpy()
         print(f"  ({name}: path {cm.last_path()})")

@@ -20,7 +20,7 @@ cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, 
 bd = tuple(torch.from_numpy(a).to(dev) for a in (batch.x, batch.coo, batch.node_ptr, batch.edge_ptr))
 out = torch.empty((batch.num_graphs, model.spec().out_dim if hasattr(model.spec(), "out_dim") else 19), device=dev)
 ref = None
-for math in (0, 2, 0, 2):
+for math in (0, 2, 3, 0, 2, 3):
     runtime.set_option("math", math)
     o = cm.forward(*bd)
     torch.cuda.synchronize()
