@@ -533,21 +533,25 @@ def other_config_leg(name, dev, nstreams, budget_s=1.0):
            "path": path, "max_graph_nodes_promise": max_graph, "max_degree_promise": max_degree or None,
            "batches_in_flight": nstreams, "csr_build_in_timed_region": True}
     if w["conv"] in ("sage", "pna"):
-        # the opt-in math mode on the layer-by-layer GEMMs that dominate these two (never `value`: see opt_in_math_bf16x6 above)
+        # the opt-in math modes on the layer-by-layer GEMMs that dominate these two (never `value`: see opt_in_math_* above)
         from gnnbuilder_amd import runtime
-        runtime.set_option("math", 1)
-        try:
-            for i in range(len(batches)):
-                pipe.step(i)
-            pipe.check()
-            t2 = [region(k) for _ in range(3)]
-        finally:
-            runtime.set_option("math", 0)
-        e2 = float(np.median(t2))
-        res["opt_in_math_bf16x6"] = {"value": graphs / e2, "unit": "graphs/s", "ms_per_step": e2 / k * 1e3, "repeats": 3,
-                                     "note": "gnnb_set_option(\"math\", 1): the layer-by-layer GEMMs as 6 bf16 MFMA products on an exact "
-                                             "hi/mid/lo split of both operands, fp32 accumulate (fp32-equivalent: per GEMM no worse than 2x "
-                                             "the fp32-MFMA kernel's error + 1e-7 against a float64 product); NOT `value`"}
+        notes = {1: ("opt_in_math_bf16x6", "gnnb_set_option(\"math\", 1): the layer-by-layer GEMMs as 6 bf16 MFMA products on an exact hi/mid/lo split of "
+                                            "both operands, fp32 accumulate (fp32-equivalent: per GEMM no worse than 2x the fp32-MFMA kernel's error + "
+                                            "1e-7 against a float64 product); NOT `value`"),
+                 3: ("opt_in_math_f16x3_reduced_precision", "gnnb_set_option(\"math\", 3): the same GEMMs as 3 fp16 MFMA products on round-to-nearest hi + mid "
+                                                             "fp16 pieces of both operands, fp32 accumulate: ~22 significant bits per product, fp16's RANGE "
+                                                             "(values < 65504, pieces below 6e-8 lost); REDUCED precision, NOT `value`")}
+        for mode, (key, note) in notes.items():
+            runtime.set_option("math", mode)
+            try:
+                for i in range(len(batches)):
+                    pipe.step(i)
+                pipe.check()
+                t2 = [region(k) for _ in range(3)]
+            finally:
+                runtime.set_option("math", 0)
+            e2 = float(np.median(t2))
+            res[key] = {"value": graphs / e2, "unit": "graphs/s", "ms_per_step": e2 / k * 1e3, "repeats": 3, "note": note}
     if w["conv"] in ("gcn", "gin"):
         fused = measure_fused_stack(cm, pipe.dev_batches[0], (int(batches[0].x.shape[1]), w["hidden"], w.get("out_dim", w["hidden"]), len(w["pools"])),
                                     iters=50, conv=w["conv"], layers=w["layers"])
@@ -832,6 +836,19 @@ def main():
         split_ms = el2 / args.steps * 1e3
     # opt-in REDUCED-precision mode (never `value`): k_gcn2_zf's wide update on hi + mid bf16 pieces, three products ("bf16x3")
     reduced = None
+    if not dry and not args.no_roofline and w["conv"] in ("sage", "pna"):
+        reduced = {"how": "gnnb_set_option(\"math\", 3) / GNNB_MATH=3: the layer-by-layer LDS-DMA GEMMs as 3 fp16 MFMA products (hi.hi + hi.mid + mid.hi) on "
+                          "round-to-nearest hi + mid fp16 pieces of both operands, fp32 accumulate: ~22 significant bits per product, fp16's RANGE "
+                          "(|values| < 65504, pieces below 6e-8 lost).  REDUCED precision, an accuracy-vs-throughput study mode (SURVEY 8 f-4); "
+                          "NOT used for `value`",
+                   "accuracy": "whole models against the oracle: within 2e-5 of the output scale (test_layer_by_layer_models_in_the_f16x3_math_mode); "
+                               "per GEMM against a float64 product: < 4e-6 at K = 416 .. 832 (test_large_k_gemm_bf16x6_math_is_fp32_equivalent)"}
+        runtime.set_option("math", 3)
+        for i in range(args.warmup):
+            step(i)
+        el3 = float(np.median([timed_region() for _ in range(repeats)]))
+        runtime.set_option("math", 0)
+        reduced["f16x3"] = {"value": graphs_done / el3, "unit": "graphs/s", "ms_per_step": el3 / args.steps * 1e3}
     if not dry and not args.no_roofline and w["conv"] == "gcn" and w["layers"] == 2:
         reduced = {"how": "gnnb_set_option(\"math\", 2 | 3) / GNNB_MATH: H.W1^T of k_gcn2_zf as 3 MFMA products (hi.hi + hi.mid + mid.hi) on round-to-nearest "
                           "hi + mid 16-bit pieces of both operands, fp32 accumulate.  2 = bf16 pieces: ~18 significant bits per product, fp32's "

@@ -1158,6 +1158,35 @@ def test_gcn_stack_bf16x3_math_is_the_reduced_precision_mode(dev, fin, h0, h1, a
         assert np.abs(reduced - exact).max() > 0.0  # (the mode ran: the fp32 form is bit-stable, this one rounds differently)
 
 
+@pytest.mark.parametrize("conv,shape,hidden,promise_degree", [("sage", "molhiv", 256, False), ("pna", "qm9", 128, True), ("pna", "molhiv", 128, False),
+                                                         ("gin", "molhiv", 128, False)])
+def test_layer_by_layer_models_in_the_f16x3_math_mode(dev, conv, shape, hidden, promise_degree):
+    """Opt-in math mode 3 on whole layer-by-layer models (the BASELINE config 4 / 5 shapes, small batches): the LDS-DMA GEMMs
+    multiply hi + mid fp16 pieces (three products, fp32 accumulate); aggregates, first-layer kernels and the readout stay fp32.
+    REDUCED precision: the bound is 2e-5 of the output scale against the oracle (north star: 1e-4) -- PNA's sum / std
+    aggregates times the degree scalers stay far below fp16's 65504 on molecule-shaped inputs."""
+    batch = synthetic.make_batch(shape, 700, seed=5)
+    model = make_model(conv, in_dim=int(batch.x.shape[1]), hidden=hidden, layers=3 if conv != "sage" else 2, out_dim=hidden, act="relu",
+                       pools=("add",) if conv == "gin" else ("add", "mean", "max"), task_out=3, seed=11)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    deg = int(np.bincount(batch.coo[:, 1]).max())  # (global node ids)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges)
+    if promise_degree and deg <= 15:
+        cm.set_max_degree(deg)  # (the degree-class form of PNA: k_linear_dma's row-class mode)
+    args = to_dev(batch, dev)
+    try:
+        runtime.set_option("math", 3)
+        got = cm.forward(*args).cpu().numpy()
+        cm.check()
+    finally:
+        runtime.set_option("math", 0)
+    exact = cm.forward(*args).cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(got).all()
+    assert np.abs(exact - ref).max() < TOL * scale
+    assert np.abs(got - ref).max() < 2e-5 * scale, (np.abs(got - ref).max(), scale)
+
+
 def _random_graphs(rng, count, n_max, fin, dense):
     """Arbitrary directed multigraphs: empty graphs, isolated nodes, self loops, repeated edges, hubs."""
     graphs = []
@@ -1240,6 +1269,16 @@ def test_large_k_gemm_bf16x6_math_is_fp32_equivalent(dev, M, N, F):
     e_split = (split[rows].double() - ref).abs().max().item()
     e_exact = (exact[rows].double() - ref).abs().max().item()
     assert e_split < 2e-6 and e_split < 2.0 * e_exact + 1e-7, (e_split, e_exact)
+    # math 3 (opt-in, REDUCED precision): fp16 hi + mid pieces, three products -- the same shapes, inside fp16's range here:
+    # ~22 significant bits per product; the bound leaves room for the 2^-21 per-term error over K = 13 F terms
+    try:
+        runtime.set_option("math", 3)
+        half3 = runtime.linear(segs, wd, bd, skip=sd, act="tanh").cpu()
+    finally:
+        runtime.set_option("math", 0)
+    e_half3 = (half3[rows].double() - ref).abs().max().item()
+    assert e_half3 < 4e-6, (e_half3, e_exact)
+    assert not torch.equal(half3, exact)  # (the mode ran)
 
 
 @pytest.mark.parametrize("mlp_hidden,mlp_layers,task_out,pools,h1", [

@@ -25,12 +25,19 @@ for w, name in NAMES:
     g = d["roofline_gather_aggregate"]
     if w == "c2":
         dv = f"**{fmt(drv['value'])}**, {drv['ms_per_step'] * 1e3:.1f} µs"
+        rp = drv.get("opt_in_math_reduced_precision")
+        if rp:
+            dv += (f" (opt-in REDUCED precision, not `value`: bf16x3 {fmt(rp['bf16x3']['value'])}, {rp['bf16x3']['ms_per_step'] * 1e3:.1f} µs; "
+                   f"f16x3 {fmt(rp['f16x3']['value'])}, {rp['f16x3']['ms_per_step'] * 1e3:.1f} µs)")
     else:
         o = others[w]
         dv = f"**{fmt(o['value'])}**, {o['ms_per_step'] * 1e3:.1f} µs"
-        m = o.get("opt_in_math_bf16x6")
+        m, m3 = o.get("opt_in_math_bf16x6"), o.get("opt_in_math_f16x3_reduced_precision")
         if m:
-            dv += f" (opt-in bf16x6 GEMMs, not `value`: {fmt(m['value'])}, {m['ms_per_step'] * 1e3:.1f} µs)"
+            dv += f" (opt-in, not `value`: bf16x6 GEMMs {fmt(m['value'])}, {m['ms_per_step'] * 1e3:.1f} µs"
+            if m3:
+                dv += f"; f16x3, reduced precision, {fmt(m3['value'])}, {m3['ms_per_step'] * 1e3:.1f} µs"
+            dv += ")"
     kern = re.sub(r" \(.*", "", r["kernel"])
     solo = f"`{kern}` {r['us_per_launch']:.1f} µs = {r['achieved']:.1f} TFLOP/s = **{r['frac']:.3f}**"
     ip = r.get("in_pipeline")
