@@ -212,6 +212,8 @@ static constexpr int DBUF_B = (DM + DN) * BK * 4; // 32 KB: A chunk | W chunk
 // MATH 1 (opt-in, gnnb_set_option("math", 1)): the same chunks, but each 16-wide k block is multiplied as six
 // v_mfma_f32_32x32x16_bf16 products of an exact 3-way bf16 split of BOTH operands (see split3), the fragments split in
 // the wave after the LDS read -- 24 MFMA of 8 passes instead of 32 of 16 per k block and accumulator quartet.
+// MATH 2 (opt-in, gnnb_set_option("math", 3), REDUCED precision, round 5): hi + mid fp16 pieces of both operands, three
+// v_mfma_f32_32x32x16_f16 products per k block -- ~22 significant bits per product, fp16's range (gnnb_device.h).
 // POOL: the pooling epilogue as its own instantiation (as a run-time branch of the one kernel it cost the plain GEMM 6-8 %:
 // 109 -> 101 TFLOP/s at the C4 shape, round 4)
 // RC (round 4, PNA with a degree promise): the rows of A and Y are taken through a permutation that sorts them into DEGREE
