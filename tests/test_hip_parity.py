@@ -1621,7 +1621,8 @@ FULL_SIZE = [
 ]
 
 
-def _full_size_check(dev, case, as_bench):
+def _full_size_check(dev, case, as_bench, tol=None):
+    tol = TOL if tol is None else tol
     name, conv, shape, hidden, layers, pools, B = case
     fin, out = synthetic.SHAPES[shape]["f_in"], synthetic.SHAPES[shape]["out"]
     model = make_model(conv, in_dim=fin, hidden=hidden, layers=layers, pools=pools, task_out=out, seed=B + hidden)
@@ -1646,7 +1647,7 @@ def _full_size_check(dev, case, as_bench):
     sub = pack_graphs([batch.graph(int(g)) for g in idx])
     ref = O.forward_batched(model.spec(), canon(model), sub.x, sub.coo, sub.node_ptr, sub.edge_ptr)
     err = np.abs(out_d[idx] - ref).max()
-    assert err < TOL * max(1.0, float(np.abs(ref).max())), f"{name}: max err {err:.3e} (|ref| max {np.abs(ref).max():.3e})"
+    assert err < tol * max(1.0, float(np.abs(ref).max())), f"{name}: max err {err:.3e} (|ref| max {np.abs(ref).max():.3e})"
     order = np.arange(B - 1, -1, -1)
     rev = pack_graphs([batch.graph(int(g)) for g in order])
     out_rev = cm.forward(*to_dev(rev, dev)).cpu().numpy()
@@ -1685,6 +1686,22 @@ def test_full_size_configs_3_4_5_on_the_routes_bench_times(dev, case):
             runtime.set_option("pna_classes", 1)
         diff = np.abs(out_g - out_d).max()
         assert 0.0 < diff < 5e-5 * max(1.0, float(np.abs(out_d).max()))
+
+
+@pytest.mark.parametrize("case,math,bound", [
+    (("c2", "gcn", "qm9", 128, 2, ("add", "mean", "max"), 4096), 2, 2e-5), (("c2", "gcn", "qm9", 128, 2, ("add", "mean", "max"), 4096), 3, 2e-6),
+    (FULL_SIZE[1], 1, None), (FULL_SIZE[1], 3, 2e-5), (FULL_SIZE[2], 1, None), (FULL_SIZE[2], 3, 2e-5)], ids=lambda v: v[0] if isinstance(v, tuple) else str(v))
+def test_full_size_configs_in_the_opt_in_math_modes(dev, case, math, bound):
+    """The opt-in math legs of the bench line at the sizes and on the routes the bench times them: BASELINE config 2 with the
+    reduced-precision forms of k_gcn2_zf (math 2 / 3), configs 4 and 5 with the bf16x6 (1: fp32-equivalent, the north-star
+    tolerance) and f16x3 (3: reduced, 2e-5 of the output scale) GEMMs -- the same sample of 256 graphs against the oracle and
+    the same reversed-order check as the fp32 tests."""
+    try:
+        runtime.set_option("math", math)
+        cm, _, _, _ = _full_size_check(dev, case, as_bench=True, tol=bound)
+        assert cm.last_path() == ("stack_zf" if case[0] == "c2" else "layerwise")
+    finally:
+        runtime.set_option("math", 0)
 
 
 @pytest.mark.parametrize("width", [64, 128, 256])
