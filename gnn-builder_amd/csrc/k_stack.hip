@@ -110,6 +110,97 @@ __device__ __forceinline__ void g2_mma_s(const float *__restrict__ Asrc, int lda
     }
 }
 
+// ---- "f16x3" (H3; opt-in, REDUCED precision: gnnb_set_option("math", 3)) for the deep / GIN variants: the A operand of every
+// 128-wide product lives in LDS as hi + mid fp16 pieces, two planes inside the SAME padded fp32 row ([hi: h0 x 2 B][mid: h0 x 2 B]
+// [pad]; the producer -- P1, or the product before -- writes them), the weight slice as hi + mid pieces in the same 4 KQ
+// registers; three v_mfma_f32_16x16x32_f16 per 32-wide k block (mid.hi... hi.mid, hi.hi) instead of eight fp32 MFMAs of twice
+// the passes.  Chunks of rows 4..11 (mod 16) are stored with the lowest bit of their index flipped (k_stack_zf.hip: conflict-
+// free fragment reads); ONE fragment buffer (block q + 1 requested behind block q's MFMAs: the register budget is 128).
+__device__ __forceinline__ int g2_h3_key(int row) { return ((row & 15) + 4) >> 3 & 1; }
+// byte offset of element (row, column c) inside its plane (add row * row bytes, + 2 h0 for the mid plane)
+__device__ __forceinline__ int g2_h3_off(int row, int c) { return 16 * ((c >> 3) ^ g2_h3_key(row)) + 2 * (c & 7); }
+__device__ __forceinline__ void g2_h3_store(char *buf, int rowb, int midoff, int row, int c, float x)
+{
+    const _Float16 h = (_Float16)x, m = (_Float16)(x - (float)h);
+    char *p = buf + row * rowb + g2_h3_off(row, c);
+    *reinterpret_cast<_Float16 *>(p) = h;
+    *reinterpret_cast<_Float16 *>(p + midoff) = m;
+}
+template <int ACT, int KQ32, int NU>
+__device__ __forceinline__ void g2_mma_h3(const char *__restrict__ planes, int rowb, int midoff, const float (&wr)[KQ32 * 8], float bias,
+                                          int rg, int nrg, int li, int lg, float (&v)[NU][4])
+{
+    constexpr int NA = NU == 1 ? 2 : NU;
+    f32x4 acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++)
+        acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const char *ap[NU];
+    {
+        int lane_off = li * rowb + ((lg ^ g2_h3_key(li)) << 4);
+        asm volatile("" : "+v"(lane_off));
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            ap[k] = planes + (rg + k * nrg) * 16 * rowb + lane_off;
+    }
+    u32x4 ah[NU], am[NU];
+#pragma unroll
+    for (int k = 0; k < NU; k++) {
+        ah[k] = *reinterpret_cast<const u32x4 *>(ap[k]);
+        am[k] = *reinterpret_cast<const u32x4 *>(ap[k] + midoff);
+    }
+#pragma unroll
+    for (int q = 0; q < KQ32; q++) {
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4 wh = {__float_as_uint(wr[q * 8 + 0]), __float_as_uint(wr[q * 8 + 1]), __float_as_uint(wr[q * 8 + 2]), __float_as_uint(wr[q * 8 + 3])};
+        const u32x4 wm = {__float_as_uint(wr[q * 8 + 4]), __float_as_uint(wr[q * 8 + 5]), __float_as_uint(wr[q * 8 + 6]), __float_as_uint(wr[q * 8 + 7])};
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[NU == 1 ? 1 : k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(am[k]), as_f16x8(wh), acc[NU == 1 ? 1 : k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(ah[k]), as_f16x8(wm), acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+            acc[NU == 1 ? 1 : k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(ah[k]), as_f16x8(wh), acc[NU == 1 ? 1 : k], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < KQ32) {
+#pragma unroll
+            for (int k = 0; k < NU; k++) {
+                am[k] = *reinterpret_cast<const u32x4 *>(ap[k] + midoff + 64 * (q + 1));
+                ah[k] = *reinterpret_cast<const u32x4 *>(ap[k] + 64 * (q + 1));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            v[k][r] = act_t<ACT>((NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias);
+}
+// (units in groups of at most two, as g2_mma_s)
+template <int ACT, int KQ32, int NU>
+__device__ __forceinline__ void g2_mma_h3_s(const char *__restrict__ planes, int rowb, int midoff, const float (&wr)[KQ32 * 8], float bias,
+                                            int rg, int nrg, int li, int lg, float (&v)[NU][4])
+{
+    if constexpr (NU > 2) {
+        float va[2][4], vb[NU - 2][4];
+        g2_mma_h3<ACT, KQ32, 2>(planes, rowb, midoff, wr, bias, rg, nrg, li, lg, va);
+        __builtin_amdgcn_sched_barrier(0);
+        g2_mma_h3<ACT, KQ32, NU - 2>(planes, rowb, midoff, wr, bias, rg + 2 * nrg, nrg, li, lg, vb);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v[0][r] = va[0][r];
+            v[1][r] = va[1][r];
+#pragma unroll
+            for (int k = 2; k < NU; k++)
+                v[k][r] = vb[k - 2][r];
+        }
+    } else {
+        g2_mma_h3<ACT, KQ32, NU>(planes, rowb, midoff, wr, bias, rg, nrg, li, lg, v);
+    }
+}
+
 // M1 of the fused stack with bf16x6: A1 lives in LDS as three bf16 planes [rows][h0] (16-B chunks of
 // eight k values, XOR-swizzled by row), the wave's W1 slice as three register sets.  Lane (li, lg) of a
 // 16x16x32 MFMA holds k = 32 kb + 8 lg .. + 7 of row / column li for both operands.
@@ -172,7 +263,7 @@ __device__ __forceinline__ void g2_mma_bf6(const char *__restrict__ planes, int 
 // connection behind the second), all wide matrices hidden x hidden at one stride in the blob: index 0 = layer 0's
 // second linear, 2l - 1 / 2l = layer l's first / second.  A linear whose input and output share a buffer multiplies,
 // waits for everybody at a barrier, then writes.
-template <int ACT, int KQ0, int KQ1, int MATH, bool DEEP = false, bool GIN = false>
+template <int ACT, int KQ0, int KQ1, int MATH, bool DEEP = false, bool GIN = false, bool H3 = false>
 __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
@@ -192,6 +283,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         h1 = 16 * KQ1;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!H3 || ((DEEP || GIN) && MATH == 0 && KQ1 % 2 == 0), "f16x3: the deep / GIN variants, whole 32-wide k blocks");
     constexpr int G2_UNITS = g2_units(MATH), G2_CAP = 16 * G2_UNITS;
     constexpr bool G2_SPLIT = (DEEP || GIN) && KQ1 >= 4; // wide products in groups of two units (register budget: g2_mma_s)
     constexpr bool G2_W0_PER_STAGE = DEEP || GIN || (MATH && KQ0 == 2); // the narrow slice re-read per stage (see M0)
@@ -505,6 +597,27 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         // (DEEP) this wave's weight slice + bias for a 128-wide layer -> the w1r registers: ordinary loads, requested
         // here, first used behind the next barrier
         auto load_slice = [&](const float *Wl, const float *bl, int ncol, int nlim) {
+            if constexpr (H3) {
+                // (f16x3: per 32-wide k block the lane's eight k values 32 q + 8 lg .. + 7 of weight row ncol, split into hi and
+                // mid fp16 pieces here -- ~20 instructions per block, five slices per stage -- and kept in the same registers)
+#pragma unroll
+                for (int q = 0; q < KQ1 / 2; q++) {
+                    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                    if (ncol < nlim) {
+                        v0 = *reinterpret_cast<const float4 *>(Wl + (size_t)ncol * h0 + 32 * q + 8 * lg);
+                        v1 = *reinterpret_cast<const float4 *>(Wl + (size_t)ncol * h0 + 32 * q + 8 * lg + 4);
+                    }
+                    u32x4 hh, mm;
+                    split2x8_f16(v0, v1, hh, mm);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        w1r[q * 8 + i] = __uint_as_float(hh[i]);
+                        w1r[q * 8 + 4 + i] = __uint_as_float(mm[i]);
+                    }
+                }
+                bias1 = (ncol < nlim && bl) ? bl[ncol] : 0.0f;
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < KQ1; q++) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -549,8 +662,12 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 #pragma unroll
                     for (int k = 0; k < NU; k++)
 #pragma unroll
-                        for (int r = 0; r < 4; r++)
-                            H[((rg0 + k * nrg0) * 16 + lg * 4 + r) * ldh + n0c] = v[k][r];
+                        for (int r = 0; r < 4; r++) {
+                            if constexpr (H3 && GIN) // (the next product reads H: fp16 pieces)
+                                g2_h3_store(reinterpret_cast<char *>(H), ldh * 4, 2 * h0, (rg0 + k * nrg0) * 16 + lg * 4 + r, n0c, v[k][r]);
+                            else
+                                H[((rg0 + k * nrg0) * 16 + lg * 4 + r) * ldh + n0c] = v[k][r];
+                        }
                 }
             };
             if (G2_UNITS > 3 && nu == 4)
@@ -607,7 +724,15 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                                            V::splat(GIN ? 1.0f : __int_as_float(da.w) * sdinv[j])));
                 }
                 accA = vadd(accA, vmul(selfA, V::splat(__int_as_float(da.x))));
-                if (MATH) {
+                if constexpr (H3) {
+                    // fp16 pieces: this lane's 4 values = half of a 16-B chunk of 8, in each of the two planes of row rA
+                    const _Float16 h0_ = (_Float16)accA.v.x, h1_ = (_Float16)accA.v.y, h2_ = (_Float16)accA.v.z, h3_ = (_Float16)accA.v.w;
+                    char *dstp = reinterpret_cast<char *>(A1) + rA * lda1 * 4 + g2_h3_off(rA, gl * 4);
+                    *reinterpret_cast<uint2 *>(dstp) = make_uint2(pack_f16(h0_, h1_), pack_f16(h2_, h3_));
+                    *reinterpret_cast<uint2 *>(dstp + 2 * h0) =
+                        make_uint2(pack_f16((_Float16)(accA.v.x - (float)h0_), (_Float16)(accA.v.y - (float)h1_)),
+                                   pack_f16((_Float16)(accA.v.z - (float)h2_), (_Float16)(accA.v.w - (float)h3_)));
+                } else if (MATH) {
                     // split into the three bf16 planes: this lane's 4 values = half of a 16-B chunk of 8
                     uint32_t hh[4], mm[4], ll[4];
                     split3(accA.v.x, hh[0], mm[0], ll[0]);
@@ -630,7 +755,10 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
             auto mm = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
                 float v[NU][4];
-                g2_mma_s<GNNB_ACT_NONE, KQ1, NU, G2_SPLIT>(A1, lda1, w1r, bias1, rg0, nrg0, li, lg, v);
+                if constexpr (H3)
+                    g2_mma_h3_s<GNNB_ACT_NONE, KQ1 / 2, NU>(reinterpret_cast<const char *>(A1), lda1 * 4, 2 * h0, w1r, bias1, rg0, nrg0, li, lg, v);
+                else
+                    g2_mma_s<GNNB_ACT_NONE, KQ1, NU, G2_SPLIT>(A1, lda1, w1r, bias1, rg0, nrg0, li, lg, v);
                 if (n0c < h0) {
 #pragma unroll
                     for (int k = 0; k < NU; k++)
@@ -651,14 +779,18 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 mm(IntTag<1>{});
         };
         // ---- M in place (GIN: input and output share `buf`): multiply, barrier (everybody has read), write, barrier
-        auto m_inplace = [&](float *buf, int ld, auto acttag, int next_wide) {
+        auto m_inplace = [&](float *buf, int ld, auto acttag, int next_wide, auto outtag) {
             constexpr int A = decltype(acttag)::value;
+            constexpr bool OUT_PIECES = H3 && decltype(outtag)::value != 0; // (f16x3: the NEXT product reads `buf` again)
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
             float v[G2_UNITS][4];
             auto comp = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
                 float t[NU][4];
-                g2_mma_s<A, KQ1, NU, G2_SPLIT>(buf, ld, w1r, bias1, rg0, nrg0, li, lg, t);
+                if constexpr (H3)
+                    g2_mma_h3_s<A, KQ1 / 2, NU>(reinterpret_cast<const char *>(buf), ld * 4, 2 * h0, w1r, bias1, rg0, nrg0, li, lg, t);
+                else
+                    g2_mma_s<A, KQ1, NU, G2_SPLIT>(buf, ld, w1r, bias1, rg0, nrg0, li, lg, t);
 #pragma unroll
                 for (int k = 0; k < NU; k++)
 #pragma unroll
@@ -683,8 +815,12 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 for (int k = 0; k < G2_UNITS; k++)
                     if (k < nu) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++)
-                            buf[((rg0 + k * nrg0) * 16 + lg * 4 + r) * ld + n0c] = v[k][r];
+                        for (int r = 0; r < 4; r++) {
+                            if constexpr (OUT_PIECES)
+                                g2_h3_store(reinterpret_cast<char *>(buf), ld * 4, 2 * h0, (rg0 + k * nrg0) * 16 + lg * 4 + r, n0c, v[k][r]);
+                            else
+                                buf[((rg0 + k * nrg0) * 16 + lg * 4 + r) * ld + n0c] = v[k][r];
+                        }
                     }
             }
             g2_barrier();
@@ -692,14 +828,14 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         if (GIN) {
             // layer 0's second linear, then per further layer: aggregate, first linear (ReLU, in place on A1), second
             // linear (-> H with skip + activation; the LAST one stays in the accumulators for the pooling below)
-            m_inplace(H, ldh, IntTag<ACT>{}, 1); // (its own slice, index 0, was requested in front of M0)
+            m_inplace(H, ldh, IntTag<ACT>{}, 1, IntTag<0>{}); // (its own slice, index 0, was requested in front of M0)
             G2_PT(6);
             for (int l = 1; l < nl; l++) {
                 // (layer l's first slice, index 2l - 1, is in flight since the previous in-place product)
                 phase_p1();
                 G2_PT(8);
                 g2_barrier();
-                m_inplace(A1, lda1, IntTag<GNNB_ACT_RELU>{}, 2 * l);
+                m_inplace(A1, lda1, IntTag<GNNB_ACT_RELU>{}, 2 * l, IntTag<1>{});
                 G2_PT(9);
                 if (l + 1 < nl) {
                     m_mid();
@@ -736,7 +872,9 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
             auto m1 = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
                 float v[NU][4];
-                if (MATH)
+                if constexpr (H3)
+                    g2_mma_h3_s<ACT, KQ1 / 2, NU>(reinterpret_cast<const char *>(A1), lda1 * 4, 2 * h0, w1r, bias1, 0, 1, li, lg, v);
+                else if (MATH)
                     g2_mma_bf6<ACT, KB1, NU>(reinterpret_cast<const char *>(A1), plane_b, prow_b, wh, wm, wl, bias1, li, lg, v);
                 else
                     g2_mma_s<ACT, KQ1, NU, G2_SPLIT>(A1, lda1, w1r, bias1, 0, 1, li, lg, v);
@@ -871,11 +1009,11 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     const int kq0 = f0 <= 16 ? 1 : 2, kq1 = h0 / 16;
     const int p0 = pools[0], p1 = num_pools > 1 ? pools[1] : 0, p2 = num_pools > 2 ? pools[2] : 0;
     hipError_t rc = hipErrorNotSupported;
-    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto mtag, auto dtag) {
+    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto mtag, auto dtag, auto h3tag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
         constexpr int MATH = decltype(mtag)::value;
-        constexpr bool DEEP = decltype(dtag)::value != 0, GIN = decltype(dtag)::value == 2;
-        auto kern = k_gcn2_fused<ACT, KQ0, KQ1, MATH, DEEP, GIN>;
+        constexpr bool DEEP = decltype(dtag)::value != 0, GIN = decltype(dtag)::value == 2, H3 = decltype(h3tag)::value != 0;
+        auto kern = k_gcn2_fused<ACT, KQ0, KQ1, MATH, DEEP, GIN, H3>;
         if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess) {
             rc = hipErrorNotSupported;
             return;
@@ -908,14 +1046,19 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
         rc = hipGetLastError();
     };
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
-        if (deep.gin)
-            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<2>{});
+        const bool h3 = o.math == 3; // (opt-in f16x3, REDUCED precision: the GIN and deep variants)
+        if (deep.gin && h3)
+            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<2>{}, IntTag<1>{});
+        else if (deep.gin)
+            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<2>{}, IntTag<0>{});
         else if (math)
-            go2(atag, q0tag, q1tag, IntTag<1>{}, IntTag<0>{});
+            go2(atag, q0tag, q1tag, IntTag<1>{}, IntTag<0>{}, IntTag<0>{});
+        else if (deep.nl > 2 && h3)
+            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{}, IntTag<1>{});
         else if (deep.nl > 2)
-            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{});
+            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{}, IntTag<0>{});
         else
-            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<0>{});
+            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<0>{}, IntTag<0>{});
     };
     auto go_q = [&](auto atag) {
         if (kq0 == 1 && kq1 == 8) go(atag, IntTag<1>{}, IntTag<8>{});
@@ -927,9 +1070,11 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     };
 #ifdef GNNB_DEV_FAST // development builds: only the BASELINE config 2 / 3 instantiations (seconds instead of minutes to compile)
     if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && !deep.gin && !math && deep.nl == 2)
-        go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<0>{});
+        go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<0>{}, IntTag<0>{});
+    else if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && deep.gin && o.math == 3)
+        go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<2>{}, IntTag<1>{});
     else if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && deep.gin)
-        go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<2>{});
+        go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<2>{}, IntTag<0>{});
 #else
     GNNB_DISPATCH_ACT(act, go_q)
 #endif

@@ -1158,6 +1158,32 @@ def test_gcn_stack_bf16x3_math_is_the_reduced_precision_mode(dev, fin, h0, h1, a
         assert np.abs(reduced - exact).max() > 0.0  # (the mode ran: the fp32 form is bit-stable, this one rounds differently)
 
 
+@pytest.mark.parametrize("act,skip,hidden,layers,conv", [("relu", False, 128, 3, "gin"), ("tanh", True, 64, 4, "gin"), ("gelu", False, 32, 2, "gin"),
+                                                         ("relu", True, 128, 3, "gcn"), ("sigmoid", False, 64, 5, "gcn")])
+def test_gin_and_deep_gcn_stacks_in_the_f16x3_math_mode(dev, act, skip, hidden, layers, conv):
+    """Opt-in math mode 3 in k_gcn2_fused's GIN and deep-GCN variants (round 5): every 128-wide product reads hi + mid fp16 pieces
+    that its producer (the aggregate phase or the product before) wrote into the same padded rows; three fp16 MFMA products,
+    fp32 accumulate.  REDUCED precision: 2e-5 of the output scale against the oracle; the mode must have run (its output
+    differs from the fp32 kernel's) on the stack path; empty graphs, ragged stages and the skip term are the fp32 kernel's."""
+    model = make_model(conv, in_dim=9, hidden=hidden, layers=layers, out_dim=hidden, act=act, skip=skip, pools=("add", "mean", "max"), task_out=3, seed=7)
+    batch = synthetic.make_batch("molhiv", 400, seed=layers)
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=int(np.diff(batch.node_ptr).max()))
+    args = to_dev(batch, dev)
+    try:
+        runtime.set_option("math", 3)
+        got = cm.forward(*args).cpu().numpy()
+        cm.check()
+        assert cm.last_path() == "stack"
+    finally:
+        runtime.set_option("math", 0)
+    exact = cm.forward(*args).cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(exact - ref).max() < TOL * scale
+    assert np.abs(got - ref).max() < 2e-5 * scale, (np.abs(got - ref).max(), scale)
+    assert np.abs(got - exact).max() > 0.0
+
+
 @pytest.mark.parametrize("conv,shape,hidden,promise_degree", [("sage", "molhiv", 256, False), ("pna", "qm9", 128, True), ("pna", "molhiv", 128, False),
                                                          ("gin", "molhiv", 128, False)])
 def test_layer_by_layer_models_in_the_f16x3_math_mode(dev, conv, shape, hidden, promise_degree):
