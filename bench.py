@@ -532,8 +532,8 @@ def other_config_leg(name, dev, nstreams, budget_s=1.0):
            "value_min": graphs / max(times), "value_max": graphs / min(times),
            "path": path, "max_graph_nodes_promise": max_graph, "max_degree_promise": max_degree or None,
            "batches_in_flight": nstreams, "csr_build_in_timed_region": True}
-    if w["conv"] in ("sage", "pna"):
-        # the opt-in math modes on the layer-by-layer GEMMs that dominate these two (never `value`: see opt_in_math_* above)
+    if w["conv"] in ("sage", "pna", "gin"):
+        # the opt-in math modes on the GEMMs / wide products that dominate these (never `value`: see opt_in_math_* above)
         from gnnbuilder_amd import runtime
         notes = {1: ("opt_in_math_bf16x6", "gnnb_set_option(\"math\", 1): the layer-by-layer GEMMs as 6 bf16 MFMA products on an exact hi/mid/lo split of "
                                             "both operands, fp32 accumulate (fp32-equivalent: per GEMM no worse than 2x the fp32-MFMA kernel's error + "
@@ -541,6 +541,8 @@ def other_config_leg(name, dev, nstreams, budget_s=1.0):
                  3: ("opt_in_math_f16x3_reduced_precision", "gnnb_set_option(\"math\", 3): the same GEMMs as 3 fp16 MFMA products on round-to-nearest hi + mid "
                                                              "fp16 pieces of both operands, fp32 accumulate: ~22 significant bits per product, fp16's RANGE "
                                                              "(values < 65504, pieces below 6e-8 lost); REDUCED precision, NOT `value`")}
+        if w["conv"] == "gin":
+            notes = {3: (notes[3][0], notes[3][1].replace("the same GEMMs", "the wide products of the GIN stack kernel"))}  # (math 1 leaves the GIN stack in fp32)
         for mode, (key, note) in notes.items():
             runtime.set_option("math", mode)
             try:
@@ -836,12 +838,14 @@ def main():
         split_ms = el2 / args.steps * 1e3
     # opt-in REDUCED-precision mode (never `value`): k_gcn2_zf's wide update on hi + mid bf16 pieces, three products ("bf16x3")
     reduced = None
-    if not dry and not args.no_roofline and w["conv"] in ("sage", "pna"):
-        reduced = {"how": "gnnb_set_option(\"math\", 3) / GNNB_MATH=3: the layer-by-layer LDS-DMA GEMMs as 3 fp16 MFMA products (hi.hi + hi.mid + mid.hi) on "
+    if not dry and not args.no_roofline and (w["conv"] in ("sage", "pna", "gin") or (w["conv"] == "gcn" and w["layers"] > 2)):
+        reduced = {"how": "gnnb_set_option(\"math\", 3) / GNNB_MATH=3: the layer-by-layer LDS-DMA GEMMs / the wide products of the GIN and deep-GCN "
+                          "stack kernel as 3 fp16 MFMA products (hi.hi + hi.mid + mid.hi) on "
                           "round-to-nearest hi + mid fp16 pieces of both operands, fp32 accumulate: ~22 significant bits per product, fp16's RANGE "
                           "(|values| < 65504, pieces below 6e-8 lost).  REDUCED precision, an accuracy-vs-throughput study mode (SURVEY 8 f-4); "
                           "NOT used for `value`",
-                   "accuracy": "whole models against the oracle: within 2e-5 of the output scale (test_layer_by_layer_models_in_the_f16x3_math_mode); "
+                   "accuracy": "whole models against the oracle: within 2e-5 of the output scale (test_layer_by_layer_models_in_the_f16x3_math_mode, "
+                               "test_gin_and_deep_gcn_stacks_in_the_f16x3_math_mode, test_full_size_configs_in_the_opt_in_math_modes); "
                                "per GEMM against a float64 product: < 4e-6 at K = 416 .. 832 (test_large_k_gemm_bf16x6_math_is_fp32_equivalent)"}
         runtime.set_option("math", 3)
         for i in range(args.warmup):

@@ -385,7 +385,8 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  * code_gen.py:39-52): as 1, and the 2-layer GCN stack kernel k_gcn2_zf (input widths <= 16) multiplies H.W1^T as three bf16
  * MFMA products on round-to-nearest hi + mid bf16 pieces of both operands, fp32 accumulate -- ~18 significant bits per product
  * (outputs within ~3e-6 of their scale of the fp32 form at BASELINE config 2).
- * 3 = as 2 with fp16 pieces ("f16x3", GNNB_MATH=3): ~22 significant bits per product at the same speed or better (7.5e-8 against
+ * 3 = as 2 with fp16 pieces ("f16x3", GNNB_MATH=3), also in the LDS-DMA GEMMs and in the GIN / deep-GCN stack kernel (every
+ * BASELINE config has a reduced form): ~22 significant bits per product at the same speed or better (7.5e-8 against
  * a float64 evaluation at BASELINE config 2, where the fp32 form has 7.1e-8) -- but fp16's RANGE: hidden activations or
  * weights of 65504 and above turn into inf, and pieces below 6e-8 are lost (an absolute floor per operand element).
  * Unknown names or values out of range return GNNB_ERR_INVALID. */

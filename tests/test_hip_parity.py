@@ -1716,16 +1716,17 @@ def test_full_size_configs_3_4_5_on_the_routes_bench_times(dev, case):
 
 @pytest.mark.parametrize("case,math,bound", [
     (("c2", "gcn", "qm9", 128, 2, ("add", "mean", "max"), 4096), 2, 2e-5), (("c2", "gcn", "qm9", 128, 2, ("add", "mean", "max"), 4096), 3, 2e-6),
-    (FULL_SIZE[1], 1, None), (FULL_SIZE[1], 3, 2e-5), (FULL_SIZE[2], 1, None), (FULL_SIZE[2], 3, 2e-5)], ids=lambda v: v[0] if isinstance(v, tuple) else str(v))
+    (FULL_SIZE[0], 3, 2e-5), (FULL_SIZE[1], 1, None), (FULL_SIZE[1], 3, 2e-5), (FULL_SIZE[2], 1, None), (FULL_SIZE[2], 3, 2e-5)],
+    ids=lambda v: v[0] if isinstance(v, tuple) else str(v))
 def test_full_size_configs_in_the_opt_in_math_modes(dev, case, math, bound):
     """The opt-in math legs of the bench line at the sizes and on the routes the bench times them: BASELINE config 2 with the
-    reduced-precision forms of k_gcn2_zf (math 2 / 3), configs 4 and 5 with the bf16x6 (1: fp32-equivalent, the north-star
+    reduced-precision forms of k_gcn2_zf (math 2 / 3), config 3 with the f16x3 form of the GIN stack kernel, configs 4 and 5 with the bf16x6 (1: fp32-equivalent, the north-star
     tolerance) and f16x3 (3: reduced, 2e-5 of the output scale) GEMMs -- the same sample of 256 graphs against the oracle and
     the same reversed-order check as the fp32 tests."""
     try:
         runtime.set_option("math", math)
         cm, _, _, _ = _full_size_check(dev, case, as_bench=True, tol=bound)
-        assert cm.last_path() == ("stack_zf" if case[0] == "c2" else "layerwise")
+        assert cm.last_path() == {"c2": "stack_zf", "c3": "stack"}.get(case[0], "layerwise")
     finally:
         runtime.set_option("math", 0)
 

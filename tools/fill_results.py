@@ -33,6 +33,8 @@ for w, name in NAMES:
         o = others[w]
         dv = f"**{fmt(o['value'])}**, {o['ms_per_step'] * 1e3:.1f} µs"
         m, m3 = o.get("opt_in_math_bf16x6"), o.get("opt_in_math_f16x3_reduced_precision")
+        if m3 and not m:
+            dv += f" (opt-in, not `value`: f16x3, reduced precision, {fmt(m3['value'])}, {m3['ms_per_step'] * 1e3:.1f} µs)"
         if m:
             dv += f" (opt-in, not `value`: bf16x6 GEMMs {fmt(m['value'])}, {m['ms_per_step'] * 1e3:.1f} µs"
             if m3:
