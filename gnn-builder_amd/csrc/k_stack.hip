@@ -598,8 +598,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         // here, first used behind the next barrier
         auto load_slice = [&](const float *Wl, const float *bl, int ncol, int nlim) {
             if constexpr (H3) {
-                // (f16x3: per 32-wide k block the lane's eight k values 32 q + 8 lg .. + 7 of weight row ncol, split into hi and
-                // mid fp16 pieces here -- ~20 instructions per block, five slices per stage -- and kept in the same registers)
+                // (f16x3: per 32-wide k block the lane's eight k values 32 q + 8 lg .. + 7 of weight row ncol)
 #pragma unroll
                 for (int q = 0; q < KQ1 / 2; q++) {
                     float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
@@ -607,13 +606,10 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                         v0 = *reinterpret_cast<const float4 *>(Wl + (size_t)ncol * h0 + 32 * q + 8 * lg);
                         v1 = *reinterpret_cast<const float4 *>(Wl + (size_t)ncol * h0 + 32 * q + 8 * lg + 4);
                     }
-                    u32x4 hh, mm;
-                    split2x8_f16(v0, v1, hh, mm);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        w1r[q * 8 + i] = __uint_as_float(hh[i]);
-                        w1r[q * 8 + 4 + i] = __uint_as_float(mm[i]);
-                    }
+                    // (RAW here: the loads stay in flight behind P1 / the write-back as in the fp32 form; split_slice()
+                    // turns them into pieces right in front of the product)
+                    w1r[q * 8 + 0] = v0.x, w1r[q * 8 + 1] = v0.y, w1r[q * 8 + 2] = v0.z, w1r[q * 8 + 3] = v0.w;
+                    w1r[q * 8 + 4] = v1.x, w1r[q * 8 + 5] = v1.y, w1r[q * 8 + 6] = v1.z, w1r[q * 8 + 7] = v1.w;
                 }
                 bias1 = (ncol < nlim && bl) ? bl[ncol] : 0.0f;
                 return;
@@ -629,6 +625,22 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 w1r[q * 4 + 3] = v.w;
             }
             bias1 = (ncol < nlim && bl) ? bl[ncol] : 0.0f;
+        };
+        // (f16x3) the raw slice -> hi + mid fp16 pieces, in place: ~20 instructions per k block, five slices per stage
+        auto split_slice = [&]() {
+            if constexpr (H3) {
+#pragma unroll
+                for (int q = 0; q < KQ1 / 2; q++) {
+                    u32x4 hh, mm;
+                    split2x8_f16(make_float4(w1r[q * 8 + 0], w1r[q * 8 + 1], w1r[q * 8 + 2], w1r[q * 8 + 3]),
+                                 make_float4(w1r[q * 8 + 4], w1r[q * 8 + 5], w1r[q * 8 + 6], w1r[q * 8 + 7]), hh, mm);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        w1r[q * 8 + i] = __uint_as_float(hh[i]);
+                        w1r[q * 8 + 4 + i] = __uint_as_float(mm[i]);
+                    }
+                }
+            }
         };
         if (GIN)
             load_slice(Wmid, bmid, n0c, h0); // layer 0's second linear: in flight behind M0
@@ -751,6 +763,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         // ---- M (a 128-wide layer whose output replaces H): H = act(A1 . Wl^T + bl (+ H)) -- a lane reads exactly the
         // elements it writes, so the skip term needs no second buffer
         auto m_mid = [&]() {
+            split_slice();
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
             auto mm = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
@@ -782,6 +795,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         auto m_inplace = [&](float *buf, int ld, auto acttag, int next_wide, auto outtag) {
             constexpr int A = decltype(acttag)::value;
             constexpr bool OUT_PIECES = H3 && decltype(outtag)::value != 0; // (f16x3: the NEXT product reads `buf` again)
+            split_slice();
             const int nu = rg0 < units ? (units - rg0 + nrg0 - 1) / nrg0 : 0;
             float v[G2_UNITS][4];
             auto comp = [&](auto nutag) {
@@ -869,6 +883,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         // (reference global_add/mean/max_pool, gnn_builder_lib.h:2709-2803; rows in order within a lane,
         // lane groups combined pairwise)
         if (wv < (1 << cs1l) && units > 0) {
+            split_slice();
             auto m1 = [&](auto nutag) {
                 constexpr int NU = decltype(nutag)::value;
                 float v[NU][4];
@@ -1053,10 +1068,16 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
             go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<2>{}, IntTag<0>{});
         else if (math)
             go2(atag, q0tag, q1tag, IntTag<1>{}, IntTag<0>{}, IntTag<0>{});
-        else if (deep.nl > 2 && h3)
-            go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{}, IntTag<1>{});
-        else if (deep.nl > 2)
+        else if (deep.nl > 2) {
+            // (the deep GELU variants have no register to spare -- 125 of 128 in fp32, the f16x3 form spilled one --: they keep fp32)
+            if constexpr (decltype(atag)::value != GNNB_ACT_GELU) {
+                if (h3) {
+                    go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{}, IntTag<1>{});
+                    return;
+                }
+            }
             go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{}, IntTag<0>{});
+        }
         else
             go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<0>{}, IntTag<0>{});
     };
