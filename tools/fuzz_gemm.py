@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised check of gnnb_linear's large-K path (k_linear_dma: tail slices / stream-K tail, narrow N, segments, row scalers, skip, activations,
-both math modes) against a float64 product on sampled rows.   python tools/fuzz_gemm.py [cases] [seed]"""
+the fp32 / bf16x6 / f16x3 math modes) against a float64 product on sampled rows.   python tools/fuzz_gemm.py [cases] [seed]"""
 import sys
 from pathlib import Path
 
@@ -16,7 +16,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
 acts = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "none": lambda v: v,
         "gelu": lambda v: torch.nn.functional.gelu(v)}
-worst = [0.0, 0.0]
+worst = {0: 0.0, 1: 0.0, 3: 0.0}
 for it in range(cases):
     M = int(rng.choice([rng.integers(1, 600), rng.integers(600, 40000), rng.integers(40000, 160000)]))
     N = int(rng.integers(33, 300))                      # (33 .. 64: the 32-column wave tiles)
@@ -45,16 +45,16 @@ for it in range(cases):
     wd = w.to(dev)
     bd = None if b is None else b.to(dev)
     sd = None if skip is None else skip.to(dev)
-    for math in (0, 1):
+    for math in (0, 1, 3):  # (3: f16x3, reduced precision -- its bound is looser)
         runtime.set_option("math", math)
         got = runtime.linear(segs, wd, bd, skip=sd, act=act).cpu()
         err = float((got[rows].double() - ref).abs().max())
         worst[math] = max(worst[math], err)
-        if not err < 5e-6:
+        if not err < (2e-5 if math == 3 else 5e-6):
             print(f"FAIL case {it} math={math}: M={M} N={N} ks={ks} act={act} skip={use_skip} bias={use_bias}: err {err:.3e}")
             runtime.set_option("math", 0)
             sys.exit(1)
     runtime.set_option("math", 0)
     if it % 10 == 0:
         print(f"case {it}: M={M} N={N} ks={ks} act={act}: ok", flush=True)
-print(f"{cases} cases, worst |error| fp32-MFMA {worst[0]:.2e}, bf16x6 {worst[1]:.2e}")
+print(f"{cases} cases, worst |error| fp32-MFMA {worst[0]:.2e}, bf16x6 {worst[1]:.2e}, f16x3 {worst[3]:.2e}")
