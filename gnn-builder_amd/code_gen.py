@@ -41,6 +41,9 @@ template_env = jinja2.Environment(
 )
 
 
+MATH_MODES = {"fp32": 0, "bf16x6": 1, "bf16x3": 2, "f16x3": 3}  # gnnb_set_option("math", n): include/gnnb_hip.h
+
+
 class FPX:
     """Fixed-point spec of the reference (code_gen.py:39-52).  ``Project(float_or_fixed="fixed", fpx=FPX(W, I))``
     selects the layer-boundary emulation of ``ap_fixed<W, I, AP_TRN, AP_WRAP>`` (``gnnb_model_desc.fpx_w / fpx_i``,
@@ -83,6 +86,7 @@ class Project:
         cosim_wave_debug: bool = False,
         arch: str = "gfx950",
         max_degree: Optional[int] = None,
+        math: str = "fp32",
     ):
         self.model = model
         self.dataset = dataset
@@ -103,6 +107,15 @@ class Project:
         self.max_degree = max_degree
         if self.max_degree is None and dataset is not None:
             self.max_degree = self._degree_bound_from(dataset)
+
+        # (MI355X backend only) the arithmetic of the wide products -- the throughput side of the reference's float_or_fixed
+        # switch (code_gen.py:39-52), which on an FPGA buys area and clock: "fp32" (default: native fp32 MFMA), "bf16x6"
+        # (fp32-equivalent: six bf16 products of an exact three-way split), "bf16x3" / "f16x3" (REDUCED precision: three
+        # products on hi + mid bf16 / fp16 pieces; f16x3 has fp16's range).  Emitted as gnnb_set_option("math", n) in front of
+        # gnnb_model_create -- a PROCESS-WIDE runtime option (include/gnnb_hip.h): designs in one process share it.
+        self.math = math
+        if math not in MATH_MODES:
+            raise ValueError(f"math must be one of {sorted(MATH_MODES)}")
 
         self.pyg_output_encoding = pyg_output_encoding
         valid_output_encodings = ["regression", "classification_integer", "classification_onehot"]
@@ -186,6 +199,8 @@ class Project:
             "model_top_name": self.name,
             "max_nodes": self.max_nodes,
             "max_degree": int(self.max_degree or 0),
+            "math_mode": MATH_MODES[self.math],
+            "math_name": self.math,
             "max_edges": self.max_edges,
             "in_dim": self.model.input_node_features_dim,
             "out_dim": self.model.output_features_dim,

@@ -110,11 +110,30 @@ def test_constructor_validation_matches_the_reference():
     for w_, i_ in ((8, 9), (8, 0)):  # I > W, I < 1: refused by the Project, not later by gnnb_model_create
         with pytest.raises(ValueError):
             gnnb.Project("p", model, "regression", None, "/tmp", float_or_fixed="fixed", fpx=gnnb.FPX(w_, i_))
+    # math (MI355X only): a known mode name, rendered as the runtime option in front of gnnb_model_create
+    with pytest.raises(ValueError):
+        gnnb.Project("p", model, "regression", None, "/tmp", math="fp8")
+    assert gnnb.Project("p", model, "regression", None, "/tmp").template_dict["math_mode"] == 0
+    assert gnnb.Project("p", model, "regression", None, "/tmp", math="f16x3").template_dict["math_mode"] == 3
     p = gnnb.Project("p", model, "regression", None, "/tmp")
     with pytest.raises(NotImplementedError):
         p.run_vitis_hls_synthesis()
     with pytest.raises(Exception, match="does not exist"):
         gnnb.Project("never_generated", model, "regression", None, "/tmp/gnnb_nowhere").build_and_run_testbench()
+
+
+def test_math_mode_is_rendered_into_the_generated_shim(tmp_path):
+    """Project(math=...) -> gnnb_set_option("math", n) in front of gnnb_model_create in <name>.cpp; the default emits nothing."""
+    model = make_model("gcn", hidden=8)
+    ds = ListDataset.from_batch(synthetic.make_batch("esol", 2, seed=1), y_dim=1)
+    for mode, n in (("fp32", None), ("bf16x6", 1), ("f16x3", 3)):
+        proj = gnnb.Project(f"m_{mode}", model, "regression", None, tmp_path, dataset=ds, max_nodes=64, max_edges=200, math=mode)
+        proj.gen_hw_model()
+        src = (proj.model_dir / "model.cpp").read_text()
+        if n is None:
+            assert "gnnb_set_option" not in src
+        else:
+            assert f'gnnb_set_option("math", {n});' in src and src.index("gnnb_set_option") < src.index("gnnb_model_create(&k_desc")
 
 
 def test_tb_data_reader_round_trips_what_the_writer_wrote(project):

@@ -29,6 +29,21 @@ def test_project_testbench_end_to_end(tmp_path, conv):
     assert 0 < res["model_runtime_batched"] < res["model_runtime"]
 
 
+@pytest.mark.parametrize("conv,mode,bound", [("gcn", "f16x3", 2e-5), ("sage", "bf16x6", 1e-5), ("gin", "f16x3", 2e-5)])
+def test_project_math_modes_end_to_end(tmp_path, conv, mode, bound):
+    """Project(math=...) (MI355X only: the throughput side of the reference's float_or_fixed switch, code_gen.py:39-52) through
+    the generated shim and testbench: the mode is set by the generated code itself (a separate process), MAE against the
+    PyTorch golden inside the mode's bound."""
+    model = make_model(conv, in_dim=11, hidden=128, layers=2, task_out=19)
+    ds = ListDataset.from_batch(synthetic.make_batch("qm9", 24, seed=6), y_dim=19)
+    proj = gnnb.Project(f"tbm_{conv}", model, "regression", None, tmp_path, dataset=ds, max_nodes=40, max_edges=120, math=mode)
+    proj.gen_hw_model()
+    proj.gen_testbench()
+    proj.gen_makefile()
+    res = proj.build_and_run_testbench()
+    assert res["model_output_mae"] < bound and res["model_output_mae_batched"] < bound
+
+
 def test_generated_top_symbol_via_ctypes(tmp_path):
     """Bind the generated `<name>_top` exactly as the reference's C testbench calls it."""
     import subprocess
