@@ -226,7 +226,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ skip, float *__restrict__ Y, int M,
                                                     int N, int act, int tiles_m, int tiles_n, int split_from, int split,
-                                                    PoolEpilogue pe, StreamK sk, RowClasses rc)
+                                                    PoolEpilogue pe, StreamK sk, RowClasses rc, int bias_in_lds)
 {
     constexpr bool POOL = MODE == 1, RC = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,6 +255,16 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     // the parts up IN RUN ORDER and runs the epilogue:
     // deterministic, one summation order per shape.  The launcher puts ALL tiles into that space when there is at least one
     // whole round of them (split_from = 0: no last round is left), else the tiles of the partial round.
+    // The bias through LDS (round 5, not in the row-class mode, whose bias changes with the tile): read from global memory
+    // inside the epilogue it is a load the compiler tracks, and the s_waitcnt in front of its first use also waits for the
+    // chunk DMA of the NEXT item that is in flight by then -- ~9.5 k cycles per tile with nothing of the workgroup on the
+    // matrix pipe (tools/gemm_k_sweep.py: t = 56.8 us + 0.506 us K at 4 tiles per workgroup before).  Staged HERE, in front
+    // of the first DMA issue; the epilogue reads it with ds_read (lgkmcnt).  The launcher adds the bytes when N is small enough.
+    float *const sbias = reinterpret_cast<float *>(smem + (size_t)DNBUF * DBUF_B + 16);
+    const bool bias_lds = !RC && bias != nullptr && bias_in_lds != 0;
+    if (bias_lds)
+        for (int i = tid; i < N; i += DWG)
+            sbias[i] = bias[i];
     const int num_tiles = tiles_m * tiles_n;
     const bool skm = sk.q > 0;
     const int num_items = skm ? split_from : split_from + split * (num_tiles - split_from); // handed out round-robin
@@ -659,7 +669,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             const int cg = n0 + wcol + cw;
                             float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
                             if (bias && vec && cg + 3 < N) {
-                                const float4 bv = *reinterpret_cast<const float4 *>(bias + cg);
+                                const float4 bv = bias_lds ? *reinterpret_cast<const float4 *>(sbias + cg) : *reinterpret_cast<const float4 *>(bias + cg);
                                 v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
                             } else if (bias) {
                                 v.x += cg + 0 < N ? bias[cg + 0] : 0.0f;
@@ -799,7 +809,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                             float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2],
                                                    acc[mi][ni][4 * q + 3]);
                             if (bias) {
-                                const float4 bv = *reinterpret_cast<const float4 *>(bias + colg);
+                                const float4 bv = bias_lds ? *reinterpret_cast<const float4 *>(sbias + colg) : *reinterpret_cast<const float4 *>(bias + colg);
                                 v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
                             }
                             if (skip) {
@@ -1805,7 +1815,8 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
         for (int sg = 0; sg < g.nseg && plain; sg++)
             plain = g.avec[sg] && g.wvec[sg] && (g.k[sg] % BK == 0) && (g.koff[sg] % 4 == 0);
         if (plain) {
-            const size_t lds = (size_t)DNBUF * DBUF_B + 16; // (+ the stream-K arrival flag)
+            const int bias_in_lds = (bias && !rcp && N <= 2048) ? 1 : 0; // (8 KB at most beside the two 64-KB workgroups of a CU)
+            const size_t lds = (size_t)DNBUF * DBUF_B + 16 + (bias_in_lds ? (((size_t)N * 4 + 15) & ~(size_t)15) : 0); // (+ the stream-K arrival flag, + the bias)
             {
                 const int mode = pep ? 1 : (rcp ? 2 : 0);
                 const int mv = options().math == 3 ? 2 : (options().math ? 1 : 0);
@@ -1848,7 +1859,7 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
                                       : std::min(split_from + split * (tiles - split_from), resident);
 #define GNNB_DMA_LAUNCH(MATHV, MODEV)                                                                                    \
     hipLaunchKernelGGL((k_linear_dma<MATHV, MODEV>), dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, \
-                       tn, split_from, split, pe, sk, rc)
+                       tn, split_from, split, pe, sk, rc, bias_in_lds)
             if (options().math == 3) { // (f16x3: opt-in, reduced precision)
                 if (pep)
                     GNNB_DMA_LAUNCH(2, 1);
