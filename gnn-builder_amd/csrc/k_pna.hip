@@ -32,7 +32,13 @@ struct PaStage {
     int ok, nb, rows, e0, ne, next_t;
 };
 
-template <int KQ>
+// MX = 2 ("f16x3", opt-in REDUCED precision: gnnb_set_option("math", 3)): the product on the fp16 matrix cores, hi + mid fp16
+// pieces of both operands, three products per 32-wide k block (k_stack_zf.hip / gnnb_device.h).  The x rows arrive by DMA as
+// fp32, and split by every wave that reads them the pieces would cost what the matrix cores save -- so the stage's rows are
+// split ONCE, cooperatively and in place (every thread reads its eight values, barrier, writes 16 B into each of the two planes
+// of the same padded row), in front of M: two barriers more per stage.  P still goes back over the rows in fp32.
+__device__ __forceinline__ int pa_h3_key(int row) { return (((row & 15) + 4) >> 3) & 1; }
+template <int KQ, int MX = 0>
 __global__ __launch_bounds__(PA_WG, 2) void k_pna_pagg(const float *__restrict__ x, const int4 *__restrict__ node_rec,
                                                        const int32_t *__restrict__ col, const int32_t *__restrict__ tile_first,
                                                        const int32_t *__restrict__ tile_edge, int num_tiles, int N, int E,
@@ -110,7 +116,21 @@ __global__ __launch_bounds__(PA_WG, 2) void k_pna_pagg(const float *__restrict__
     // ---- the wave's 16-column slice of Wb -> registers: k step t of block q multiplies input column 16 q + 4 lg + t
     const int cs = wave & ((1 << CSL) - 1), rg = wave >> CSL;
     float wr[KQ * 4];
-    {
+    if constexpr (MX != 0) {
+        static_assert(KQ % 2 == 0, "f16x3: whole 32-wide k blocks");
+        // (per 32-wide k block the lane's eight k values 32 q + 8 lg .. + 7 of its weight row as {hi x 4 dwords, mid x 4 dwords})
+        const float *wrow = Wb + (size_t)(cs * 16 + li) * ldw + 8 * lg;
+#pragma unroll
+        for (int q = 0; q < KQ / 2; q++) {
+            u32x4 hh, mm;
+            split2x8_f16(*reinterpret_cast<const float4 *>(wrow + 32 * q), *reinterpret_cast<const float4 *>(wrow + 32 * q + 4), hh, mm);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                wr[q * 8 + i] = __uint_as_float(hh[i]);
+                wr[q * 8 + 4 + i] = __uint_as_float(mm[i]);
+            }
+        }
+    } else {
         const float *wrow = Wb + (size_t)(cs * 16 + li) * ldw + 4 * lg;
 #pragma unroll
         for (int q = 0; q < KQ; q++) {
@@ -144,6 +164,52 @@ __global__ __launch_bounds__(PA_WG, 2) void k_pna_pagg(const float *__restrict__
 #pragma unroll
         for (int k = 0; k < NU; k++)
             acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (MX != 0) {
+            // ---- the stage's rows -> hi + mid fp16 pieces, in place (rows past `rows` keep whatever they hold: their products are never stored)
+            constexpr int IPR = F / 8;                                  // items of eight values per row
+            constexpr int IPT = (PA_CAP * IPR + PA_WG - 1) / PA_WG;     // items per thread
+            float4 v0[IPT], v1[IPT];
+#pragma unroll
+            for (int i = 0; i < IPT; i++) {
+                const int it = min(tid + i * PA_WG, PA_CAP * IPR - 1), row = it / IPR, c8 = it % IPR;
+                v0[i] = *reinterpret_cast<const float4 *>(XP + row * LDX + c8 * 8);
+                v1[i] = *reinterpret_cast<const float4 *>(XP + row * LDX + c8 * 8 + 4);
+            }
+            g2_barrier();
+#pragma unroll
+            for (int i = 0; i < IPT; i++) {
+                const int it = tid + i * PA_WG, row = it / IPR, c8 = it % IPR;
+                if (it < PA_CAP * IPR && row < rows) {
+                    u32x4 hh, mm;
+                    split2x8_f16(v0[i], v1[i], hh, mm);
+                    char *pr = reinterpret_cast<char *>(XP) + row * (LDX * 4) + ((c8 ^ pa_h3_key(row)) << 4);
+                    *reinterpret_cast<u32x4 *>(pr) = hh;
+                    *reinterpret_cast<u32x4 *>(pr + 2 * F) = mm;
+                }
+            }
+            g2_barrier();
+#pragma unroll
+            for (int k = 0; k < NU; k++) {
+                const int u = rg + k * NRG;
+                if (u < units) { // (wave-uniform)
+                    const char *ap = reinterpret_cast<const char *>(XP) + (u * 16 + li) * (LDX * 4) + ((lg ^ pa_h3_key(li)) << 4);
+                    u32x4 ah[KQ / 2], am[KQ / 2];
+#pragma unroll
+                    for (int q = 0; q < KQ / 2; q++) {
+                        ah[q] = *reinterpret_cast<const u32x4 *>(ap + 64 * q);
+                        am[q] = *reinterpret_cast<const u32x4 *>(ap + 2 * F + 64 * q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < KQ / 2; q++) {
+                        const u32x4 wh = {__float_as_uint(wr[q * 8 + 0]), __float_as_uint(wr[q * 8 + 1]), __float_as_uint(wr[q * 8 + 2]), __float_as_uint(wr[q * 8 + 3])};
+                        const u32x4 wm = {__float_as_uint(wr[q * 8 + 4]), __float_as_uint(wr[q * 8 + 5]), __float_as_uint(wr[q * 8 + 6]), __float_as_uint(wr[q * 8 + 7])};
+                        acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(wm), as_f16x8(ah[q]), acc[k], 0, 0, 0);
+                        acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(wh), as_f16x8(am[q]), acc[k], 0, 0, 0);
+                        acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(wh), as_f16x8(ah[q]), acc[k], 0, 0, 0);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < NU; k++) {
             const int u = rg + k * NRG;
@@ -278,14 +344,21 @@ hipError_t launch_pna_pagg(const BatchTables &t, const float *x, int F, const fl
     if ((t.num_tiles + grid - 1) / grid > 62) // a workgroup keeps its run of the tile table in one register per lane
         grid = (t.num_tiles + 61) / 62;
     hipError_t rc = hipErrorNotSupported;
-    auto go = [&](auto qtag) {
+    const bool h3 = options().math == 3; // (opt-in f16x3, REDUCED precision)
+    auto go1 = [&](auto qtag, auto mxtag) {
         constexpr int KQ = decltype(qtag)::value;
-        auto kern = k_pna_pagg<KQ>;
+        auto kern = k_pna_pagg<KQ, decltype(mxtag)::value>;
         if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess)
             return;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PA_WG), lds, s, x, t.node_rec, t.col, t.tile_first, t.tile_edge, t.num_tiles,
                            t.num_nodes, t.num_edges, wb, ldw, out);
         rc = hipGetLastError();
+    };
+    auto go = [&](auto qtag) {
+        if (h3)
+            go1(qtag, IntTag<2>{});
+        else
+            go1(qtag, IntTag<0>{});
     };
     if (F == 128)
         go(IntTag<8>{});

@@ -1824,10 +1824,19 @@ def test_pna_product_and_aggregate_in_one_kernel(dev, hidden, out, layers, fin):
             assert cm.last_path() == "layerwise"
             if name == "one_kernel":
                 assert np.array_equal(outs[name], cm.forward(*to_dev(batch, dev)).cpu().numpy())
+                # the opt-in f16x3 mode (REDUCED precision): the kernel's product on fp16 pieces, the rows split in place once per
+                # stage; the class GEMMs in their f16x3 form too -- 2e-5 of the output scale against the oracle
+                runtime.set_option("math", 3)
+                reduced = cm.forward(*to_dev(batch, dev)).cpu().numpy()
+                cm.check()
+                runtime.set_option("math", 0)
     finally:
         runtime.set_option("pna_pagg", 1)
         runtime.set_option("pna_first", 1)
+        runtime.set_option("math", 0)
     scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(reduced).all() and np.abs(reduced - ref).max() < 2e-5 * scale, np.abs(reduced - ref).max()
+    assert not np.array_equal(reduced, outs["one_kernel"])
     for k, v in outs.items():
         assert np.isfinite(v).all() and np.abs(v - ref).max() < TOL * scale, k
     assert np.abs(outs["one_kernel"] - outs["two_kernels"]).max() < 2e-5 * scale
