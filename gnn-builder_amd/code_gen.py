@@ -111,8 +111,10 @@ class Project:
         # (MI355X backend only) the arithmetic of the wide products -- the throughput side of the reference's float_or_fixed
         # switch (code_gen.py:39-52), which on an FPGA buys area and clock: "fp32" (default: native fp32 MFMA), "bf16x6"
         # (fp32-equivalent: six bf16 products of an exact three-way split), "bf16x3" / "f16x3" (REDUCED precision: three
-        # products on hi + mid bf16 / fp16 pieces; f16x3 has fp16's range).  Emitted as gnnb_set_option("math", n) in front of
-        # gnnb_model_create -- a PROCESS-WIDE runtime option (include/gnnb_hip.h): designs in one process share it.
+        # products on hi + mid bf16 / fp16 pieces; f16x3 has fp16's range).  Emitted as the `math` field of the generated
+        # design's gnnb_model_desc -- a property of THIS design, captured by gnnb_model_create like the reference bakes
+        # float_or_fixed / fpx into model.h (model.h.jinja:38-62): designs of different precision share a process without
+        # touching each other; the reduced modes' shims return GNNB_ERR_RANGE when a kernel left fp16's range.
         self.math = math
         if math not in MATH_MODES:
             raise ValueError(f"math must be one of {sorted(MATH_MODES)}")

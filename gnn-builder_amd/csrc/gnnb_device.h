@@ -146,6 +146,40 @@ __device__ inline Vf<1> pyg_std(const Vf<1> &m2, const Vf<1> &m)
 }
 
 // -------------------------------------------------------------------------------------
+// ---- Overflow contract of the REDUCED-precision math modes (gnnb_model_desc::math 2 "bf16x3" / 3 "f16x3"; VERDICT round 5,
+// item 3).  The reference's fixed-point build has DEFINED overflow (ap_fixed<W, I, AP_TRN, AP_WRAP>, code_gen.py:39-52,
+// model.h.jinja:38-62); fp16 pieces do not: an activation or weight of 65504 and above becomes inf, silently.  Every kernel
+// that multiplies on 16-bit pieces therefore looks at what it PRODUCED (the fp32 accumulators of its reduced products): a
+// non-finite value sets bit GNNB_FLAG_RANGE of the workspace's flag word (BatchTables::err, beside graph prep's bits) and
+// gnnb_workspace_check returns GNNB_ERR_RANGE -- the caller reruns the model with math = 0.  Cost: one v_cmp_class per
+// accumulator value and one scalar OR, in the opt-in modes only; the fp32 instantiations carry none of it.
+struct RangeProbe {
+    // (a wave-uniform lane mask, i.e. a scalar register pair: as a per-lane flag carried across a stage's barriers it became a
+    // vector register in the deep-GCN stack variants that sit at the 128-register budget, and spilled)
+    unsigned long long bad = 0ull;
+    __device__ __forceinline__ void see(float v, bool in_range = true)
+    {
+        bad |= __ballot(in_range && __builtin_amdgcn_classf(v, 0x207)); // sNaN | qNaN | -inf | +inf
+    }
+    template <typename ACC, int N>
+    __device__ __forceinline__ void see_vec(const ACC &a, bool in_range = true)
+    {
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            see(a[i], in_range);
+    }
+    __device__ __forceinline__ bool any() const { return bad != 0ull; } // wave-uniform
+    // one atomic per wave that saw something (rare), and the host-mapped copy graph prep's flag_batch writes too
+    __device__ __forceinline__ void report(int32_t *err, int32_t *err_host) const
+    {
+        if (err && bad != 0ull && (threadIdx.x & 63) == 0) {
+            atomicOr(err, GNNB_FLAG_RANGE);
+            if (err_host)
+                *reinterpret_cast<volatile int32_t *>(err_host) = GNNB_FLAG_RANGE;
+        }
+    }
+};
+
 // LDS-DMA helpers (global_load_lds: global -> LDS without VGPR staging).
 typedef __attribute__((address_space(3))) void *lds_vptr;
 typedef const __attribute__((address_space(1))) void *glb_vptr;

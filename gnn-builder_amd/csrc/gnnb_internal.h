@@ -50,6 +50,9 @@ struct BatchTables {
     int32_t num_tiles;
 };
 
+// bit of BatchTables::err set by a kernel that multiplies on 16-bit pieces (math modes 2 / 3) when it produced a non-finite
+// value: the overflow contract of the reduced modes (gnnb_device.h: RangeProbe), reported as GNNB_ERR_RANGE
+constexpr int GNNB_FLAG_RANGE = 64;
 constexpr int GNNB_G2_STAGE_ROWS = 64;     // rows per stage of the fused 2-layer GCN kernel (4 MFMA units)
 constexpr int GNNB_G2_STAGE_ROWS_BF6 = 48; // ... in the opt-in bf16x6 math mode (3 units)
 // rows per stage of the transform-first 2-layer GCN kernel k_gcn2_zf for input width f0 and the promised graph size (176 or 96)
@@ -117,6 +120,29 @@ struct Options {
                          //     bit 1: the run pre-touched line by line (slower); bits 2, 3: ablations (GCN, w = 128, one row-instruction)
 };
 Options &options();
+
+// The math mode of the launches the CALLING THREAD issues (0 fp32 MFMA, 1 bf16x6, 2 bf16x3, 3 f16x3: include/gnnb_hip.h).
+// Inside a model's forward or its workspace's graph prep: the model's own mode (gnnb_model_desc::math, captured by
+// gnnb_model_create) -- two designs of different precision in one process, or another thread calling gnnb_set_option,
+// never change each other's arithmetic (reference: precision is baked into the generated design, model.h.jinja:38-62).
+// Outside (the stand-alone gnnb_linear / gnnb_aggregate entries) and for models created with math = -1: the process-wide
+// option as it stands at the launch.  Every launcher reads launch_math(), never options().math.
+int launch_math();
+// ... and the flag word of the workspace whose forward the calling thread is in ({nullptr, nullptr} outside: the stand-alone
+// entries have no workspace and report nothing): where the reduced modes' kernels that take no BatchTables (k_linear_dma) drop
+// GNNB_FLAG_RANGE
+struct FlagWord {
+    int32_t *err, *err_host;
+};
+FlagWord launch_flag_word();
+struct MathScope { // entry points: `MathScope scope(ws->desc.math, ws->t.err, ws->t.err_host_dev);`
+    int prev;
+    FlagWord prev_flag;
+    explicit MathScope(int model_math, int32_t *err = nullptr, int32_t *err_host = nullptr);
+    ~MathScope();
+    MathScope(const MathScope &) = delete;
+    MathScope &operator=(const MathScope &) = delete;
+};
 
 // drop_self_loops: edges (v, v) are not entered into the tables (GCN: PyG's add_remaining_self_loops)
 hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,

@@ -65,6 +65,23 @@ Options &options()
     return o;
 }
 
+static thread_local int tl_math = -1; // >= 0: the calling thread is inside an entry point of a model with its own math mode
+static thread_local FlagWord tl_flag = {nullptr, nullptr};
+int launch_math() { return tl_math >= 0 ? tl_math : options().math; }
+FlagWord launch_flag_word() { return tl_flag; }
+MathScope::MathScope(int model_math, int32_t *err, int32_t *err_host) : prev(tl_math), prev_flag(tl_flag)
+{
+    if (model_math >= 0)
+        tl_math = model_math;
+    if (err)
+        tl_flag = FlagWord{err, err_host};
+}
+MathScope::~MathScope()
+{
+    tl_math = prev;
+    tl_flag = prev_flag;
+}
+
 // ---------------------------------------------------------------------------------------
 struct LayerDims {
     int fin, fout;
@@ -134,6 +151,8 @@ static int validate_desc(const gnnb_model_desc *d)
                           d->fpx_w - d->fpx_i > 24))
         return fail(GNNB_ERR_INVALID, "fixed-point emulation takes 2 <= W <= 32, 1 <= I <= W, W - I <= 24 (fp32 carries the "
                                       "grid values exactly only up to 24 fractional bits)");
+    if (d->math < -1 || d->math > 3)
+        return fail(GNNB_ERR_INVALID, "math must be -1 (follow the process-wide option) or 0 .. 3 (fp32, bf16x6, bf16x3, f16x3)");
     return GNNB_OK;
 }
 
@@ -781,6 +800,7 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
 {
     if (!ws || !node_ptr_dev || !edge_ptr_dev || (num_edges > 0 && !coo_dev))
         return fail(GNNB_ERR_INVALID, "null argument to gnnb_graph_prep");
+    MathScope math_scope(ws->desc.math); // (the tile granularity depends on which stack kernel the mode selects)
     if (num_graphs < 0 || num_nodes < 0 || num_edges < 0)
         return fail(GNNB_ERR_INVALID, "negative batch size");
     if (num_graphs > ws->max_graphs || num_nodes > ws->max_nodes || num_edges > ws->max_edges)
@@ -791,10 +811,14 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     // broken ptr arrays, broken max_graph_nodes promise) and nobody called gnnb_workspace_check since.  Read from a
     // host-mapped word without synchronising: it reports what has already run, never the batch being enqueued now.
     if (ws->err_host && *(volatile int32_t *)ws->err_host != 0) {
+        const int32_t seen = *(volatile int32_t *)ws->err_host;
         *(volatile int32_t *)ws->err_host = 0;
         // reported now: the device word is cleared as well (in stream order), or a later gnnb_workspace_check would blame
         // a good batch for it
         (void)hipMemsetAsync(ws->t.err, 0, sizeof(int32_t), (hipStream_t)stream);
+        if (seen == GNNB_FLAG_RANGE)
+            return fail(GNNB_ERR_RANGE, "an earlier forward on this workspace met a non-finite value in a reduced-precision math mode "
+                                        "(fp16's range exceeded: its results were unspecified); run the model with math = 0");
         return fail(GNNB_ERR_GRAPH, "an earlier batch on this workspace was flagged as malformed (its results were "
                                     "unspecified); gnnb_workspace_check reports and clears the flags");
     }
@@ -818,7 +842,7 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
         ws->max_graph_nodes > 0) {
         // (a 2-layer fp32 GCN stack runs k_gcn2_zf with its 96-row stages; everything else k_gcn2_fused)
         const bool zf = ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && options().fuse_zf;
-        const bool bf6 = !zf && options().math && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2; // (the only bf16x6 stack form)
+        const bool bf6 = !zf && launch_math() && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2; // (the only bf16x6 stack form)
         const int stage_rows = zf ? zf_stage_rows(ws->desc.in_dim, ws->max_graph_nodes) : bf6 ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
         while (t.tile_rows > 4 && ws->max_graph_nodes + t.tile_rows - 1 > stage_rows)
             t.tile_rows >>= 1;
@@ -855,7 +879,7 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     t.stage_cut_n = 0;
     if (options().stage_cut && options().fuse_gcn2 && ws->plan_scratch && ws->max_graph_nodes > 0 && ws->desc.fpx_w <= 0 && num_nodes > 0) {
         const bool zf_route = ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2 && options().fuse_zf;
-        const bool bf6 = !zf_route && options().math && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2;
+        const bool bf6 = !zf_route && launch_math() && ws->desc.conv_type == GNNB_CONV_GCN && ws->desc.num_layers == 2;
         const int cap = bf6 ? GNNB_G2_STAGE_ROWS_BF6 : GNNB_G2_STAGE_ROWS;
         const BatchTables ts = small_segment(ws);
         const int grid = gcn2_fused_grid(ts.num_tiles);
@@ -916,10 +940,15 @@ int gnnb_workspace_check(gnnb_workspace *ws, void *stream)
     }
     if (ws->err_host)
         *(volatile int32_t *)ws->err_host = 0;
-    if (err != 0)
+    if (err & ~GNNB_FLAG_RANGE)
         return fail(GNNB_ERR_GRAPH, "malformed batch (flags 0x%x): 1/2 ptr arrays not monotone/complete, 4 an edge leaves "
                                     "its graph, 8 a graph exceeds the max_graph_nodes promise, 16 the large-segment offsets "
-                                    "disagree with node_ptr / edge_ptr, 32 a node exceeds the max_degree promise", err);
+                                    "disagree with node_ptr / edge_ptr, 32 a node exceeds the max_degree promise, 64 a reduced-precision "
+                                    "kernel produced a non-finite value", err);
+    if (err & GNNB_FLAG_RANGE)
+        return fail(GNNB_ERR_RANGE, "a reduced-precision math mode (bf16x3 / f16x3) produced a non-finite value since the last check: an "
+                                    "activation or a weight beyond fp16's range (65504), or non-finite inputs; the results of that forward "
+                                    "are unspecified -- run the model with math = 0 (flag 0x40)");
     return GNNB_OK;
 }
 
@@ -994,6 +1023,7 @@ int gnnb_pna_product_aggregate(gnnb_workspace *ws, const float *x_dev, const flo
 {
     if (!ws || !ws->prepared)
         return fail(GNNB_ERR_INVALID, "gnnb_pna_product_aggregate needs a prepared batch (gnnb_graph_prep)");
+    MathScope math_scope(ws->desc.math);
     if (!x_dev || !wb_dev || !out_dev || width < 1 || ldw < width)
         return fail(GNNB_ERR_INVALID, "bad argument to gnnb_pna_product_aggregate");
     hipError_t he = launch_pna_pagg(ws->t, x_dev, width, wb_dev, ldw, out_dev, (hipStream_t)stream);
@@ -1527,6 +1557,8 @@ static bool ensure_side_stream(gnnb_workspace *ws)
 int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev,
                           float *out_dev, void *stream)
 {
+    // every launch below runs in the MODEL's math mode; the reduced modes' kernels flag this workspace
+    MathScope math_scope(model ? model->desc.math : -1, ws ? ws->t.err : nullptr, ws ? ws->t.err_host_dev : nullptr);
     int rc = forward_prepared_body(model, ws, x_dev, out_dev, stream);
     if (rc != GNNB_OK)
         return rc;
@@ -1828,6 +1860,7 @@ int gnnb_gcn_stack_timed(const gnnb_model *model, gnnb_workspace *ws, const floa
 {
     if (!model || !ws || !x_dev || iters < 1 || !out_us_per_launch)
         return fail(GNNB_ERR_INVALID, "bad argument to gnnb_gcn_stack_timed");
+    MathScope math_scope(model->desc.math, ws->t.err, ws->t.err_host_dev);
     if (!ws->prepared)
         return fail(GNNB_ERR_INVALID, "workspace has no prepared batch");
     const G2Deep deep = gcn_stack_middle_layers(model);

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(FM_WG, 2) void k_sage_first_mean(const float *__res
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int c0 = (cw * SPW + j) * 16 + 4 * lg;
-                    if (j < SPW && c0 < Nout) // (Nout % 4 == 0: the lane's four columns are inside or outside together)
+                    // (FM_CAP = 56 is no multiple of 16: the last unit's rows 56 .. 63 lie past YT's carve -- not stored; A0's rows
+                    // there are read from inside the allocation, YT's own first rows, and their products dropped here)
+                    if (j < SPW && c0 < Nout && u * 16 + li < FM_CAP) // (Nout % 4 == 0: the lane's four columns are inside or outside together)
                         *reinterpret_cast<float4 *>(YT + (u * 16 + li) * LDY + c0) =
                             make_float4(act_t<ACT>(acc[j][0]), act_t<ACT>(acc[j][1]), act_t<ACT>(acc[j][2]), act_t<ACT>(acc[j][3]));
                 }
@@ -312,6 +314,10 @@ hipError_t launch_sage_first_mean(const BatchTables &t, const float *x, int F, c
         return hipErrorNotSupported;
     if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > FM_CAP)
         return hipErrorNotSupported; // whole graphs must fit a stage (validated on the device by graph prep: flag 8)
+    // a batch with a large segment: the promise covers graphs [0, promise_graphs) only and graph prep validates nothing about the
+    // rest -- those graphs need not fit a stage (round-5 advisor finding: they got clamped sources, unflagged): layer by layer
+    if (t.promise_graphs < t.num_graphs || t.large_n >= 0)
+        return hipErrorNotSupported;
     if ((((uintptr_t)y | (uintptr_t)mean_out) & 15))
         return hipErrorNotSupported;
     const int kq = K <= 16 ? 1 : 2;

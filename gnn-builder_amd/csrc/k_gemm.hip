@@ -226,7 +226,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ skip, float *__restrict__ Y, int M,
                                                     int N, int act, int tiles_m, int tiles_n, int split_from, int split,
-                                                    PoolEpilogue pe, StreamK sk, RowClasses rc, int bias_in_lds)
+                                                    PoolEpilogue pe, StreamK sk, RowClasses rc, int bias_in_lds,
+                                                    int32_t *__restrict__ err, int32_t *__restrict__ err_host) // MATH 2: GNNB_FLAG_RANGE (gnnb_device.h RangeProbe)
 {
     constexpr bool POOL = MODE == 1, RC = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -641,6 +642,20 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         }
         if (MC == 0)
             return;
+        // (f16x3: the reduced mode's overflow contract -- what this run of chunks gave, parked stream-K parts included, is looked at
+        // before any epilogue; rows past M re-read valid rows.  The atomic, rare, is one more vector-memory instruction: counted)
+        if constexpr (MATH == 2) {
+            RangeProbe rp;
+#pragma unroll
+            for (int mi = 0; mi < MC; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NT; ni++)
+                    rp.see_vec<f32x16, 16>(acc[mi][ni]);
+            if (rp.any()) {
+                rp.report(err, err_host);
+                vm++;
+            }
+        }
 
         // ---- pooling epilogue (the model's LAST conv layer): act(acc + bias) is pooled per graph instead of stored.
         // Per 32-row block of the wave: the block goes through an 8-KB scratch in the chunk buffer that was consumed last
@@ -1282,7 +1297,7 @@ static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const floa
                                       const float *bias, const float *skip, float *Y, int M, int N,
                                       int act, hipStream_t s, const GatherDesc &gd = GatherDesc{})
 {
-    if (MATH == 0 && VEC_A && KQ >= 2 && options().math != 0 && K == 16 * KQ && N % 32 == 0 && ldw % 4 == 0 &&
+    if (MATH == 0 && VEC_A && KQ >= 2 && launch_math() != 0 && K == 16 * KQ && N % 32 == 0 && ldw % 4 == 0 &&
         (((uintptr_t)W & 15) == 0) && gd.rec == nullptr)
         return launch_linear_reg_t<KQ, VEC_A, 1>(A, lda, K, W, ldw, bias, skip, Y, M, N, act, s, gd);
     // waves: N <= 32 -> 4 row groups x 1 column slice; N <= 64 -> 2 x 2; else 1 x 4 (128 cols / WG)
@@ -1576,7 +1591,7 @@ __global__ __launch_bounds__(WG, 1) void k_linear_wlds(const float *__restrict__
 static bool linear_wlds_eligible(const GemmArgs &g, const float *w, int ldw, const float *bias, const float *skip,
                                  const float *y, int N)
 {
-    if (options().gemm_variant != 0 || options().math != 0 || !options().gemm_wlds)
+    if (options().gemm_variant != 0 || launch_math() != 0 || !options().gemm_wlds)
         return false;
     if (skip != nullptr) // (a skip tile per unit would not leave room for the ring beside a 64 KB W: k_linear_reg)
         return false;
@@ -1819,7 +1834,7 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
             const size_t lds = (size_t)DNBUF * DBUF_B + 16 + (bias_in_lds ? (((size_t)N * 4 + 15) & ~(size_t)15) : 0); // (+ the stream-K arrival flag, + the bias)
             {
                 const int mode = pep ? 1 : (rcp ? 2 : 0);
-                const int mv = options().math == 3 ? 2 : (options().math ? 1 : 0);
+                const int mv = launch_math() == 3 ? 2 : (launch_math() ? 1 : 0);
                 const void *fns[3][3] = {
                     {reinterpret_cast<const void *>(k_linear_dma<0, 0>), reinterpret_cast<const void *>(k_linear_dma<0, 1>), reinterpret_cast<const void *>(k_linear_dma<0, 2>)},
                     {reinterpret_cast<const void *>(k_linear_dma<1, 0>), reinterpret_cast<const void *>(k_linear_dma<1, 1>), reinterpret_cast<const void *>(k_linear_dma<1, 2>)},
@@ -1859,15 +1874,16 @@ hipError_t launch_linear(const GemmArgs &g, const float *w, int ldw, const float
                                       : std::min(split_from + split * (tiles - split_from), resident);
 #define GNNB_DMA_LAUNCH(MATHV, MODEV)                                                                                    \
     hipLaunchKernelGGL((k_linear_dma<MATHV, MODEV>), dim3(grid), dim3(DWG), lds, s, g, w, ldw, bias, skip, y, M, N, act, tm, \
-                       tn, split_from, split, pe, sk, rc, bias_in_lds)
-            if (options().math == 3) { // (f16x3: opt-in, reduced precision)
+                       tn, split_from, split, pe, sk, rc, bias_in_lds, flagw.err, flagw.err_host)
+            const FlagWord flagw = launch_flag_word(); // (the workspace whose forward this launch belongs to; none: stand-alone gnnb_linear)
+            if (launch_math() == 3) { // (f16x3: opt-in, reduced precision)
                 if (pep)
                     GNNB_DMA_LAUNCH(2, 1);
                 else if (rcp)
                     GNNB_DMA_LAUNCH(2, 2);
                 else
                     GNNB_DMA_LAUNCH(2, 0);
-            } else if (options().math) {
+            } else if (launch_math()) {
                 if (pep)
                     GNNB_DMA_LAUNCH(1, 1);
                 else if (rcp)

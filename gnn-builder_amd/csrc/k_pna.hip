@@ -42,7 +42,8 @@ template <int KQ, int MX = 0>
 __global__ __launch_bounds__(PA_WG, 2) void k_pna_pagg(const float *__restrict__ x, const int4 *__restrict__ node_rec,
                                                        const int32_t *__restrict__ col, const int32_t *__restrict__ tile_first,
                                                        const int32_t *__restrict__ tile_edge, int num_tiles, int N, int E,
-                                                       const float *__restrict__ Wb, int ldw, float *__restrict__ out)
+                                                       const float *__restrict__ Wb, int ldw, float *__restrict__ out,
+                                                       int32_t *__restrict__ err, int32_t *__restrict__ err_host) // MX != 0: GNNB_FLAG_RANGE (gnnb_device.h RangeProbe)
 {
     constexpr int F = 16 * KQ, LDX = F + 4;             // padded row (floats)
     constexpr int G = F / 4;                            // lanes per row (float4 each)
@@ -228,6 +229,19 @@ __global__ __launch_bounds__(PA_WG, 2) void k_pna_pagg(const float *__restrict__
                 }
             }
         }
+        // (the reduced form's overflow contract: a non-finite P in a row of the stage -- an x or Wb element beyond fp16's range --
+        // is flagged; the atomic is one more vector-memory instruction of this wave: counted)
+        if constexpr (MX != 0) {
+            RangeProbe rp;
+#pragma unroll
+            for (int k = 0; k < NU; k++)
+                if (rg + k * NRG < units)
+                    rp.see_vec<f32x4, 4>(acc[k], (rg + k * NRG) * 16 + li < rows);
+            if (rp.any()) {
+                rp.report(err, err_host);
+                vm++;
+            }
+        }
         g2_barrier(); // everybody has read X
         // ---- PW: P over X (lane (li, lg): columns 16 cs + 4 lg .. + 3 of row 16 u + li)
 #pragma unroll
@@ -331,6 +345,10 @@ hipError_t launch_pna_pagg(const BatchTables &t, const float *x, int F, const fl
         return hipSuccess;
     if (!options().pna_pagg || !(F == 128 || F == 64 || F == 32) || t.tile_lo != 0)
         return hipErrorNotSupported;
+    // a batch with a large segment: the max_graph_nodes promise covers graphs [0, promise_graphs) only and graph prep validates
+    // nothing about the rest -- those graphs need not fit a stage (round-5 advisor finding: they got clamped sources, unflagged)
+    if (t.promise_graphs < t.num_graphs || t.large_n >= 0)
+        return hipErrorNotSupported;
     // whole graphs must fit a stage (validated on the device by graph prep: flag 8)
     if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > PA_CAP)
         return hipErrorNotSupported;
@@ -344,14 +362,14 @@ hipError_t launch_pna_pagg(const BatchTables &t, const float *x, int F, const fl
     if ((t.num_tiles + grid - 1) / grid > 62) // a workgroup keeps its run of the tile table in one register per lane
         grid = (t.num_tiles + 61) / 62;
     hipError_t rc = hipErrorNotSupported;
-    const bool h3 = options().math == 3; // (opt-in f16x3, REDUCED precision)
+    const bool h3 = launch_math() == 3; // (opt-in f16x3, REDUCED precision)
     auto go1 = [&](auto qtag, auto mxtag) {
         constexpr int KQ = decltype(qtag)::value;
         auto kern = k_pna_pagg<KQ, decltype(mxtag)::value>;
         if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess)
             return;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PA_WG), lds, s, x, t.node_rec, t.col, t.tile_first, t.tile_edge, t.num_tiles,
-                           t.num_nodes, t.num_edges, wb, ldw, out);
+                           t.num_nodes, t.num_edges, wb, ldw, out, t.err, t.err_host_dev);
         rc = hipGetLastError();
     };
     auto go = [&](auto qtag) {

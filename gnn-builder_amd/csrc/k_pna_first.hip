@@ -333,6 +333,10 @@ hipError_t launch_pna_first(const BatchTables &t, const float *x, int F, const f
         return hipErrorNotSupported;
     if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > PF_CAP)
         return hipErrorNotSupported; // whole graphs must fit a stage (validated on the device by graph prep: flag 8)
+    // a batch with a large segment: the promise covers graphs [0, promise_graphs) only and graph prep validates nothing about the
+    // rest -- those graphs need not fit a stage (round-5 advisor finding: they got clamped sources, unflagged): layer by layer
+    if (t.promise_graphs < t.num_graphs || t.large_n >= 0)
+        return hipErrorNotSupported;
     const int kq = (13 * F + 15) / 16;
     if (Nout > 16 * kq) // (the output tile is written over A0)
         return hipErrorNotSupported;

@@ -126,9 +126,12 @@ __device__ __forceinline__ void g2_h3_store(char *buf, int rowb, int midoff, int
     *reinterpret_cast<_Float16 *>(p) = h;
     *reinterpret_cast<_Float16 *>(p + midoff) = m;
 }
+#ifndef GNNB_H3_PROBE // (development: 0 = no probe, 1 / 2 / 3 / 4 / 5 = forms measured against the register budget, see below)
+#define GNNB_H3_PROBE 6
+#endif
 template <int ACT, int KQ32, int NU>
 __device__ __forceinline__ void g2_mma_h3(const char *__restrict__ planes, int rowb, int midoff, const float (&wr)[KQ32 * 8], float bias,
-                                          int rg, int nrg, int li, int lg, float (&v)[NU][4])
+                                          int rg, int nrg, int li, int lg, float (&v)[NU][4], int *sflag, int rows)
 {
     constexpr int NA = NU == 1 ? 2 : NU;
     f32x4 acc[NA];
@@ -172,22 +175,116 @@ __device__ __forceinline__ void g2_mma_h3(const char *__restrict__ planes, int r
             }
         }
     }
+    // (the reduced modes' overflow contract, gnnb_device.h: what the product gave, BEFORE the activation -- ReLU turns a NaN into 0 --,
+    // in the rows the stage holds; rows past its end are stale LDS.  Seen -> one LDS word, which the kernel's last instructions turn
+    // into the workspace's flag: nothing of the probe lives in a register outside this epilogue -- carried through the stage as a
+    // scalar mask beside the flag word's address it spilled SGPRs into vector lanes in the variants that sit at 128 registers)
+#if GNNB_H3_PROBE == 0
 #pragma unroll
     for (int k = 0; k < NU; k++)
 #pragma unroll
         for (int r = 0; r < 4; r++)
             v[k][r] = act_t<ACT>((NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias);
+#elif GNNB_H3_PROBE == 1
+    RangeProbe rp;
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float pre = (NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias;
+            rp.see(pre, (rg + k * nrg) * 16 + lg * 4 + r < rows);
+            v[k][r] = act_t<ACT>(pre);
+        }
+    if (rp.any() && li + lg == 0)
+        *sflag = 1;
+#elif GNNB_H3_PROBE == 2
+    // one probe value per lane: t stays 0 while every accumulator of the stage's rows is finite (inf * 0 and nan * 0 are nan)
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float pre = (NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias;
+            t = __builtin_fmaf((rg + k * nrg) * 16 + lg * 4 + r < rows ? pre : 0.0f, 0.0f, t);
+            v[k][r] = act_t<ACT>(pre);
+        }
+    if (t != t)
+        *sflag = 1;
+#elif GNNB_H3_PROBE == 4 // experiment: no row mask
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float pre = (NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias;
+            t = __builtin_fmaf(pre, 0.0f, t);
+            v[k][r] = act_t<ACT>(pre);
+        }
+    if (t != t)
+        *sflag = 1;
+#elif GNNB_H3_PROBE == 5 // experiment: no row mask, probe folded into v (no branch)
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float pre = (NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias;
+            t = __builtin_fmaf(pre, 0.0f, t);
+            v[k][r] = act_t<ACT>(pre);
+        }
+    asm volatile("" :: "v"(t));
+#elif GNNB_H3_PROBE == 6
+    // one probe value per lane over ALL sixteen rows of the units (t stays 0 while every accumulator is finite: inf * 0 and
+    // nan * 0 are nan); only when that trips -- rare -- the rows are looked at one by one against the stage's end (rows past it
+    // are stale LDS): the row masks, a scalar register pair each, exist inside that branch only
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            t = __builtin_fmaf(NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r], 0.0f, t);
+    if (__ballot(t != t) != 0ull) {
+        RangeProbe rp;
+#pragma unroll
+        for (int k = 0; k < NU; k++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                rp.see(NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r], (rg + k * nrg) * 16 + lg * 4 + r < rows);
+        if (rp.any() && li + lg == 0)
+            *sflag = 1;
+    }
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            v[k][r] = act_t<ACT>((NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias);
+#elif GNNB_H3_PROBE == 3
+    // as 2, the row mask formed arithmetically (no compare: every v_cmp result is a scalar register pair, and these variants spill those)
+    float t = 0.0f;
+    const int lim = rows - rg * 16 - lg * 4; // rows of the stage from this lane's first row of unit 0 on
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float pre = (NU == 1 ? acc[0][r] + acc[1][r] : acc[k][r]) + bias;
+            const int m = (k * nrg * 16 + r - lim) >> 31; // all ones while the row is inside the stage
+            t = __builtin_fmaf(__int_as_float(__float_as_int(pre) & m), 0.0f, t);
+            v[k][r] = act_t<ACT>(pre);
+        }
+    if (t != t)
+        *sflag = 1;
+#endif
 }
 // (units in groups of at most two, as g2_mma_s)
 template <int ACT, int KQ32, int NU>
 __device__ __forceinline__ void g2_mma_h3_s(const char *__restrict__ planes, int rowb, int midoff, const float (&wr)[KQ32 * 8], float bias,
-                                            int rg, int nrg, int li, int lg, float (&v)[NU][4])
+                                            int rg, int nrg, int li, int lg, float (&v)[NU][4], int *sflag, int rows)
 {
     if constexpr (NU > 2) {
         float va[2][4], vb[NU - 2][4];
-        g2_mma_h3<ACT, KQ32, 2>(planes, rowb, midoff, wr, bias, rg, nrg, li, lg, va);
+        g2_mma_h3<ACT, KQ32, 2>(planes, rowb, midoff, wr, bias, rg, nrg, li, lg, va, sflag, rows);
         __builtin_amdgcn_sched_barrier(0);
-        g2_mma_h3<ACT, KQ32, NU - 2>(planes, rowb, midoff, wr, bias, rg + 2 * nrg, nrg, li, lg, vb);
+        g2_mma_h3<ACT, KQ32, NU - 2>(planes, rowb, midoff, wr, bias, rg + 2 * nrg, nrg, li, lg, vb, sflag, rows);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             v[0][r] = va[0][r];
@@ -197,7 +294,7 @@ __device__ __forceinline__ void g2_mma_h3_s(const char *__restrict__ planes, int
                 v[k][r] = vb[k - 2][r];
         }
     } else {
-        g2_mma_h3<ACT, KQ32, NU>(planes, rowb, midoff, wr, bias, rg, nrg, li, lg, v);
+        g2_mma_h3<ACT, KQ32, NU>(planes, rowb, midoff, wr, bias, rg, nrg, li, lg, v, sflag, rows);
     }
 }
 
@@ -272,7 +369,8 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ b1,
     int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled, int nl,
     const float *__restrict__ Wmid, const float *__restrict__ bmid, long mid_stride, long bmid_stride, int skip,
-    float gin_eps, const int32_t *__restrict__ stage_cut)
+    float gin_eps, const int32_t *__restrict__ stage_cut,
+    int32_t *__restrict__ err, int32_t *__restrict__ err_host) // H3: the workspace's flag word (GNNB_FLAG_RANGE, gnnb_device.h RangeProbe)
 {
     const int h1out = h1; // the width of the pooled rows (GIN: the model's out_dim <= hidden; the products run hidden-wide)
     if (GIN) {
@@ -317,6 +415,11 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
     int4 *REC = reinterpret_cast<int4 *>(reinterpret_cast<char *>(A1) + (MATH ? 3 * plane_b : G2_CAP * lda1 * 4));
     int32_t *stile = reinterpret_cast<int32_t *>(REC + 3 * G2_CAP);
     int32_t *sgraph = stile + (G2_TCAP + 1);
+    // (f16x3: "a reduced product of this workgroup gave a non-finite value" -- the last word of the first SMALL buffer's slack:
+    // the DMA writes 65 of its 68 graph-boundary words)
+    [[maybe_unused]] int *SFLAG = reinterpret_cast<int *>(smem + rows_b + small_b - 4);
+    if (H3 && tid == 0)
+        *SFLAG = 0;
 
     // the workgroup's run of node tiles: whole stages of the batch's global greedy stage list when graph prep made the cut
     // table for this grid (every workgroup the same number of stages +- 1, none ragged: round 5), else equal tile counts
@@ -343,9 +446,9 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         st.rows = 0;
         st.ga = 0;
         st.gb = 0;
+        st.nb = stile[min(ta, t1) - t0]; // (past the run: its end -- the stage before reads its own row count from there)
         if (ta >= t1)
             return st;
-        st.nb = stile[ta - t0];
         int tb = ta + 1;
         while (tb < t1 && stile[tb + 1 - t0] - st.nb <= G2_CAP)
             tb++;
@@ -511,6 +614,10 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         const int32_t *sgp = reinterpret_cast<const int32_t *>(sbase + G2_CAP * 4);
         const int rows = cur.rows, nb = cur.nb;
         const int units = (rows + 15) >> 4;
+        // (f16x3: the reduced products' probe masks rows past the stage's end -- in a branch that runs only once something non-finite
+        // was seen.  `rows` is uniform but sits in a VECTOR register (it comes from LDS): kept alive through the products it cost the
+        // variants at the 128-register budget a spill; the difference of two values that ARE alive there is formed inside the branch)
+        [[maybe_unused]] const int rows_p = min(nxt.nb - nb, G2_CAP);
         // The thread index is re-made OPAQUE every stage and every per-lane quantity below is derived from
         // it again (a dozen VALU ops).  Otherwise the compiler hoists ~50 loop-invariant LDS offsets out of
         // the stage loop, runs out of its 128 registers and parks them in scratch -- whose reloads are
@@ -769,7 +876,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 constexpr int NU = decltype(nutag)::value;
                 float v[NU][4];
                 if constexpr (H3)
-                    g2_mma_h3_s<GNNB_ACT_NONE, KQ1 / 2, NU>(reinterpret_cast<const char *>(A1), lda1 * 4, 2 * h0, w1r, bias1, rg0, nrg0, li, lg, v);
+                    g2_mma_h3_s<GNNB_ACT_NONE, KQ1 / 2, NU>(reinterpret_cast<const char *>(A1), lda1 * 4, 2 * h0, w1r, bias1, rg0, nrg0, li, lg, v, SFLAG, rows_p);
                 else
                     g2_mma_s<GNNB_ACT_NONE, KQ1, NU, G2_SPLIT>(A1, lda1, w1r, bias1, rg0, nrg0, li, lg, v);
                 if (n0c < h0) {
@@ -802,7 +909,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 constexpr int NU = decltype(nutag)::value;
                 float t[NU][4];
                 if constexpr (H3)
-                    g2_mma_h3_s<A, KQ1 / 2, NU>(reinterpret_cast<const char *>(buf), ld * 4, 2 * h0, w1r, bias1, rg0, nrg0, li, lg, t);
+                    g2_mma_h3_s<A, KQ1 / 2, NU>(reinterpret_cast<const char *>(buf), ld * 4, 2 * h0, w1r, bias1, rg0, nrg0, li, lg, t, SFLAG, rows_p);
                 else
                     g2_mma_s<A, KQ1, NU, G2_SPLIT>(buf, ld, w1r, bias1, rg0, nrg0, li, lg, t);
 #pragma unroll
@@ -888,7 +995,7 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
                 constexpr int NU = decltype(nutag)::value;
                 float v[NU][4];
                 if constexpr (H3)
-                    g2_mma_h3_s<ACT, KQ1 / 2, NU>(reinterpret_cast<const char *>(A1), lda1 * 4, 2 * h0, w1r, bias1, 0, 1, li, lg, v);
+                    g2_mma_h3_s<ACT, KQ1 / 2, NU>(reinterpret_cast<const char *>(A1), lda1 * 4, 2 * h0, w1r, bias1, 0, 1, li, lg, v, SFLAG, rows_p);
                 else if (MATH)
                     g2_mma_bf6<ACT, KB1, NU>(reinterpret_cast<const char *>(A1), plane_b, prow_b, wh, wm, wl, bias1, li, lg, v);
                 else
@@ -959,6 +1066,14 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
         cur = nxt;
         b ^= 1;
     }
+    if constexpr (H3) { // the reduced mode's overflow contract: GNNB_FLAG_RANGE into the workspace's flag word (gnnb_device.h)
+        __syncthreads();
+        if (tid == 0 && *SFLAG != 0 && err) {
+            atomicOr(err, GNNB_FLAG_RANGE);
+            if (err_host)
+                *reinterpret_cast<volatile int32_t *>(err_host) = GNNB_FLAG_RANGE;
+        }
+    }
 #ifdef GNNB_PROBE
     if (lane == 0 && blockIdx.x < 512) {
         unsigned long long *o = g_probe + 8 * 8192 + (blockIdx.x * 8 + wave) * 16; // second half: other kernels stamp the first
@@ -1005,7 +1120,7 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
     // GIN stacks: fp32 mode, out <= hidden (the wide matrices come hidden x hidden, zero-padded: gnnb_model_create), biases present
     if (deep.gin && (h1 > h0 || !deep.wmid || !deep.bmid || (((uintptr_t)deep.wmid) & 15) || (deep.mid_stride & 3)))
         return hipErrorNotSupported;
-    const int math = (o.math && deep.nl == 2 && !deep.gin) ? 1 : 0;
+    const int math = (launch_math() && deep.nl == 2 && !deep.gin) ? 1 : 0;
     const int cap = 16 * g2_units(math);
     if (t.max_graph_nodes_hint <= 0 || t.max_graph_nodes_hint + t.tile_rows - 1 > cap)
         return hipErrorNotSupported; // no promise that whole graphs fit a stage
@@ -1057,11 +1172,11 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
         const int32_t *cut = (t.stage_cut && t.stage_cut_n == (int)grid) ? t.stage_cut : nullptr;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_WG), lds, s, x, f0, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_graph, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, w0, b0, h0, w1, b1, h1, p0, p1, p2,
-                           num_pools, pooled, deep.nl, deep.wmid, deep.bmid, deep.mid_stride, deep.bmid_stride, deep.skip, deep.eps, cut);
+                           num_pools, pooled, deep.nl, deep.wmid, deep.bmid, deep.mid_stride, deep.bmid_stride, deep.skip, deep.eps, cut, t.err, t.err_host_dev);
         rc = hipGetLastError();
     };
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
-        const bool h3 = o.math == 3; // (opt-in f16x3, REDUCED precision: the GIN and deep variants)
+        const bool h3 = launch_math() == 3; // (opt-in f16x3, REDUCED precision: the GIN and deep variants)
         if (deep.gin && h3)
             go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<2>{}, IntTag<1>{});
         else if (deep.gin)
@@ -1069,8 +1184,10 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
         else if (math)
             go2(atag, q0tag, q1tag, IntTag<1>{}, IntTag<0>{}, IntTag<0>{});
         else if (deep.nl > 2) {
-            // (the deep GELU variants have no register to spare -- 125 of 128 in fp32, the f16x3 form spilled one --: they keep fp32)
-            if constexpr (decltype(atag)::value != GNNB_ACT_GELU) {
+            // (the deep variants have no register to spare -- GELU 125 of 128 in fp32, its f16x3 form spilled one; with the reduced
+            // mode's overflow probe, round 6, the sigmoid / tanh forms at hidden 128 spill one too --: only ReLU stacks take f16x3,
+            // the others keep fp32 in the mode, which is never less accurate)
+            if constexpr (decltype(atag)::value == GNNB_ACT_RELU) {
                 if (h3) {
                     go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{}, IntTag<1>{});
                     return;
@@ -1089,10 +1206,15 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
         else if (kq0 == 2 && kq1 == 4) go(atag, IntTag<2>{}, IntTag<4>{});
         else go(atag, IntTag<2>{}, IntTag<2>{});
     };
-#ifdef GNNB_DEV_FAST // development builds: only the BASELINE config 2 / 3 instantiations (seconds instead of minutes to compile)
+#ifdef GNNB_DEV_DEEPH3 // development builds: the deep-GCN f16x3 variants that sit at the 128-register budget, nothing else
+    if (act == GNNB_ACT_RELU)
+        go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<1>{}, IntTag<1>{});
+    else
+        go2(IntTag<GNNB_ACT_SIGMOID>{}, IntTag<2>{}, IntTag<8>{}, IntTag<0>{}, IntTag<1>{}, IntTag<1>{});
+#elif defined(GNNB_DEV_FAST) // development builds: only the BASELINE config 2 / 3 instantiations (seconds instead of minutes to compile)
     if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && !deep.gin && !math && deep.nl == 2)
         go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<0>{}, IntTag<0>{});
-    else if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && deep.gin && o.math == 3)
+    else if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && deep.gin && launch_math() == 3)
         go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<2>{}, IntTag<1>{});
     else if (act == GNNB_ACT_RELU && kq0 == 1 && kq1 == 8 && deep.gin)
         go2(IntTag<GNNB_ACT_RELU>{}, IntTag<1>{}, IntTag<8>{}, IntTag<0>{}, IntTag<2>{}, IntTag<0>{});

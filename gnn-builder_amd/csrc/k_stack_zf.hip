@@ -266,7 +266,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const int32_t *__restrict__ node_ptr, int num_tiles, int num_graphs, int N, int E, const float *__restrict__ W0,
     const float *__restrict__ b0, int h0, const float *__restrict__ W1, const float *__restrict__ W1f,
     const float *__restrict__ b1, int h1, int p0, int p1, int p2, int np, float *__restrict__ pooled,
-    const HeadArgs *__restrict__ head_dev, float *__restrict__ head_out, int head_ldact // head_dev != nullptr: the MLP head runs here too (round 5, below)
+    const HeadArgs *__restrict__ head_dev, float *__restrict__ head_out, int head_ldact, // head_dev != nullptr: the MLP head runs here too (round 5, below)
+    int32_t *__restrict__ err, int32_t *__restrict__ err_host // MX != 0: the workspace's flag word (GNNB_FLAG_RANGE: a non-finite Z, gnnb_device.h RangeProbe)
 #ifdef GNNB_ZF_ABLATE
     , unsigned long long *dbg_span // [2]: min start / max end wall clock (100 MHz) over the workgroups of this launch
     , int dbg // development only (-DGNNB_ZF_ABLATE): bit 0 skips P1, 1 skips P0', 2 skips M1, 3 skips M0, 4 skips the Z write
@@ -675,6 +676,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     int nst = 0;
     unsigned long long prows = 0, pgraphs = 0, punits = 0;
 #define ZF_PT(i) do { const unsigned long long _n = clock64(); pt[i] += _n - pt_last; pt_last = _n; } while (0)
+#elif defined(GNNB_ZF_MARK) // static instruction table (tools/isa_table.py): phase boundaries as comments in the ISA
+#define ZF_PT(i) asm volatile("; ZFMARK " #i)
 #else
 #define ZF_PT(i) do { } while (0)
 #endif
@@ -856,6 +859,16 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         g2_barrier(); // everybody has read H; everybody's DMA is in
         ZF_PT(5);
 
+        // (reduced-precision forms: the overflow contract -- a non-finite value of Z in a row of the stage, i.e. an H or W1
+        // element beyond fp16's range, or non-finite inputs, is flagged; rows past the stage's end hold stale LDS and are not looked at)
+        if constexpr (MX != 0) {
+            RangeProbe rp;
+#pragma unroll
+            for (int k = 0; k < ZMAX; k++)
+                if (k < nu1)
+                    rp.see_vec<f32x4, 4>(z[k], (rg1 + k * nrg1) * 16 + li < rows);
+            rp.report(err, err_host);
+        }
         // ---- ZW: Z -> H in place
         if ((n1c - li) + 4 * lg < h1 && ZF_ON(4)) { // (h1 % 4 == 0: the lane's four columns are inside or outside together)
 #pragma unroll
@@ -1324,7 +1337,7 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, f0, t.node_rec, t.col, t.dinv,
                            t.tile_first, t.tile_graph, t.tile_edge, t.graph_ptr, t.num_tiles, t.num_graphs, t.num_nodes, t.num_edges, w0, b0, h0, w1, w1f, b1, h1,
-                           p0, p1, p2, num_pools, pooled, head_dev, head_out, head_ldact
+                           p0, p1, p2, num_pools, pooled, head_dev, head_out, head_ldact, t.err, t.err_host_dev
 #ifdef GNNB_ZF_ABLATE
                            , zf_dbg_span_slot(), getenv("GNNB_ZF_DBG") ? atoi(getenv("GNNB_ZF_DBG")) : 0
 #endif
@@ -1334,9 +1347,9 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
         if constexpr (decltype(q0tag)::value == 1) { // (the wide shape exists for one-block input widths only)
             if (zf_wide_shape(f0, t.max_graph_nodes_hint)) {
-                if (o.math == 2) // (the opt-in bf16x3 / f16x3 forms of M1 exist in the wide shape only: every BASELINE GCN model)
+                if (launch_math() == 2) // (the opt-in bf16x3 / f16x3 forms of M1 exist in the wide shape only: every BASELINE GCN model)
                     go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{}, IntTag<1>{});
-                else if (o.math == 3)
+                else if (launch_math() == 3)
                     go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{}, IntTag<2>{});
                 else
                     go2(atag, q0tag, q1tag, IntTag<16>{}, IntTag<11>{}, IntTag<0>{});

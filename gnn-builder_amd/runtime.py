@@ -59,7 +59,17 @@ class ModelDesc(C.Structure):
         ("output_activation", C.c_int32),
         ("fpx_w", C.c_int32),
         ("fpx_i", C.c_int32),
+        ("math", C.c_int32),
     ]
+
+
+MATH_MODES = {"fp32": 0, "bf16x6": 1, "bf16x3": 2, "f16x3": 3}  # gnnb_model_desc::math (include/gnnb_hip.h)
+GNNB_ERR_RANGE = -6
+
+
+class GnnbRangeError(GnnbError):
+    """A reduced-precision math mode (bf16x3 / f16x3) produced a non-finite value (``GNNB_ERR_RANGE``): fp16's range was
+    exceeded by an activation or a weight.  The flagged forward's results are unspecified; run the model with math="fp32"."""
 
 
 class GemmSeg(C.Structure):
@@ -161,7 +171,7 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
 def _check(rc: int) -> None:
     if rc != GNNB_OK:
         msg = load_library(require_gpu=False).gnnb_last_error()
-        raise GnnbError(f"libgnnb_hip error {rc}: {msg.decode() if msg else '?'}")
+        raise (GnnbRangeError if rc == GNNB_ERR_RANGE else GnnbError)(f"libgnnb_hip error {rc}: {msg.decode() if msg else '?'}")
 
 
 def set_option(name: str, value: int) -> None:
@@ -189,6 +199,11 @@ def make_desc(spec: dict) -> ModelDesc:
     d.output_activation = OUT_ACT[spec.get("output_activation")]
     fpx = spec.get("fpx") or (0, 0)            # (W, I) of the reference's FPX, or None for float
     d.fpx_w, d.fpx_i = int(fpx[0]), int(fpx[1])
+    # the design's arithmetic (reference: Project(float_or_fixed, fpx) baked into the generated design): a mode name or
+    # number fixes it for this model whatever set_option("math") says later; None = -1 = every launch follows the
+    # process-wide option as it stands at that launch (A/B measurements and the tests that toggle it)
+    m = spec.get("math")
+    d.math = -1 if m is None else (MATH_MODES[m] if isinstance(m, str) else int(m))
     return d
 
 
@@ -250,12 +265,17 @@ class CompiledModel:
 
     @classmethod
     def from_model(cls, model, max_graphs: int, max_nodes: int, max_edges: int,
-                   max_graph_nodes: int = 0, fpx=None) -> "CompiledModel":
+                   max_graph_nodes: int = 0, fpx=None, math=None) -> "CompiledModel":
         """``model``: a ``gnnbuilder_amd.models.GNNModel``.  ``max_graph_nodes``: promise on the largest
         graph (0 = none); small molecules enable the LDS-resident fused kernels, and the promise is
         validated on the device (``check()`` raises if a batch breaks it).  ``fpx``: ``(W, I)`` or a
-        ``code_gen.FPX`` = layer-boundary emulation of the reference's ``ap_fixed<W, I>`` build (None: float)."""
+        ``code_gen.FPX`` = layer-boundary emulation of the reference's ``ap_fixed<W, I>`` build (None: float).
+        ``math``: "fp32" | "bf16x6" | "bf16x3" | "f16x3" (or 0..3) = the model's own arithmetic, captured at creation
+        (``gnnb_model_desc::math``); None = follow ``set_option("math", ...)`` at every launch.  In the reduced modes
+        ``check()`` raises ``GnnbRangeError`` when a kernel produced a non-finite value (fp16's range)."""
         spec = model.spec()
+        if math is not None:
+            spec["math"] = math
         if fpx is not None:
             spec["fpx"] = (int(fpx.W), int(fpx.I)) if hasattr(fpx, "W") else (int(fpx[0]), int(fpx[1]))
         return cls(spec, model.canonical_params(), max_graphs, max_nodes, max_edges, max_graph_nodes)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNB_VERSION 102
+#define GNNB_VERSION 103
 
 typedef enum gnnb_status {
     GNNB_OK = 0,
@@ -42,8 +42,11 @@ typedef enum gnnb_status {
     GNNB_ERR_CAPACITY = -2,  /* batch exceeds the workspace (reference: silent overflow) */
     GNNB_ERR_HIP = -3,       /* a HIP runtime call failed */
     GNNB_ERR_NO_DEVICE = -4, /* no gfx950 device visible */
-    GNNB_ERR_GRAPH = -5      /* malformed batch: an edge leaves its graph, ptr not monotone, a broken max_graph_nodes
+    GNNB_ERR_GRAPH = -5,     /* malformed batch: an edge leaves its graph, ptr not monotone, a broken max_graph_nodes
                               * promise, a large-segment triple that disagrees with the ptr arrays */
+    GNNB_ERR_RANGE = -6      /* a REDUCED-precision math mode (gnnb_model_desc::math 2 / 3) produced a non-finite value: fp16's
+                              * range (65504) was exceeded by an activation or a weight, or the inputs were not finite.  The
+                              * results of that forward are unspecified; run the model with math = 0 (gnnb_workspace_check) */
 } gnnb_status;
 
 /* gnnbuilder/models.py:453-459 (SUPPORTED_GNN_CONVS; GAT has no native path in the
@@ -90,6 +93,20 @@ typedef struct gnnb_model_desc {
      * format reproduces the float model to 1e-3.  The fused stack kernels are not used in this mode. */
     int32_t fpx_w;
     int32_t fpx_i;
+    /* Arithmetic of the dense updates -- a property of the DESIGN, as float_or_fixed / fpx are in the reference
+     * (code_gen.py:63-82 Project(float_or_fixed, fpx) baked into model.h.jinja:38-62), captured by gnnb_model_create
+     * and used by every launch of this model's forwards and of its workspaces' graph preps, whatever other models of
+     * the process use and whatever gnnb_set_option("math", ...) is called later, from any thread:
+     *    0  native fp32 MFMA everywhere (what bench.py's `value` runs)
+     *    1  "bf16x6": fp32-equivalent, six bf16 MFMA products of an exact 3-way split
+     *    2  "bf16x3": REDUCED precision (~18 significant bits per product)
+     *    3  "f16x3":  REDUCED precision (~22 bits) with fp16's RANGE -- see "math" under gnnb_set_option below
+     *   -1  not a property of this model: every launch follows the process-wide option "math" as it stands AT THAT
+     *       LAUNCH (the pre-103 behaviour; what the Python runtime passes unless told otherwise, for A/B measurements)
+     * (version 103; a zero-initialised description is a native-fp32 design.)  In modes 2 and 3 every reduced kernel
+     * checks what it produces: a non-finite value sets flag 64 of the workspace, reported as GNNB_ERR_RANGE by
+     * gnnb_workspace_check (and lazily by the next gnnb_graph_prep on that workspace). */
+    int32_t math;
 } gnnb_model_desc;
 
 #define GNNB_MAX_LAYERS 16
@@ -377,7 +394,10 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *                                forms always carry it); 0 = the skip operand
  *   large_fork (default 2)       how a batch's large segment (gnnb_workspace_set_large_segment) runs: 2 = small per-layer
  *                                kernels behind the stack kernel, 1 = the same on a side stream, 0 = the big layer-wise kernels
- * "math": 0 (default) = native fp32 MFMA everywhere; 1 = every wide update (the fused GCN stack's A1.W1^T, the
+ * "math": the PROCESS-WIDE default of the math mode -- what the stand-alone entries (gnnb_linear, ...) run in and what models
+ * created with gnnb_model_desc::math = -1 follow at every launch; a model whose description names a mode (0 .. 3) never reads
+ * it (version 103: two designs of different precision in one process, or a thread calling gnnb_set_option, do not change each
+ * other's arithmetic).  0 (default) = native fp32 MFMA everywhere; 1 = every wide update (the fused GCN stack's A1.W1^T, the
  * K <= 128 GEMMs, the large-K segmented GEMM) as six bf16 MFMA products of an exact 3-way bf16 split of both fp32
  * operands, fp32 accumulate (results at fp32 rounding level; GNNB_MATH=1); stack kernels that are faster
  * in fp32 than any bf16x6 form (k_gcn2_zf, the GIN / deep stacks) keep running: the mode is never slower than 0.

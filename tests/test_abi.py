@@ -43,15 +43,21 @@ def test_library_has_gfx950_code_object(lib_path):
 
 def test_library_loads_and_reports_version(lib_path):
     lib = runtime.load_library(require_gpu=False)
-    assert lib.gnnb_version() == 102
+    assert lib.gnnb_version() == 103
     for sym in runtime.EXPORTED_SYMBOLS:
         assert hasattr(lib, sym)
 
 
 def test_struct_layout_matches_header():
-    # 18 int32/float fields + pools[3] = 20 * 4 bytes
+    # 19 int32/float fields (version 103: + math) + pools[3] = 21 * 4 bytes, in the header's order
     import ctypes
-    assert ctypes.sizeof(runtime.ModelDesc) == 20 * 4
+    import re
+    assert ctypes.sizeof(runtime.ModelDesc) == 21 * 4
+    hdr = (ROOT / "include" / "gnnb_hip.h").read_text()
+    body = hdr[hdr.index("typedef struct gnnb_model_desc {"):hdr.index("} gnnb_model_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"(?:int32_t|float)\s+(\w+)(?:\[\d+\])?;", body)
+    assert names == [f[0] for f in runtime.ModelDesc._fields_]
     assert ctypes.sizeof(runtime.GemmSeg) == 24
 
 

@@ -123,17 +123,18 @@ def test_constructor_validation_matches_the_reference():
 
 
 def test_math_mode_is_rendered_into_the_generated_shim(tmp_path):
-    """Project(math=...) -> gnnb_set_option("math", n) in front of gnnb_model_create in <name>.cpp; the default emits nothing."""
+    """Project(math=...) -> the `math` field of the generated design's gnnb_model_desc (its own arithmetic, captured by
+    gnnb_model_create: no process-wide option is touched); the reduced modes' shims ask the workspace for GNNB_ERR_RANGE."""
     model = make_model("gcn", hidden=8)
     ds = ListDataset.from_batch(synthetic.make_batch("esol", 2, seed=1), y_dim=1)
-    for mode, n in (("fp32", None), ("bf16x6", 1), ("f16x3", 3)):
+    for mode, n in (("fp32", 0), ("bf16x6", 1), ("f16x3", 3)):
         proj = gnnb.Project(f"m_{mode}", model, "regression", None, tmp_path, dataset=ds, max_nodes=64, max_edges=200, math=mode)
         proj.gen_hw_model()
         src = (proj.model_dir / "model.cpp").read_text()
-        if n is None:
-            assert "gnnb_set_option" not in src
-        else:
-            assert f'gnnb_set_option("math", {n});' in src and src.index("gnnb_set_option") < src.index("gnnb_model_create(&k_desc")
+        assert "gnnb_set_option" not in src
+        desc = src[src.index("k_desc = {"):src.index("};", src.index("k_desc = {"))]
+        assert f"/* math           */ {n}," in desc
+        assert ("gnnb_workspace_check(g_ws, NULL)" in src) == (n >= 2)
 
 
 def test_tb_data_reader_round_trips_what_the_writer_wrote(project):

@@ -2130,6 +2130,46 @@ def test_large_segment_keeps_the_stack_for_the_rest_of_the_batch(dev, conv, laye
     assert np.abs(lw - out).max() < 5e-5 * scale
 
 
+@pytest.mark.parametrize("conv,layers,hidden,degree", [("sage", 2, 256, False), ("sage", 3, 128, False), ("pna", 3, 128, True), ("pna", 2, 64, False)])
+def test_large_segment_under_graphsage_and_pna(dev, conv, layers, hidden, degree):
+    """Round-5 advisor finding (high): with a large segment set the max_graph_nodes promise covers graphs [0, promise_graphs)
+    only -- graph prep validates nothing about the rest -- but GraphSAGE / PNA run the WHOLE batch layer by layer, and their
+    stage kernels (k_sage_first_mean, k_pna_first, k_pna_pagg: whole graphs in a 56 / 64-row stage) tested the promise alone:
+    the large graphs got clamped sources, unflagged.  Those launchers now refuse such a batch (the layer-by-layer kernels
+    run); every graph against the oracle, the 300-node graph included."""
+    model = make_model(conv, in_dim=9, hidden=hidden, layers=layers, out_dim=hidden, act="relu", pools=("add", "max", "mean"), task_out=3, seed=6)
+    b0 = synthetic.make_batch("molhiv_tail", 300, seed=12)
+    rng = np.random.default_rng(40)
+    n_big = 300
+    big_e = np.stack([rng.integers(0, n_big, 600), rng.integers(0, n_big, 600)], 1).astype(np.int32)
+    graphs = [b0.graph(g) for g in range(150)] + [(rng.uniform(-1, 1, (n_big, 9)).astype(np.float32), big_e)] + [b0.graph(g) for g in range(150, 300)]
+    batch = pack_graphs(graphs)
+    limit = 40
+    assert (np.diff(batch.node_ptr) > limit).sum() >= 3
+    ref = O.forward_batched(model.spec(), canon(model), batch.x, batch.coo, batch.node_ptr, batch.edge_ptr)
+    from gnnbuilder_amd.batching import order_large_last
+    ordered, perm, (g0, n0, e0) = order_large_last(batch, limit)
+    cm = runtime.CompiledModel.from_model(model, ordered.num_graphs, ordered.num_nodes, ordered.num_edges, max_graph_nodes=limit)
+    if degree:  # (PNA's degree-class form: the promise holds for the whole batch)
+        maxdeg = int(np.bincount(ordered.coo[:, 1], minlength=ordered.num_nodes).max())
+        if maxdeg <= 15:
+            cm.set_max_degree(maxdeg)
+    cm.set_large_segment(g0, n0, e0)
+    out = cm.forward(*to_dev(ordered, dev)).cpu().numpy()[np.argsort(perm)]
+    cm.check()
+    assert cm.last_path() == "layerwise"
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(out - ref).max(axis=1)
+    assert err.max() < TOL * scale, (int(err.argmax()), float(err.max()))
+    # the same batch without a segment and an honest promise: the same kernels, the same bits
+    cm2 = runtime.CompiledModel.from_model(model, ordered.num_graphs, ordered.num_nodes, ordered.num_edges, max_graph_nodes=n_big)
+    if degree and maxdeg <= 15:
+        cm2.set_max_degree(maxdeg)
+    out2 = cm2.forward(*to_dev(ordered, dev)).cpu().numpy()[np.argsort(perm)]
+    cm2.check()
+    assert np.array_equal(out, out2)
+
+
 def test_large_segment_edge_cases(dev):
     """All graphs large (segment starts at graph 0: plain layer-by-layer run), no graph large (segment empty: plain stack
     run), a segment outside the batch is refused, and a graph in FRONT of the segment that breaks the promise is still
