@@ -965,6 +965,13 @@ def main():
         ceiling = copy_ceiling(batches[0].num_nodes, w["hidden"], dev)
         if "copy_same_launch_shape" in agg:
             ceiling["own_float4_copy_same_launch_shape_hbm"] = agg["copy_same_launch_shape"]
+        # what plain byte-moving kernels reach on this pool's boxes (tools/copy_forms.py, committed; not re-measured here): the
+        # best form at the C5-sized and the C2-sized launch, and what the ring kernel's own ownership pattern costs
+        cal = ROOT / "profiles" / "r06_copy_calibration.json"
+        if cal.exists():
+            c = json.loads(cal.read_text())
+            ceiling["pool_copy_ceiling_tbps"] = {**c["pool_copy_ceiling_tbps"], "measured_in_this_run": False,
+                                                 "file": "profiles/r06_copy_calibration.json", "findings": c["findings"][1:4]}
         gather = {
             "kernel": "k_aggregate_ring<GCN> (gather-aggregate, width %d)" % w["hidden"],
             "bound": "hbm", "achieved": agg["hbm"]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -180,6 +180,18 @@ struct RangeProbe {
     }
 };
 
+// The run [c0, c1) of `total` units that workgroup b of G takes: floor(b total / G) .. floor((b + 1) total / G), in 32-bit
+// arithmetic.  Written as (long long) b * total / G the two cuts were two SOFTWARE 64-bit divisions -- ~300 scalar instructions
+// per wave in front of every persistent kernel's first DMA (round 6, read from the ISA: 1.1 M of k_gcn2_zf's 3.7 M scalar
+// instructions per launch at BASELINE config 2 were these).  Exact: total = q G + r  =>  floor(b total / G) = b q + floor(b r / G),
+// and b r < G^2 fits 32 bits for grids below 65536 workgroups (the launchers' grids are a few per CU).
+__device__ __forceinline__ void run_cuts(unsigned b, unsigned G, unsigned total, int &c0, int &c1)
+{
+    const unsigned q = total / G, r = total - q * G;
+    c0 = (int)(b * q + (b * r) / G);
+    c1 = (int)((b + 1) * q + ((b + 1) * r) / G);
+}
+
 // LDS-DMA helpers (global_load_lds: global -> LDS without VGPR staging).
 typedef __attribute__((address_space(3))) void *lds_vptr;
 typedef const __attribute__((address_space(1))) void *glb_vptr;
@@ -344,8 +356,15 @@ __device__ inline float act_apply(float v, int act)
 template <int ACT>
 __device__ inline float act_t(float v)
 {
-    if (ACT == GNNB_ACT_RELU)
-        return v > 0.0f ? v : 0.0f;
+    if (ACT == GNNB_ACT_RELU) {
+        // ONE v_max_f32: written as `v > 0 ? v : 0` (or fmaxf) the compiler canonicalises an operand it cannot prove quiet
+        // first -- v_max v, v, v in front of every v_max v, 0, v behind an MFMA: twice the instructions in every epilogue
+        // (round 6, read from k_gcn2_zf's ISA; fp32 MFMA and VALU share the issue port).  Same result for every input but a
+        // signalling NaN (quieted instead of 0), which no kernel produces.
+        float r;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+        return r;
+    }
     if (ACT == GNNB_ACT_GELU)
         return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     if (ACT == GNNB_ACT_SIGMOID)

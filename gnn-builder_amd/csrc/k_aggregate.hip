@@ -357,8 +357,9 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
         if (r_hi <= r_lo)
             return;
     } else {
-        t0 = tile_lo + (int)(((long long)blockIdx.x * (num_tiles - tile_lo)) / gridDim.x);
-        t1 = tile_lo + (int)(((long long)(blockIdx.x + 1) * (num_tiles - tile_lo)) / gridDim.x);
+        run_cuts(blockIdx.x, gridDim.x, (unsigned)(num_tiles - tile_lo), t0, t1); // (32-bit: gnnb_device.h)
+        t0 += tile_lo;
+        t1 += tile_lo;
     }
     if (t0 >= t1)
         return; // (workgroup-uniform)
@@ -400,8 +401,14 @@ __global__ __launch_bounds__(1024) void k_aggregate_ring(
             const char *gx = reinterpret_cast<const char *>(x + (size_t)nb_ * w);
             if (VEC == 4) {
                 for (int c = sw * 1024; c < bytes; c += sn * 1024, ops++)
-                    if (c + lane * 16 < bytes)
+                    if (c + lane * 16 < bytes) {
+#ifdef GNNB_AGG_NT_LOAD // (development A/B, round 6: the feature rows' LDS-DMA with the non-temporal policy -- every row is read once)
+                        const uint32_t a_ = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_vptr)(sb + c));
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(a_), "v"(gx + c + lane * 16) : "memory");
+#else
                         dma16_to_lds_u(gx + c + lane * 16, sb + c);
+#endif
+                    }
             } else {
                 for (int c = sw * 64; c < rows_ * w; c += sn * 64, ops++)
                     if (c + lane < rows_ * w)

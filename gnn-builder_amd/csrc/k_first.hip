@@ -58,8 +58,9 @@ __global__ __launch_bounds__(F1_WG, 2) void k_conv_first(
     // per-wave scratch for the output transpose: 16 rows x 32 columns (+ 4 floats of padding per row)
     float *ST = A0 + F1_CAP * LD0 + wave * (16 * 36);
 
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    int t0, t1;
+
+    run_cuts(blockIdx.x, gridDim.x, (unsigned)num_tiles, t0, t1); // (32-bit: gnnb_device.h)
     if (t1 <= t0)
         return;
     // window of the tile table in registers: lane l holds tile t0 + l (the launcher keeps runs below 64 tiles)

@@ -43,8 +43,9 @@ __global__ __launch_bounds__(FM_WG, 2) void k_sage_first_mean(const float *__res
     float *A0 = reinterpret_cast<float *>(smem + 2 * (size_t)in_b);
     float *YT = A0 + FM_CAP * LD0;
 
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    int t0, t1;
+
+    run_cuts(blockIdx.x, gridDim.x, (unsigned)num_tiles, t0, t1); // (32-bit: gnnb_device.h)
     if (t1 <= t0)
         return;
     // window of the tile table in registers: lane l holds tile t0 + l (the launcher keeps runs below 64 tiles); clamped: the

@@ -952,8 +952,8 @@ __global__ __launch_bounds__(WG, MATH ? 2 : 3) void k_linear_reg(
     // ---- persistent range, balanced in UNITS of 16*RG rows (half a stage), so the remainder a
     // workgroup may carry is half a stage.  Local stage j covers units [u0+2j, min(u0+2j+2, u1)).
     const int num_units = (M + unit_rows - 1) / unit_rows;
-    const int u0 = (int)(((long long)blockIdx.x * num_units) / gridDim.x);
-    const int u1 = (int)(((long long)(blockIdx.x + 1) * num_units) / gridDim.x);
+    int u0, u1;
+    run_cuts(blockIdx.x, gridDim.x, (unsigned)num_units, u0, u1); // (32-bit: gnnb_device.h)
     if (u1 <= u0)
         return;
     const int nstages = (u1 - u0 + SR - 1) / SR;

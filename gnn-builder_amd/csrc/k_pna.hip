@@ -57,8 +57,9 @@ __global__ __launch_bounds__(PA_WG, 2) void k_pna_pagg(const float *__restrict__
     // ---- LDS carve: two buffers {x rows, padded -> P | node records | CSR slice}
     constexpr int xs_b = PA_CAP * LDX * 4, rec_o = xs_b, col_o = rec_o + PA_CAP * 32, in_b = col_o + PA_ECAP * 4;
 
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    int t0, t1;
+
+    run_cuts(blockIdx.x, gridDim.x, (unsigned)num_tiles, t0, t1); // (32-bit: gnnb_device.h)
     if (t1 <= t0)
         return;
     // window of the tile table in registers: lane l holds tile t0 + l (the launcher keeps runs below 64 tiles)

@@ -50,8 +50,9 @@ __global__ __launch_bounds__(PF_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     float *A0 = PQ + ((PF_CAP * LDP + 3) & ~3);
     float *YT = A0;
 
-    const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    int t0, t1;
+
+    run_cuts(blockIdx.x, gridDim.x, (unsigned)num_tiles, t0, t1); // (32-bit: gnnb_device.h)
     if (t1 <= t0)
         return;
     const int ti = min(t0 + min(lane, t1 - t0), num_tiles);

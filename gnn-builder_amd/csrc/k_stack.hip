@@ -423,8 +423,8 @@ __global__ __launch_bounds__(G2_WG, 4) void k_gcn2_fused(
 
     // the workgroup's run of node tiles: whole stages of the batch's global greedy stage list when graph prep made the cut
     // table for this grid (every workgroup the same number of stages +- 1, none ragged: round 5), else equal tile counts
-    int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
-    int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+    int t0, t1;
+    run_cuts(blockIdx.x, gridDim.x, (unsigned)num_tiles, t0, t1); // (32-bit: gnnb_device.h)
     if (stage_cut && stage_cut[gridDim.x + 1] == 1) { // (clamped: a flagged batch's table may hold anything; the run must stay in range and below the LDS window)
         t0 = min(max(stage_cut[blockIdx.x], 0), num_tiles);
         t1 = min(max(stage_cut[blockIdx.x + 1], t0), min(num_tiles, t0 + G2_TCAP - 1));
@@ -1185,9 +1185,9 @@ hipError_t launch_gcn2_fused(const BatchTables &t, const float *x, int f0, const
             go2(atag, q0tag, q1tag, IntTag<1>{}, IntTag<0>{}, IntTag<0>{});
         else if (deep.nl > 2) {
             // (the deep variants have no register to spare -- GELU 125 of 128 in fp32, its f16x3 form spilled one; with the reduced
-            // mode's overflow probe, round 6, the sigmoid / tanh forms at hidden 128 spill one too --: only ReLU stacks take f16x3,
-            // the others keep fp32 in the mode, which is never less accurate)
-            if constexpr (decltype(atag)::value == GNNB_ACT_RELU) {
+            // mode's overflow probe, round 6, the sigmoid / tanh forms at hidden 128 spill one too --: at hidden 128 only ReLU stacks
+            // take f16x3, the others keep fp32 in the mode, which is never less accurate; narrower stacks have registers to spare)
+            if constexpr (decltype(atag)::value == GNNB_ACT_RELU || (decltype(atag)::value != GNNB_ACT_GELU && decltype(q1tag)::value < 8)) {
                 if (h3) {
                     go2(atag, q0tag, q1tag, IntTag<0>{}, IntTag<1>{}, IntTag<1>{});
                     return;

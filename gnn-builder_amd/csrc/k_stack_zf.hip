@@ -258,7 +258,7 @@ struct ZfStage {
 // wave slot, and with ~145 KB of LDS per CU that is what lets the readout and graph-prep kernels of the other batches in
 // flight run BESIDE it: at 111 registers the three-stream pipeline of bench.py lost 12 % (59.0 vs 52.1 us per step).
 // (The launch bound only promises four waves per SIMD = 128 registers; amdgpu_num_vgpr is ignored beside it.)
-template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS, int MX = 0>
+template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS, int MX = 0, bool H1FULL = false>
 __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
@@ -277,6 +277,17 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
 #endif
 )
 {
+    // WIDTHS THE COMPILER MAY TREAT AS CONSTANTS (round 6; same-box A/B at BASELINE config 2, wide shape, us per launch: all run-time
+    // 38.7; h0 38.25; + layer 1's wave roles 37.95; + P1's lane geometry 37.3; + the H / Z row stride or the Z write's column
+    // predicate +-0; h1 constant EVERYWHERE -- prologue loads, carve, stride -- 42.3: slower than none, as round 4 found, "the
+    // kernel sits in a code-generation optimum that instruction counts do not predict").  h0 is 16 KQ1 by dispatch; H1FULL says
+    // the last layer is as wide (h1 == 16 KQ1: every BASELINE GCN model): the wave roles (cs1l, nrg1) and P1's (csl, Gl, S, the lane
+    // -> (row slot, chunk) map) are then literals -- ~45 scalar registers less to spill into vector lanes and read back with
+    // v_readlane inside the stage loop (the ISA had 92 such instructions there, 27 now), and the two scalar loops that re-derived
+    // them per stage are gone.  h1 itself stays the run-time argument everywhere else.
+    h0 = 16 * KQ1;
+    const int h1g = H1FULL ? 16 * KQ1 : h1; // layer 1's wave roles
+    const int h1p = H1FULL ? 16 * KQ1 : h1; // P1's lane geometry and the pooled row's width
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ZF_CAP = 16 * ZF_UNITS, G2_NW = NW;
     constexpr int GMAX = ZF_CAP <= 96 ? 64 : 128; // graph boundaries of a stage kept in LDS (more: empty graphs piling up)
@@ -349,8 +360,13 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     // fixed-size chunks was built and measured: a chunk must fit a stage whatever its last graph's overhang, i.e. 64
     // nominal rows of a 96-row stage, which turns two stages per workgroup into 2.25 -- three rounds, 55 us instead of 44.
     // The planner below uses the capacity adaptively instead: what one stage's overhang takes the other gives.)
+#ifdef ZF_OLD_CUTS // (development A/B: the two 64-bit software divisions every wave ran until round 6)
     const int t0 = (int)(((long long)blockIdx.x * num_tiles) / gridDim.x);
     const int t1 = (int)(((long long)(blockIdx.x + 1) * num_tiles) / gridDim.x);
+#else
+    int t0, t1;
+    run_cuts(blockIdx.x, gridDim.x, (unsigned)num_tiles, t0, t1); // (32-bit: gnnb_device.h)
+#endif
     if (t1 <= t0)
         return;
     // Every wave fetches the run's tile-table entries into REGISTERS (lane l: tile t0 + l; the launcher keeps runs below
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     int cs0l = 0, cs1l = 0;
     while ((16 << cs0l) < h0)
         cs0l++;
-    while ((16 << cs1l) < h1)
+    while ((16 << cs1l) < h1g)
         cs1l++; // h <= 128 -> <= 3
     const int nrg0 = G2_NW >> cs0l, nrg1 = G2_NW >> cs1l;
     constexpr int LOG2NW = NW == 16 ? 4 : 3;
@@ -891,7 +907,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         const int ngr = cur.gb - cur.ga;
         int csl = 0; // log2(CS)
         {
-            const int nv = h1 >> 2; // float4 chunks per row
+            const int nv = h1p >> 2; // float4 chunks per row
             const bool pow2 = (nv & (nv - 1)) == 0;
             // (column parts only while the tasks fill at most HALF of the waves: the phase is bound by the instructions the
             // SIMDs have to issue -- shared with the MFMA stream of the co-resident workgroup --, not by the longest wave,
@@ -906,7 +922,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
         if (ZF_ON(0)) {
             typedef Vf<4> V;
             int glog2 = 2; // lanes per row: the next power of two >= chunks per part
-            while ((4 << glog2) < (h1 >> csl) && glog2 < 5)
+            while ((4 << glog2) < (h1p >> csl) && glog2 < 5)
                 glog2++;
             const int Gl = 1 << glog2, S = 64 >> glog2;
             // lane -> (row slot sr, chunk gl).  ds_read_b128 is served in four passes of sixteen lanes, {0-3, 12-15, 20-27},
@@ -930,7 +946,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             const int32_t *scol = reinterpret_cast<const int32_t *>(SCOLb + (size_t)b * ECAP * 4);
             const bool col_lds = cur.ne <= ECAP;
             const int e0 = cur.e0;
-            const int wpart = (h1 >> csl); // columns per part
+            const int wpart = (h1p >> csl); // columns per part
             auto reduce_graph = [&](int gi, int cpart, int r0g, int r1g) { // wave-uniform row range of graph ga + gi
                 r0g = max(__builtin_amdgcn_readfirstlane(r0g) - nb, 0);
                 r1g = min(__builtin_amdgcn_readfirstlane(r1g) - nb, rows);
@@ -1104,7 +1120,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                             rr = n > 0 ? vmul(sum, V::splat(1.0f / (float)n)) : V::splat(0.0f);
                         else if (pools[kk] == GNNB_POOL_MAX)
                             rr = n > 0 ? mx : V::splat(0.0f);
-                        rr.store(pooled + ((size_t)(cur.ga + gi) * np + kk) * h1 + col0);
+                        rr.store(pooled + ((size_t)(cur.ga + gi) * np + kk) * h1p + col0);
                     }
                 }
             };
@@ -1296,10 +1312,10 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
         }
     }
     hipError_t rc = hipErrorNotSupported;
-    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag, auto mxtag) {
+    auto go3 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag, auto mxtag, auto fulltag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
         constexpr int NW = decltype(nwtag)::value, NU = decltype(utag)::value, MX = decltype(mxtag)::value;
-        auto kern = k_gcn2_zf<ACT, KQ0, KQ1, NW, NU, MX>;
+        auto kern = k_gcn2_zf<ACT, KQ0, KQ1, NW, NU, MX, decltype(fulltag)::value != 0>;
         if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess) {
             rc = hipErrorNotSupported;
             return;
@@ -1343,6 +1359,16 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
 #endif
         );
         rc = hipGetLastError();
+    };
+    // (the wide shape also exists with the last layer's width as a literal: h1 == h0 -- see the kernel's note on widths)
+    auto go2 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag, auto mxtag) {
+        if constexpr (decltype(nwtag)::value == 16) {
+            if (h1 == h0) {
+                go3(atag, q0tag, q1tag, nwtag, utag, mxtag, IntTag<1>{});
+                return;
+            }
+        }
+        go3(atag, q0tag, q1tag, nwtag, utag, mxtag, IntTag<0>{});
     };
     auto go = [&](auto atag, auto q0tag, auto q1tag) {
         if constexpr (decltype(q0tag)::value == 1) { // (the wide shape exists for one-block input widths only)

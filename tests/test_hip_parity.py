@@ -2161,13 +2161,13 @@ def test_large_segment_under_graphsage_and_pna(dev, conv, layers, hidden, degree
     scale = max(1.0, float(np.abs(ref).max()))
     err = np.abs(out - ref).max(axis=1)
     assert err.max() < TOL * scale, (int(err.argmax()), float(err.max()))
-    # the same batch without a segment and an honest promise: the same kernels, the same bits
+    # the same batch without a segment and an honest promise: layer by layer too (other launch shapes: same numbers, not the same bits)
     cm2 = runtime.CompiledModel.from_model(model, ordered.num_graphs, ordered.num_nodes, ordered.num_edges, max_graph_nodes=n_big)
     if degree and maxdeg <= 15:
         cm2.set_max_degree(maxdeg)
     out2 = cm2.forward(*to_dev(ordered, dev)).cpu().numpy()[np.argsort(perm)]
     cm2.check()
-    assert np.array_equal(out, out2)
+    assert cm2.last_path() == "layerwise" and np.abs(out - out2).max() < 5e-5 * scale
 
 
 def test_large_segment_edge_cases(dev):

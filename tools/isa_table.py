@@ -8,7 +8,7 @@ LDS, VMEM, SMEM, waits / barriers, branches.  Loops are reported with their back
 can be formed as  sum(block count x trips).  No GPU needed.  ("build the per-phase static
 instruction table from the ISA".)
 
-    python tools/isa_table.py                      # k_gcn2_zf<RELU, 1, 8, 16, 11, fp32>, the BASELINE config 2 kernel
+    python tools/isa_table.py                      # k_gcn2_zf<RELU, 1, 8, 16 waves, 11 units, fp32, h1 == h0>, the BASELINE config 2 kernel
     python tools/isa_table.py --blocks             # + every basic block
     python tools/isa_table.py --json profiles/r06_c2_gcn2_isa_table.json
 """
@@ -109,7 +109,7 @@ def parse(text: list[str]):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--unit", default="k_stack_zf")
-    ap.add_argument("--kernel", default=r"k_gcn2_zfILi0ELi1ELi8ELi16ELi11ELi0E")
+    ap.add_argument("--kernel", default=r"k_gcn2_zfILi0ELi1ELi8ELi16ELi11ELi0ELb1E")
     ap.add_argument("--define", action="append", default=["GNNB_DEV_FAST", "GNNB_ZF_MARK"])
     ap.add_argument("--blocks", action="store_true")
     ap.add_argument("--dump", help="write the kernel's assembly text here")

@@ -132,11 +132,162 @@ __global__ __launch_bounds__(256) void k_copy_lds(const f32x4 *__restrict__ src,
     }
 }
 
+// ---- the same bytes with BLOCKED ownership (what a persistent kernel that walks a contiguous run of rows per workgroup does --
+// k_aggregate_ring: one run of node tiles per CU): workgroup b owns elements [b n / G, (b + 1) n / G).  At any moment the chip then
+// reads G windows that lie n / G apart instead of one sliding window of G x 4 KiB: does the address pattern alone cost bandwidth?
+__global__ __launch_bounds__(256) void k_copy_nt_blk(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n)
+{
+    const size_t per = (n + gridDim.x - 1) / gridDim.x, lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+// LDS-DMA ring per wave (as k_copy_lds), the workgroup owning a contiguous run of 1-KiB pieces, its four waves interleaved inside it
+__global__ __launch_bounds__(256) void k_copy_lds_blk(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n)
+{
+    __shared__ __attribute__((aligned(16))) char buf[4 * 4 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t pieces = n / 64;
+    const size_t per = (pieces + gridDim.x - 1) / gridDim.x, lo = (size_t)blockIdx.x * per, hi = lo + per < pieces ? lo + per : pieces;
+    char *mine = buf + wave * 4096;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)mine;
+    auto fire = [&](size_t p, int slot) {
+        const f32x4 *g = src + p * 64 + lane;
+        const uint32_t m0 = __builtin_amdgcn_readfirstlane(lbase + slot * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(g) : "memory");
+    };
+    size_t p = lo + wave;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (p + k * 4 < hi)
+            fire(p + k * 4, k);
+    int slot = 0;
+    for (; p < hi; p += 4) {
+        const size_t pn = p + 12;
+        if (pn < hi) {
+            fire(pn, (slot + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(mine + slot * 1024 + lane * 16);
+        __builtin_nontemporal_store(v, dst + p * 64 + lane);
+        slot = (slot + 1) & 3;
+    }
+}
+// ... and with 1024-thread workgroups (16 waves, as the ring kernel): the workgroup owns a contiguous run, 16 waves interleaved
+__global__ __launch_bounds__(1024) void k_copy_lds_blk16(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n)
+{
+    __shared__ __attribute__((aligned(16))) char buf[16 * 4 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t pieces = n / 64;
+    const size_t per = (pieces + gridDim.x - 1) / gridDim.x, lo = (size_t)blockIdx.x * per, hi = lo + per < pieces ? lo + per : pieces;
+    char *mine = buf + wave * 4096;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)mine;
+    auto fire = [&](size_t p, int slot) {
+        const f32x4 *g = src + p * 64 + lane;
+        const uint32_t m0 = __builtin_amdgcn_readfirstlane(lbase + slot * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(g) : "memory");
+    };
+    size_t p = lo + wave;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (p + k * 16 < hi)
+            fire(p + k * 16, k);
+    int slot = 0;
+    for (; p < hi; p += 16) {
+        const size_t pn = p + 48;
+        if (pn < hi) {
+            fire(pn, (slot + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(mine + slot * 1024 + lane * 16);
+        __builtin_nontemporal_store(v, dst + p * 64 + lane);
+        slot = (slot + 1) & 3;
+    }
+}
+// the ring kernel's OTHER property: 16-wave workgroups whose waves interleave over the whole buffer (no blocked ownership)
+__global__ __launch_bounds__(1024) void k_copy_lds_16(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n)
+{
+    __shared__ __attribute__((aligned(16))) char buf[16 * 4 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t nwaves = (size_t)gridDim.x * 16, w = (size_t)blockIdx.x * 16 + wave;
+    const size_t pieces = n / 64;
+    char *mine = buf + wave * 4096;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)mine;
+    auto fire = [&](size_t p, int slot) {
+        const f32x4 *g = src + p * 64 + lane;
+        const uint32_t m0 = __builtin_amdgcn_readfirstlane(lbase + slot * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(g) : "memory");
+    };
+    size_t p = w;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (p + k * nwaves < pieces)
+            fire(p + k * nwaves, k);
+    int slot = 0;
+    for (; p < pieces; p += nwaves) {
+        const size_t pn = p + 3 * nwaves;
+        if (pn < pieces) {
+            fire(pn, (slot + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(mine + slot * 1024 + lane * 16);
+        __builtin_nontemporal_store(v, dst + p * 64 + lane);
+        slot = (slot + 1) & 3;
+    }
+}
+
+// ... and in between: the 16-wave workgroup takes CHUNKS of CK KiB round robin (chunk c = b, b + G, ...), its waves interleaved inside
+// a chunk -- ownership interleaved at the granularity of one LDS stage of the ring kernel instead of one run per launch
+template <int CK>
+__global__ __launch_bounds__(1024) void k_copy_lds_chunk16(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n)
+{
+    __shared__ __attribute__((aligned(16))) char buf[16 * 4 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t pieces = n / 64;
+    char *mine = buf + wave * 4096;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)mine;
+    auto fire = [&](size_t p, int slot) {
+        const f32x4 *g = src + p * 64 + lane;
+        const uint32_t m0 = __builtin_amdgcn_readfirstlane(lbase + slot * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(g) : "memory");
+    };
+    // the wave's k-th piece: chunk (b + (k / PW) G), piece wave + 16 (k % PW) inside it; PW = pieces per wave and chunk
+    constexpr int PW = CK / 16;
+    const size_t nchunks = (pieces + CK - 1) / CK;
+    auto piece_of = [&](size_t k) -> size_t {
+        const size_t c = blockIdx.x + (k / PW) * (size_t)gridDim.x;
+        return c < nchunks ? c * CK + wave + 16 * (k % PW) : pieces;
+    };
+    size_t k = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        if (piece_of(j) < pieces)
+            fire(piece_of(j), j);
+    int slot = 0;
+    for (;; k++) {
+        const size_t p = piece_of(k);
+        if (p >= pieces)
+            break;
+        const size_t pn = piece_of(k + 3);
+        if (pn < pieces) {
+            fire(pn, (slot + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(mine + slot * 1024 + lane * 16);
+        __builtin_nontemporal_store(v, dst + p * 64 + lane);
+        slot = (slot + 1) & 3;
+    }
+}
+
 typedef void (*kern_t)(const f32x4 *, f32x4 *, size_t);
 struct Form {
     const char *name;
     kern_t k;
     int reads, writes; // bytes moved per element = 16 * (reads + writes)
+    int threads = 256; // per workgroup
 };
 
 int main(int argc, char **argv)
@@ -144,7 +295,11 @@ int main(int argc, char **argv)
     const int reps = argc > 1 ? atoi(argv[1]) : 20, trials = argc > 2 ? atoi(argv[2]) : 5;
     const Form forms[] = {{"copy", k_copy, 1, 1},         {"copy_nt", k_copy_nt, 1, 1}, {"copy_nt_st", k_copy_nt_st, 1, 1},
                           {"copy_u4", k_copy_u4, 1, 1},   {"read", k_read, 1, 0},       {"write", k_write, 0, 1},
-                          {"write_nt", k_write_nt, 0, 1}, {"copy_lds", k_copy_lds, 1, 1}};
+                          {"write_nt", k_write_nt, 0, 1}, {"copy_lds", k_copy_lds, 1, 1},
+                          {"copy_nt_blk", k_copy_nt_blk, 1, 1}, {"copy_lds_blk", k_copy_lds_blk, 1, 1},
+                          {"copy_lds_16", k_copy_lds_16, 1, 1, 1024}, {"copy_lds_blk16", k_copy_lds_blk16, 1, 1, 1024},
+                          {"copy_lds_chunk16_64k", k_copy_lds_chunk16<64>, 1, 1, 1024}, {"copy_lds_chunk16_128k", k_copy_lds_chunk16<128>, 1, 1, 1024},
+                          {"copy_lds_chunk16_256k", k_copy_lds_chunk16<256>, 1, 1, 1024}};
     const double moved[] = {76.2e6, 431.3e6, 1725.2e6};
     const int wgs[] = {256, 512, 1024, 2048, 4096, 16384};
     hipDeviceProp_t prop;
@@ -172,7 +327,7 @@ int main(int argc, char **argv)
                 continue;
             CK(hipMemcpy(A, pat.data(), vn * 16, hipMemcpyHostToDevice));
             CK(hipMemset(B, 0xff, vn * 16));
-            hipLaunchKernelGGL(f.k, dim3(300), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(A), reinterpret_cast<f32x4 *>(B), vn);
+            hipLaunchKernelGGL(f.k, dim3(300), dim3(f.threads), 0, s, reinterpret_cast<const f32x4 *>(A), reinterpret_cast<f32x4 *>(B), vn);
             CK(hipStreamSynchronize(s));
             CK(hipMemcpy(back.data(), B, vn * 16, hipMemcpyDeviceToHost));
             if (memcmp(pat.data(), back.data(), vn * 16) != 0) {
@@ -193,12 +348,14 @@ int main(int argc, char **argv)
             const size_t slice = ((n * 16 + 4095) / 4096) * 4096;
             const size_t slices = std::max<size_t>(std::min<size_t>(arena / slice, 64), 1);
             for (int g : wgs) {
+                if (f.threads == 1024 && g > 512) // (16-wave workgroups: one or two per CU)
+                    continue;
                 std::vector<float> us;
                 for (int t = 0; t < trials + 1; t++) {
                     CK(hipEventRecord(e0, s));
                     for (int r = 0; r < reps; r++) {
                         const size_t o = ((size_t)(t * reps + r) % slices) * slice;
-                        hipLaunchKernelGGL(f.k, dim3(g), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(A + o), reinterpret_cast<f32x4 *>(B + o), n);
+                        hipLaunchKernelGGL(f.k, dim3(g), dim3(f.threads), 0, s, reinterpret_cast<const f32x4 *>(A + o), reinterpret_cast<f32x4 *>(B + o), n);
                     }
                     CK(hipEventRecord(e1, s));
                     CK(hipEventSynchronize(e1));
