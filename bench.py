@@ -731,7 +731,31 @@ def main():
         cm = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, max_graph_nodes=mg)
         if seg:
             cm.set_large_segment(*seg)
+        _, md = workload_promises(w, [batch], [seg])
+        if md:
+            cm.set_max_degree(md)
         bd = tuple(torch.from_numpy(a).to(dev) for a in (batch.x, batch.coo, batch.node_ptr, batch.edge_ptr))
+        # (round 6) the timed step's own kernels, each ALONE on the chip: whole forwards of one prepared batch back to back on
+        # ONE stream -- under `rocprofv3 --kernel-trace --stats` every kernel of the step (the row-class / pooling GEMMs,
+        # k_pna_pagg, k_pna_first, k_sage_first_mean, the readout) gets a per-launch average that is not stretched by the other
+        # batches of the three-stream pipeline: what `other_configs[].roofline.frac` is recomputed from
+        cm.graph_prep(bd[1], bd[2], bd[3], int(bd[0].shape[0]))
+        outb = torch.empty(batch.num_graphs, cm.out_dim, device=dev)
+        for _ in range(5):
+            cm.forward_prepared(bd[0], out=outb)
+        cm.check()
+        tmf = runtime.HipTimer()
+        torch.cuda.synchronize()
+        tmf.start()
+        nser = 40
+        for _ in range(nser):
+            cm.forward_prepared(bd[0], out=outb)
+        tmf.stop()
+        serial = {"us_per_forward_prepared_one_stream": tmf.elapsed_ms() * 1e3 / nser, "forwards": nser, "path": cm.last_path()}
+        if w["conv"] in ("sage", "pna"):
+            serial["dominant_gemm_stand_alone"] = measure_segmented_gemm(w, batch.num_nodes, dev, pna_classes=bool(md))
+        if w["conv"] == "pna" and md:
+            serial["pna_product_aggregate"] = measure_pna_product_aggregate(cm, bd, w["hidden"], dev)
         alg_bytes, agg = measure_aggregate_roofline(cm, bd, w["hidden"], dev, regimes=("hbm",))
         wkind = WORKLOAD_AGG[w["conv"]][0]
         own = None
@@ -742,7 +766,7 @@ def main():
                                     conv=w["conv"], layers=w["layers"], seg=seg) if w["conv"] in ("gcn", "gin") and w["layers"] >= 2 else None
         print(json.dumps({"roofline_only": True, "workload": args.workload, "algorithmic_bytes_per_launch": alg_bytes, **agg["hbm"],
                           "copy_same_launch_shape": agg.get("copy_same_launch_shape"), "workload_kind": own, "fused_stack": fused,
-                          "stack_path": cm.last_path() if fused else None}))
+                          "stack_path": cm.last_path() if fused else None, "serial_forward": serial}))
         return
 
     if args.shard == "one-batch":

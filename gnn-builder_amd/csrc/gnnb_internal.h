@@ -110,7 +110,8 @@ struct Options {
     int stage_cut;       // 1 = k_gcn2_fused's workgroups take whole stages of the batch's global greedy stage list (graph prep plans the
                          //     cuts: k_stage_cut -- the kernel alone 232 -> 215 us at BASELINE config 3, but the planner's latency costs the
                          //     three-stream pipeline more than that: opt-in); 0 = equal tile counts (default)
-    int zf_head;         // 1 = k_gcn2_zf runs the MLP head on the graphs it pooled (conv stack + pooling + head in one launch; default)
+    int zf_head;         // 1 = k_gcn2_zf runs the MLP head on the graphs it pooled (conv stack + pooling + head in one launch: measured
+                         //     slower than the separate readout); 0 = separate readout launch (default)
     int agg_form;        // gather-aggregate kernel: 0 = LDS ring (k_aggregate_ring), 1 = register gather (k_aggregate_rg: no LDS, no
                          // barrier; widths 64 / 128 / 256, kinds GCN / SUM / MEAN / SIMPLE / PNA; anything else falls back to the ring),
                          // 2 = register gather for PNA only.  Default 0: DESIGN 3.2 (a wash at config 2, slower inside config 4's step)
@@ -223,6 +224,7 @@ struct StreamK {
 size_t stream_k_scratch_bytes();
 StreamK stream_k_scratch_at(void *base);
 hipError_t stream_k_scratch_init(void *base, hipStream_t s); // counters zeroed, guard pattern written (in stream order)
+hipError_t stream_k_scratch_init_sync(void *base);           // the same with synchronous memsets (workspace creation)
 // diagnostics: 1 = the scratch's counters are all zero and the guard region behind them is whole, 0 = not, -1 = read-back failed.
 // owned == nullptr: the standalone scratch of (current device, s), 1 when there is none yet.  Synchronises s.
 int stream_k_guard_intact(const StreamK *owned, hipStream_t s);

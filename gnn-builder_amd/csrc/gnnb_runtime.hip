@@ -718,8 +718,10 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     (void)hipMemset(ws->t.err, 0, sizeof(int32_t));
     if (want_sk) {
         ws->sk = stream_k_scratch_at(b + o_sk);
-        (void)stream_k_scratch_init(b + o_sk, nullptr); // arrival counters zero (as every launch leaves them), guard pattern behind them
-        (void)hipStreamSynchronize(nullptr);
+        // arrival counters zero (as every launch leaves them), guard pattern behind them.  Synchronous memsets, not the null
+        // stream + a synchronise: that would join -- and could disturb a capture in progress on -- every blocking stream of the
+        // process (round-5 advisor finding)
+        (void)stream_k_scratch_init_sync(b + o_sk);
     }
     // best effort: without the mapped word only gnnb_workspace_check reports a malformed batch
     ws->t.err_host_dev = nullptr;
@@ -1029,7 +1031,8 @@ int gnnb_pna_product_aggregate(gnnb_workspace *ws, const float *x_dev, const flo
     hipError_t he = launch_pna_pagg(ws->t, x_dev, width, wb_dev, ldw, out_dev, (hipStream_t)stream);
     if (he == hipErrorNotSupported)
         return fail(GNNB_ERR_INVALID, "gnnb_pna_product_aggregate takes widths 128 / 64 / 32, 16-byte aligned operands and a workspace "
-                                      "whose max_graph_nodes promise fits a 64-row stage (promise + tile rows - 1 <= 64)");
+                                      "whose max_graph_nodes promise fits a 64-row stage (promise + tile rows - 1 <= 64), without a large "
+                                      "segment; the option pna_pagg must be on (it is %s)", options().pna_pagg ? "on" : "OFF");
     GNNB_HIP_TRY(he);
     return GNNB_OK;
 }
@@ -1111,7 +1114,12 @@ int gnnb_linear(const gnnb_gemm_seg *segs, int num_segs, const float *w_dev, int
 
 int gnnb_debug_stream_k_guard(gnnb_workspace *ws, void *stream)
 {
-    const int ok = stream_k_guard_intact(ws && ws->sk.part ? &ws->sk : nullptr, (hipStream_t)stream);
+    // (a workspace whose model has no K >= 1024 layer owns no scratch: said so, instead of silently checking the stand-alone
+    // scratch of (device, stream) or nothing at all -- round-5 advisor finding)
+    if (ws && !ws->sk.part)
+        return fail(GNNB_ERR_INVALID, "this workspace owns no stream-K scratch (no layer of its model has K >= 1024): nothing to check; "
+                                      "pass ws = NULL for the stand-alone gnnb_linear scratch of (device, stream)");
+    const int ok = stream_k_guard_intact(ws ? &ws->sk : nullptr, (hipStream_t)stream);
     if (ok < 0)
         return fail(GNNB_ERR_HIP, "reading the stream-K scratch back failed");
     if (ok == 0)

@@ -1730,6 +1730,14 @@ hipError_t stream_k_scratch_init(void *base, hipStream_t s)
         e = hipMemsetAsync(p + SK_PART_BYTES + (size_t)SK_CNT_INTS * sizeof(int), 0xA5, SK_GUARD_BYTES, s);
     return e;
 }
+hipError_t stream_k_scratch_init_sync(void *base) // (workspace creation: no stream involved)
+{
+    char *p = reinterpret_cast<char *>(base);
+    hipError_t e = hipMemset(p + SK_PART_BYTES, 0, (size_t)SK_CNT_INTS * sizeof(int));
+    if (e == hipSuccess)
+        e = hipMemset(p + SK_PART_BYTES + (size_t)SK_CNT_INTS * sizeof(int), 0xA5, SK_GUARD_BYTES);
+    return e;
+}
 // 1 = counters all zero (no launch in flight on `s`) and the guard pattern whole, 0 = not, -1 = the read-back failed
 static int stream_k_tail_ok(const StreamK &k, hipStream_t s)
 {

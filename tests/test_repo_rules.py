@@ -39,3 +39,21 @@ def test_header_cites_the_reference_interfaces():
     """Every entry point of the C ABI says which reference interface it replaces (file:line)."""
     h = (ROOT / "include" / "gnnb_hip.h").read_text()
     assert len(re.findall(r"(model\.cpp\.jinja|model_tb\.cpp\.jinja|model\.h\.jinja|gnn_builder_lib\.h|code_gen\.py|models\.py):\d+", h)) >= 10
+
+
+def test_every_unit_is_built_and_the_probe_build_follows_the_unit_list():
+    """Round-5 review: the hand-written unity source of `make probe` had fallen five translation units behind the library
+    (the diagnostic library no longer loaded).  The unit list is the ONE place that names the translation units: every
+    csrc/*.hip is in it, and the probe target generates its unity source from it (no checked-in copy)."""
+    csrc = ROOT / "gnn-builder_amd" / "csrc"
+    mk = (csrc / "Makefile").read_text()
+    units = re.search(r"^UNITS := (.*)$", mk, re.M).group(1).split()
+    on_disk = sorted(p.stem for p in csrc.glob("*.hip"))
+    assert sorted(units) == on_disk, (sorted(units), on_disk)
+    assert not (csrc / "gnnb_unity.hip").exists()
+    probe = mk[mk.index("$(OBJDIR)/gnnb_unity.hip:"):]
+    assert "for u in $(UNITS)" in probe and "$(OBJDIR)/gnnb_unity.hip" in probe[probe.index("probe:"):]
+    # (what the recipe writes, without running hipcc: one #include per unit, in order)
+    import subprocess
+    out = subprocess.run(["make", "-C", str(csrc), "-n", "probe"], capture_output=True, text=True).stdout
+    assert "-DGNNB_PROBE" in out and "gnnb_unity.hip" in out
