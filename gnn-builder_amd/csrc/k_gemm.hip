@@ -208,6 +208,15 @@ __global__ __launch_bounds__(WG) void k_linear(GemmArgs g, const float *__restri
 // the kernel ran at 84 % of the fp32 MFMA peak, with it at 65 % -- see the note on compiler-tracked loads in the item
 // body.
 static constexpr int DM = 128, DN = 128, DWG = 256, DNBUF = 2, DNW = DWG / 64, DWGPC = 2;
+// The swizzle key of a chunk row.  Round 6 (profiles/r06_c{4,5}_kernels_pmc.json: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.43-0.50 in
+// this kernel): with slot = piece ^ (row & 7) a ds_read_b128 -- served in groups of SIXTEEN lanes over 64 banks (256 B), rows
+// {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of the 32-row fragment -- puts rows r and r + 8 (mod 16) of one parity on the same slot:
+// every fragment read a two-way conflict.  Rows are 128 B: the row's parity selects the half of the 256-B bank window, so the key
+// must separate the EIGHT rows of one parity inside a group: key = (row >> 1) & 7 does (even rows of the first group: 0 1 6 7 2 3 4 5).
+#ifndef DMA_KEY_SHIFT
+#define DMA_KEY_SHIFT 1
+#endif
+__device__ __forceinline__ int dkey(int r) { return (r >> DMA_KEY_SHIFT) & 7; }
 static constexpr int DBUF_B = (DM + DN) * BK * 4; // 32 KB: A chunk | W chunk
 // MATH 1 (opt-in, gnnb_set_option("math", 1)): the same chunks, but each 16-wide k block is multiplied as six
 // v_mfma_f32_32x32x16_bf16 products of an exact 3-way bf16 split of BOTH operands (see split3), the fragments split in
@@ -236,9 +245,10 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
     const int total = g.cpre[g.nseg];
     const int li = lane & 31, lh = lane >> 5;
     const uint32_t smem_a = (uint32_t)(uintptr_t)(lds_vptr)smem;
-    // DMA lane geometry: an instruction covers 8 rows x eight 16-B pieces; LDS slot p of row r holds piece p ^ (r & 7)
+    // DMA lane geometry: an instruction covers 8 rows x eight 16-B pieces; LDS slot p of row r holds piece p ^ dkey(r)
     const int drow = lane >> 3;
-    const uint32_t dpiece_b = (uint32_t)(((lane & 7) ^ drow) << 4);
+    // (the key of local row r0 + drow, r0 a multiple of 8: with DMA_KEY_SHIFT 1 it carries bit 3 of r0 -- two lane constants)
+    const uint32_t dpiece_b0 = (uint32_t)(((lane & 7) ^ dkey(drow)) << 4), dpiece_b1 = (uint32_t)(((lane & 7) ^ dkey(8 + drow)) << 4);
 
     // PERSISTENT over work items (grid = what is resident: two workgroups per CU); the chunk pipeline runs straight
     // across item boundaries.  TAIL SPLIT: tiles / CUs is rarely whole (PNA at C4: 1153 tiles on 256 CUs = 4.5 per CU,
@@ -398,13 +408,13 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
         if (i < DA_PER) {
             const int r0 = (wave * DA_PER + i) * 8;
             if (r0 < ic.mrows) {
-                dma16_to_lds_s(ic.ga, (uint32_t)(RC ? irow[i < DA_PER_ ? i : 0] : min(r0 + drow, ic.ra_max)) * ic.lda_b + dpiece_b, ic.la + (uint32_t)r0 * 128);
+                dma16_to_lds_s(ic.ga, (uint32_t)(RC ? irow[i < DA_PER_ ? i : 0] : min(r0 + drow, ic.ra_max)) * ic.lda_b + ((r0 & 8) ? dpiece_b1 : dpiece_b0), ic.la + (uint32_t)r0 * 128);
                 vm++;
             }
         }
         if (i < DW_PER) {
             const int r0 = (wave * DW_PER + i) * 8;
-            dma16_to_lds_s(ic.gw, (uint32_t)min(r0 + drow, ic.rw_max) * ic.ldw_b + dpiece_b, ic.lw + (uint32_t)r0 * 128);
+            dma16_to_lds_s(ic.gw, (uint32_t)min(r0 + drow, ic.rw_max) * ic.ldw_b + ((r0 & 8) ? dpiece_b1 : dpiece_b0), ic.lw + (uint32_t)r0 * 128);
             vm++;
         }
     };
@@ -531,8 +541,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                         for (int mi = 0; mi < MC; mi++) {
                             const int r = rbase + mi * 32 + li;
-                            float4 f0 = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
-                            float4 f1 = *reinterpret_cast<const float4 *>(a + r * BK + (((piece + 1) ^ (r & 7)) << 2));
+                            float4 f0 = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ dkey(r)) << 2));
+                            float4 f1 = *reinterpret_cast<const float4 *>(a + r * BK + (((piece + 1) ^ dkey(r)) << 2));
                             if (scaled) {
                                 f0.x *= s[mi], f0.y *= s[mi], f0.z *= s[mi], f0.w *= s[mi];
                                 f1.x *= s[mi], f1.y *= s[mi], f1.z *= s[mi], f1.w *= s[mi];
@@ -542,8 +552,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                         for (int ni = 0; ni < NT; ni++) {
                             const int r = wcol + ni * 32 + li;
-                            const float4 f0 = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
-                            const float4 f1 = *reinterpret_cast<const float4 *>(b + r * BK + (((piece + 1) ^ (r & 7)) << 2));
+                            const float4 f0 = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ dkey(r)) << 2));
+                            const float4 f1 = *reinterpret_cast<const float4 *>(b + r * BK + (((piece + 1) ^ dkey(r)) << 2));
                             split2x8_f16(f0, f1, wh[ni], wm[ni]);
                         }
                         issue_part(ic, 2 * kb2);
@@ -566,8 +576,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                         for (int mi = 0; mi < MC; mi++) {
                             const int r = rbase + mi * 32 + li;
-                            float4 f0 = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
-                            float4 f1 = *reinterpret_cast<const float4 *>(a + r * BK + (((piece + 1) ^ (r & 7)) << 2));
+                            float4 f0 = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ dkey(r)) << 2));
+                            float4 f1 = *reinterpret_cast<const float4 *>(a + r * BK + (((piece + 1) ^ dkey(r)) << 2));
                             if (scaled) {
                                 f0.x *= s[mi], f0.y *= s[mi], f0.z *= s[mi], f0.w *= s[mi];
                                 f1.x *= s[mi], f1.y *= s[mi], f1.z *= s[mi], f1.w *= s[mi];
@@ -577,8 +587,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                         for (int ni = 0; ni < NT; ni++) {
                             const int r = wcol + ni * 32 + li;
-                            const float4 f0 = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
-                            const float4 f1 = *reinterpret_cast<const float4 *>(b + r * BK + (((piece + 1) ^ (r & 7)) << 2));
+                            const float4 f0 = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ dkey(r)) << 2));
+                            const float4 f1 = *reinterpret_cast<const float4 *>(b + r * BK + (((piece + 1) ^ dkey(r)) << 2));
                             split3x8(f0, f1, wh[ni], wm[ni], wl[ni]);
                         }
                         issue_part(ic, 2 * kb2);
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                     for (int mi = 0; mi < MC; mi++) {
                         const int r = rbase + mi * 32 + li;
-                        fa[mi] = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ (r & 7)) << 2));
+                        fa[mi] = *reinterpret_cast<const float4 *>(a + r * BK + ((piece ^ dkey(r)) << 2));
                     }
                     if (scaled) { // the row scaler multiplies the A operand, as in the register-staged kernel
 #pragma unroll
@@ -615,7 +625,7 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                     for (int ni = 0; ni < NT; ni++) {
                         const int r = wcol + ni * 32 + li;
-                        fb[ni] = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ (r & 7)) << 2));
+                        fb[ni] = *reinterpret_cast<const float4 *>(b + r * BK + ((piece ^ dkey(r)) << 2));
                     }
                     issue_part(ic, kb / 8); // (behind this step's fragment reads, in front of its MFMAs)
                     // operands SWAPPED (W fragment first): the 32x32 accumulator then holds, per lane, FOUR

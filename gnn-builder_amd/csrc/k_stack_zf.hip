@@ -916,7 +916,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
             // (round 4, wide shape: letting the parts fill ALL sixteen waves -- eight graphs x two parts -- is 0.25 us SLOWER,
             // 40.15 vs 39.9 us: the row walk of a task shortens from 4.1 k to 2.9 k cycles, but every task pays its ~1.9 k
             // cycles of set-up, combine and stores, and the next stage's P0 loses its idle waves)
-            while (pow2 && csl < 2 && (ngr << (csl + 1)) <= G2_NW / 2 && (nv >> (csl + 1)) >= 4)
+#ifndef ZF_P1_FILL // (development A/B: 1 = column parts until the tasks fill ALL waves)
+#define ZF_P1_FILL 0
+#endif
+            while (pow2 && csl < 2 && (ngr << (csl + 1)) <= (ZF_P1_FILL ? G2_NW : G2_NW / 2) && (nv >> (csl + 1)) >= 4)
                 csl++;
         }
         if (ZF_ON(0)) {
