@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Regenerates the results tables of DESIGN.md and README.md (between the R5_TABLE markers) from profiles/r05_*_bench.json
-(`bench.py --workload w --steps 100`, builder-run) and profiles/r05_driver_command.json (`bench.py --gpus 1 --steps 20
+"""Regenerates the results tables of DESIGN.md and README.md (between the R6_TABLE markers) from profiles/r06_*_bench.json
+(`bench.py --workload w --steps 100`, builder-run) and profiles/r06_driver_command.json (`bench.py --gpus 1 --steps 20
 --warmup 5`: the driver's command, whose line carries c3 / c4 / c5 as `other_configs`)."""
 import json
 import re
@@ -16,11 +16,11 @@ def fmt(v):
     return f"{v / 1e6:.2f} M" if v >= 1e6 else f"{v:,.0f}"
 
 
-drv = json.loads((P / "r05_driver_command.json").read_text())
+drv = json.loads((P / "r06_driver_command.json").read_text())
 others = {o["name"]: o for o in drv.get("other_configs", [])}
 rows = []
 for w, name in NAMES:
-    d = json.loads((P / f"r05_{w}_bench.json").read_text())
+    d = json.loads((P / f"r06_{w}_bench.json").read_text())
     r = d["roofline"]
     g = d["roofline_gather_aggregate"]
     if w == "c2":
@@ -59,7 +59,7 @@ table = ("| workload | the driver's command (`--steps 20`): graphs/s, step | `--
 for f in ("DESIGN.md", "README.md"):
     p = ROOT / f
     s = p.read_text()
-    s2 = re.sub(r"<!-- R5_TABLE_BEGIN -->.*?<!-- R5_TABLE_END -->", "<!-- R5_TABLE_BEGIN -->\n" + table + "\n<!-- R5_TABLE_END -->", s, flags=re.S)
+    s2 = re.sub(r"<!-- R6_TABLE_BEGIN -->.*?<!-- R6_TABLE_END -->", "<!-- R6_TABLE_BEGIN -->\n" + table + "\n<!-- R6_TABLE_END -->", s, flags=re.S)
     if s2 != s:
         p.write_text(s2)
         print("updated", f)
