@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "gnnb_hip.h"
 
 namespace gnnb {
@@ -59,65 +61,79 @@ constexpr int GNNB_G2_STAGE_ROWS_BF6 = 48; // ... in the opt-in bf16x6 math mode
 int zf_stage_rows(int f0, int promise);
 long gcn2_zf_tile_capacity(int f0, int promise); // node tiles it can walk in one launch
 
+// One tuning knob: a relaxed atomic int.  The knobs are process-wide and may be set (gnnb_set_option) while other threads launch
+// -- round-5 review: "35+ knobs, unsynchronised".  Every read and write is now a single atomic access: no data race; a launcher that
+// reads a knob twice may see two values, which only ever selects between kernels that give the same results (the one knob that
+// changes results, "math", is captured per model: gnnb_model_desc::math, launch_math()).
+struct OptInt {
+    std::atomic<int> v;
+    OptInt(int x) : v(x) {}
+    operator int() const { return v.load(std::memory_order_relaxed); }
+    OptInt &operator=(int x)
+    {
+        v.store(x, std::memory_order_relaxed);
+        return *this;
+    }
+};
 struct Options {
-    int tile_rows;    // node-tile granularity (rows; tiles are cut at graph boundaries)
-    int agg_lds_kb;   // LDS budget of the gather-aggregate kernel per workgroup (0 = all of the CU's / workgroups per CU)
-    int agg_ring_waves;   // waves per workgroup (0 = 16)
-    int agg_ring_slots;   // LDS stages in the ring
-    int agg_ring_wg_per_cu;
-    int agg_nt_store;     // non-temporal output stores
-    int agg_balance;      // 1 = the ring kernel's workgroups take row-balanced ranges (boundary graphs staged by both neighbours);
+    OptInt tile_rows;    // node-tile granularity (rows; tiles are cut at graph boundaries)
+    OptInt agg_lds_kb;   // LDS budget of the gather-aggregate kernel per workgroup (0 = all of the CU's / workgroups per CU)
+    OptInt agg_ring_waves;   // waves per workgroup (0 = 16)
+    OptInt agg_ring_slots;   // LDS stages in the ring
+    OptInt agg_ring_wg_per_cu;
+    OptInt agg_nt_store;     // non-temporal output stores
+    OptInt agg_balance;      // 1 = the ring kernel's workgroups take row-balanced ranges (boundary graphs staged by both neighbours);
                           //     0 = whole-graph runs (default: measured faster, 15.2 vs 15.9 us at BASELINE config 2 -- the 3 % of extra
                           //     reads cost the per-CU memory pipe more than the +-8 % row imbalance)
-    int gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
-    int gemm_max_wg_per_cu;
-    int gemm_dma;      // 1 = large-K GEMM through LDS-DMA when every segment is plain (default)
-    int gemm_wlds;     // 1 = K, N in {64,128}, no skip operand: weights-in-LDS, barrier-free kernel (default); 0 = register-resident weights
-    int gemm_wlds_slots; // ... its ring depth per wave (capped by what fits beside W in LDS)
-    int fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
-    int first_ring;    // ... 1 = in ring form (k_conv_first: graphs staged in LDS, all columns from one stage; default), 0 = inside
+    OptInt gemm_variant;  // 0 = register-resident weights when eligible (default), 1 = always the LDS-tiled kernel
+    OptInt gemm_max_wg_per_cu;
+    OptInt gemm_dma;      // 1 = large-K GEMM through LDS-DMA when every segment is plain (default)
+    OptInt gemm_wlds;     // 1 = K, N in {64,128}, no skip operand: weights-in-LDS, barrier-free kernel (default); 0 = register-resident weights
+    OptInt gemm_wlds_slots; // ... its ring depth per wave (capped by what fits beside W in LDS)
+    OptInt fuse_narrow;   // 1 = aggregate + update of a narrow-input (F_in <= 32) GCN/GIN layer in one kernel
+    OptInt first_ring;    // ... 1 = in ring form (k_conv_first: graphs staged in LDS, all columns from one stage; default), 0 = inside
                        //     k_linear_reg's A stage (round 3)
-    int fuse_zf;       // 1 = a 2-layer fp32 GCN stack takes k_gcn2_zf (last layer transformed before it is aggregated, 96-row
+    OptInt fuse_zf;       // 1 = a 2-layer fp32 GCN stack takes k_gcn2_zf (last layer transformed before it is aggregated, 96-row
                        //     stages) instead of k_gcn2_fused (default); needs fuse_gcn2
-    int large_fork;    // a batch's large segment: 2 = through k_conv_rows on the caller's stream behind the stack kernel (default:
+    OptInt large_fork;    // a batch's large segment: 2 = through k_conv_rows on the caller's stream behind the stack kernel (default:
                        //     measured best with batches in flight: C3t 15.0 M graphs/s), 1 = k_conv_rows on a forked stream (shortest
                        //     single forward, 13.5 M in the pipeline: the stack kernels leave no register space for a co-resident
                        //     wave, so the fork only reorders), 0 = through the big layer-by-layer kernels (14.2 M)
-    int zf_shape;      // k_gcn2_zf: 0 = two 8-wave workgroups per CU, 96-row stages; 1 = one 16-wave workgroup, 176-row stages;
+    OptInt zf_shape;      // k_gcn2_zf: 0 = two 8-wave workgroups per CU, 96-row stages; 1 = one 16-wave workgroup, 176-row stages;
                        //     2 = shape 1 wherever it exists (input widths up to 16), else shape 0 (default)
-    int fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it (k_gcn2_fused), 0 = layer by layer
-    int fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
-    int fuse_pool;     // 1 = global pooling in the epilogue of the last conv layer's GEMM where that GEMM has one (GraphSAGE's
+    OptInt fuse_gcn2;     // 1 = fused 2-layer GCN stack when the model and the max_graph_nodes hint allow it (k_gcn2_fused), 0 = layer by layer
+    OptInt fuse_head;     // 1 = pooling + MLP head in one kernel when it fits (default)
+    OptInt fuse_pool;     // 1 = global pooling in the epilogue of the last conv layer's GEMM where that GEMM has one (GraphSAGE's
                        //     large-K segmented GEMM; default), 0 = separate pooling pass
-    int head_small;    // 1 = readout on a pooled matrix with the small-footprint kernel that co-resides with the
+    OptInt head_small;    // 1 = readout on a pooled matrix with the small-footprint kernel that co-resides with the
                        //     conv-stack kernel of the next batch in flight (default); 0 = weights-in-LDS kernel
-    int head_split;    // 1 = layer-wise models: pooling pass + small readout instead of the one-launch pooling+MLP kernel
-    int math;          // 0 = fp32 MFMA everywhere (default); 1 = the wide update of the fused GCN stack and the
+    OptInt head_split;    // 1 = layer-wise models: pooling pass + small readout instead of the one-launch pooling+MLP kernel
+    OptInt math;          // 0 = fp32 MFMA everywhere (default); 1 = the wide update of the fused GCN stack and the
                        //     K <= 128 GEMMs as six bf16 MFMA products of an exact 3-way split of both operands
                        //     (fp32-equivalent, opt-in)
-    int gemm_tail_split; // k_linear_dma's last, partial round of tiles: 2 = cut along K into equal runs over all resident
+    OptInt gemm_tail_split; // k_linear_dma's last, partial round of tiles: 2 = cut along K into equal runs over all resident
                          // workgroups, parts added up by the last one at each tile (stream-K; default), 1 = handed out as
                          // row slices (bit-identical to 0), 0 = whole tiles
-    int pna_fold_lin;    // 1 = PNA's `lin` folded into its post-NN at upload: one 13F-wide GEMM per layer (default); 0 = two GEMMs
-    int pna_classes;     // 1 = PNA under a max_degree promise <= 15: rows sorted by degree, 5F-wide GEMM with per-class weights (default)
-    int fold_skip;       // 1 = GraphSAGE: a middle layer's skip connection folded into the root weights (Wr + I) instead of read as an operand (default)
-    int sage_first_mean; // 1 = GraphSAGE: the narrow first layer also forms the NEXT layer's mean aggregate from its output rows while they
+    OptInt pna_fold_lin;    // 1 = PNA's `lin` folded into its post-NN at upload: one 13F-wide GEMM per layer (default); 0 = two GEMMs
+    OptInt pna_classes;     // 1 = PNA under a max_degree promise <= 15: rows sorted by degree, 5F-wide GEMM with per-class weights (default)
+    OptInt fold_skip;       // 1 = GraphSAGE: a middle layer's skip connection folded into the root weights (Wr + I) instead of read as an operand (default)
+    OptInt sage_first_mean; // 1 = GraphSAGE: the narrow first layer also forms the NEXT layer's mean aggregate from its output rows while they
                          //     are in LDS (k_sage_first_mean; needs the max_graph_nodes promise; default); 0 = k_conv_first + aggregate kernel
-    int pna_first;       // 1 = a PNA layer with a narrow input (F <= 12: the first) as ONE kernel -- pre-NN, aggregate, scalers, post-NN --
+    OptInt pna_first;       // 1 = a PNA layer with a narrow input (F <= 12: the first) as ONE kernel -- pre-NN, aggregate, scalers, post-NN --
                          //     when the max_graph_nodes promise lets whole graphs be staged (k_pna_first; default); 0 = four launches
-    int pna_pagg;        // 1 = a full-width PNA layer under the degree promise + the max_graph_nodes promise: pre-NN product and aggregate in
+    OptInt pna_pagg;        // 1 = a full-width PNA layer under the degree promise + the max_graph_nodes promise: pre-NN product and aggregate in
                          //     one kernel, p never in HBM (k_pna_pagg; default); 0 = GEMM + k_aggregate_ring<PNA>
-    int stage_cut;       // 1 = k_gcn2_fused's workgroups take whole stages of the batch's global greedy stage list (graph prep plans the
+    OptInt stage_cut;       // 1 = k_gcn2_fused's workgroups take whole stages of the batch's global greedy stage list (graph prep plans the
                          //     cuts: k_stage_cut -- the kernel alone 232 -> 215 us at BASELINE config 3, but the planner's latency costs the
                          //     three-stream pipeline more than that: opt-in); 0 = equal tile counts (default)
-    int zf_head;         // 1 = k_gcn2_zf runs the MLP head on the graphs it pooled (conv stack + pooling + head in one launch: measured
+    OptInt zf_head;         // 1 = k_gcn2_zf runs the MLP head on the graphs it pooled (conv stack + pooling + head in one launch: measured
                          //     slower than the separate readout); 0 = separate readout launch (default)
-    int agg_form;        // gather-aggregate kernel: 0 = LDS ring (k_aggregate_ring), 1 = register gather (k_aggregate_rg: no LDS, no
+    OptInt agg_form;        // gather-aggregate kernel: 0 = LDS ring (k_aggregate_ring), 1 = register gather (k_aggregate_rg: no LDS, no
                          // barrier; widths 64 / 128 / 256, kinds GCN / SUM / MEAN / SIMPLE / PNA; anything else falls back to the ring),
                          // 2 = register gather for PNA only.  Default 0: DESIGN 3.2 (a wash at config 2, slower inside config 4's step)
-    int agg_rg_r;        // ... row-instructions in flight per wave and batch (0 = 1)
-    int agg_rg_wgs;      // ... 256-thread workgroups per CU, resident or not (0 = 32 at one row-instruction per batch)
-    int agg_rg_flags;    // ... bit 0: sources past the degree are not loaded (exec-masked; default) instead of aliasing the row itself;
+    OptInt agg_rg_r;        // ... row-instructions in flight per wave and batch (0 = 1)
+    OptInt agg_rg_wgs;      // ... 256-thread workgroups per CU, resident or not (0 = 32 at one row-instruction per batch)
+    OptInt agg_rg_flags;    // ... bit 0: sources past the degree are not loaded (exec-masked; default) instead of aliasing the row itself;
                          //     bit 1: the run pre-touched line by line (slower); bits 2, 3: ablations (GCN, w = 128, one row-instruction)
 };
 Options &options();

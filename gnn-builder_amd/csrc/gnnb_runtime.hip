@@ -67,7 +67,7 @@ Options &options()
 
 static thread_local int tl_math = -1; // >= 0: the calling thread is inside an entry point of a model with its own math mode
 static thread_local FlagWord tl_flag = {nullptr, nullptr};
-int launch_math() { return tl_math >= 0 ? tl_math : options().math; }
+int launch_math() { return tl_math >= 0 ? tl_math : (int)options().math; }
 FlagWord launch_flag_word() { return tl_flag; }
 MathScope::MathScope(int model_math, int32_t *err, int32_t *err_host) : prev(tl_math), prev_flag(tl_flag)
 {
@@ -837,7 +837,7 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     t.num_nodes = num_nodes;
     t.num_edges = num_edges;
     t.max_graph_nodes_hint = ws->max_graph_nodes;
-    t.tile_rows = std::max(options().tile_rows, 4);
+    t.tile_rows = std::max((int)options().tile_rows, 4);
     // A 2-layer GCN with a promise takes the fused stack only if a whole tile (tile_rows - 1 + largest graph) fits
     // one 64-row stage (48 in the bf16x6 mode): for graphs of 50..61 nodes finer tiles (8, 4) keep that path open
     if (options().fuse_gcn2 && (ws->desc.conv_type == GNNB_CONV_GCN || ws->desc.conv_type == GNNB_CONV_GIN) && ws->desc.num_layers >= 2 &&

@@ -603,9 +603,9 @@ static hipError_t launch_aggregate_ring_t(const BatchTables &t, const float *x, 
     constexpr int ECAP_PER_ROW = 4;
     const size_t per_row = (size_t)w * 4 * (MODE == GNNB_AGG_PNA ? 2 : 1) + (MODE != GNNB_AGG_COPY ? 32 + 4 + 4 * ECAP_PER_ROW : 0) +
                            (MODE == GNNB_AGG_GCN && VEC == 4 ? 16 : 0);
-    const int wgs = std::max(o.agg_ring_wg_per_cu, 1);
-    const size_t budget = (size_t)(o.agg_lds_kb > 0 ? std::min(std::max(o.agg_lds_kb, 8), 158) : 158 / wgs) * 1024;
-    int ns = std::min(std::max(o.agg_ring_slots, 1), RING_MAX_SLOTS);
+    const int wgs = std::max((int)o.agg_ring_wg_per_cu, 1);
+    const size_t budget = (size_t)(o.agg_lds_kb > 0 ? std::min(std::max((int)o.agg_lds_kb, 8), 158) : 158 / wgs) * 1024;
+    int ns = std::min(std::max((int)o.agg_ring_slots, 1), RING_MAX_SLOTS);
     int nw = o.agg_ring_waves;
     // one ring per workgroup: stages as large as the budget allows
     if (nw <= 0)
@@ -719,7 +719,7 @@ hipError_t launch_gcn_coef(const BatchTables &t, hipStream_t s)
     return hipGetLastError();
 }
 
-int aggregate_ring_grid() { return device_cu_count() * std::max(options().agg_ring_wg_per_cu, 1); }
+int aggregate_ring_grid() { return device_cu_count() * std::max((int)options().agg_ring_wg_per_cu, 1); }
 
 hipError_t launch_aggregate(const BatchTables &t, int kind, const float *x, const float *selfq,
                             float *out, int width, float eps, hipStream_t s)

@@ -248,10 +248,10 @@ static hipError_t launch_rg_t(const BatchTables &t, const float *x, const float 
     // (measured at BASELINE configs 2 / 4 / 5: many short-lived waves of ONE row-instruction per batch beat fewer, deeper ones
     // at equal rows in flight -- GCN 14.7 us at R = 1 x 16 workgroups per CU against 16.1 / 15.8 / 17.3 at R = 2 / 3 / 4 with
     // what is resident; PNA 67.4 at 32 workgroups per CU against 71.8 at 16 and 76.5 at 8)
-    int R = o.agg_rg_r > 0 ? o.agg_rg_r : 1;
+    int R = o.agg_rg_r > 0 ? (int)o.agg_rg_r : 1;
     R = std::min(std::max(R, 1), pna ? 2 : 4);
     static const int wgs_of_r[5] = {0, 32, 16, 3, 2};
-    int wgs = o.agg_rg_wgs > 0 ? o.agg_rg_wgs : wgs_of_r[R];
+    int wgs = o.agg_rg_wgs > 0 ? (int)o.agg_rg_wgs : wgs_of_r[R];
     wgs = std::min(std::max(wgs, 1), 64); // (beyond what is resident: short-lived workgroups handed out by the dispatcher)
     int grid = cus * wgs;
     // every wave owns a contiguous run of rpw rows: whole batches of R row-instructions

@@ -1348,7 +1348,7 @@ static hipError_t launch_linear_reg_t(const float *A, int lda, int K, const floa
     }
     // K = 128 keeps 64 weight registers per lane and is MFMA-bound: 2 workgroups per CU measured
     // best.  Narrow K is store- / gather-latency-bound: the more resident workgroups the better.
-    const int cap = KQ >= 8 ? options().gemm_max_wg_per_cu : (KQ >= 4 ? 3 : 6);
+    const int cap = KQ >= 8 ? (int)options().gemm_max_wg_per_cu : (KQ >= 4 ? 3 : 6);
     int gx = num_cus * (occ_blocks > cap ? cap : occ_blocks) / gy;
     if (gx < 1)
         gx = 1;
@@ -1625,7 +1625,7 @@ static hipError_t launch_linear_wlds(const GemmArgs &g, const float *w, int ldw,
     // BASELINE sizes (31.9 vs 35.8 us at M = 73 763): a wave has only 4-7 units, and the deeper ring's longer blocking
     // prologue costs more than its steadier stream gains.
     int ns = (int)((160 * 1024 - (size_t)N * K * 4) / ((size_t)4 * slot));
-    ns = std::min(std::max(ns, 1), std::min(options().gemm_wlds_slots, 4));
+    ns = std::min(std::max(ns, 1), std::min((int)options().gemm_wlds_slots, 4));
     const size_t lds = (size_t)N * K * 4 + (size_t)4 * ns * slot;
     const int num_units = (M + 15) / 16;
     int grid = std::min(num_cus, (num_units + 3) / 4);

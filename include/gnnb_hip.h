@@ -409,7 +409,9 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  * BASELINE config has a reduced form): ~22 significant bits per product at the same speed or better (7.5e-8 against
  * a float64 evaluation at BASELINE config 2, where the fp32 form has 7.1e-8) -- but fp16's RANGE: hidden activations or
  * weights of 65504 and above turn into inf, and pieces below 6e-8 are lost (an absolute floor per operand element).
- * Unknown names or values out of range return GNNB_ERR_INVALID. */
+ * Unknown names or values out of range return GNNB_ERR_INVALID.  Thread safety (version 103): every knob is one relaxed atomic
+ * word -- setting one while other threads launch is no data race; the knobs only choose between kernels that give the same
+ * results, except "math", which a model with its own gnnb_model_desc::math never reads. */
 int gnnb_set_option(const char *name, int value);
 
 #ifdef __cplusplus
