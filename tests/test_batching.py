@@ -136,3 +136,19 @@ def test_order_large_last_is_a_stable_partition():
         assert np.array_equal(xa, xb) and np.array_equal(ca, cb)
     same, perm2, seg = order_large_last(b, 10 ** 6)                                   # nothing large: the batch itself
     assert same is b and seg == (b.num_graphs, b.num_nodes, b.num_edges) and perm2.tolist() == list(range(b.num_graphs))
+
+
+def test_run_cuts_in_32_bits_equal_the_64_bit_quotients():
+    """csrc/gnnb_device.h run_cuts(): every persistent kernel's workgroup b of G takes units [floor(b T / G), floor((b + 1) T / G))
+    -- computed as b q + floor(b r / G) with T = q G + r so that no 64-bit division is needed (round 6).  The identity, and
+    that its intermediates fit 32 bits, over the launch shapes the kernels see and the corners."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    cases = [(1, 1), (256, 0), (256, 1), (256, 255), (256, 256), (512, 9216), (256, 26112), (512, 31744), (4096, 1 << 21), (65535, (1 << 22) - 1)]
+    cases += [(int(rng.integers(1, 4097)), int(rng.integers(0, 1 << 22))) for _ in range(2000)]
+    for G, T in cases:
+        b = np.unique(np.concatenate([np.arange(min(G, 4)), [G // 2, G - 1], rng.integers(0, G, 8)])).astype(np.uint64)
+        q, r = T // G, T % G
+        for bb in (b, b + 1):
+            assert int((bb * np.uint64(r)).max()) < 2 ** 32 and int((bb * np.uint64(q)).max() + (bb * np.uint64(r) // np.uint64(G)).max()) < 2 ** 32
+            assert np.array_equal(bb * np.uint64(q) + (bb * np.uint64(r)) // np.uint64(G), (bb * np.uint64(T)) // np.uint64(G))

@@ -131,3 +131,36 @@ def test_desc_rejects_unknown_math_modes(dev):
         runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, math=4)
     with pytest.raises(runtime.GnnbError):
         runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, batch.num_edges, math=-2)
+
+
+def test_a_thread_flipping_the_option_does_not_reach_a_design_with_its_own_math(dev):
+    """The process-wide knobs are relaxed atomics and a model's math mode is its own: a second thread that flips
+    gnnb_set_option("math", ...) as fast as it can while this thread runs forwards of an f16x3 design and of an fp32 design
+    changes neither's bits (ctypes releases the GIL around every call: the two threads really run side by side)."""
+    import threading
+    model, batch = _setup("gcn", 2, 128, count=256, seed=21)
+    args = to_dev(batch, dev)
+    exact = _compile(model, batch, "fp32", False)
+    reduced = _compile(model, batch, "f16x3", False)
+    solo_exact = exact.forward(*args).cpu().numpy()
+    solo_reduced = reduced.forward(*args).cpu().numpy()
+    stop = threading.Event()
+
+    def flip():
+        i = 0
+        while not stop.is_set():
+            runtime.set_option("math", i & 3)
+            i += 1
+
+    t = threading.Thread(target=flip)
+    t.start()
+    try:
+        for _ in range(40):
+            assert np.array_equal(reduced.forward(*args).cpu().numpy(), solo_reduced)
+            assert np.array_equal(exact.forward(*args).cpu().numpy(), solo_exact)
+    finally:
+        stop.set()
+        t.join()
+        runtime.set_option("math", 0)
+    exact.check()
+    reduced.check()
