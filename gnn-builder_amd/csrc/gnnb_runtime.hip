@@ -638,6 +638,9 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
         max_k = std::max(max_k, d.conv_type == GNNB_CONV_PNA ? 13 * ld.fin : d.conv_type == GNNB_CONV_SAGE ? 2 * ld.fin : std::max(ld.fin, ld.fout));
     }
     const bool want_sk = max_k >= 1024;
+    // (the stage-cut planner's tables: opt-in -- carved only for workspaces created while the option is on; a workspace created
+    // without them keeps equal tile counts whatever the option says later: round-5 advisor finding)
+    const bool want_plan = options().stage_cut && (d.conv_type == GNNB_CONV_GCN || d.conv_type == GNNB_CONV_GIN) && d.num_layers >= 2;
     const int pooledw = d.num_pools * gnn_out_width(d);
     const int mlpw = std::max(d.mlp_hidden, d.mlp_out);
     const int min_tile_rows = 4;
@@ -663,8 +666,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     const size_t o_rp = carve((N + 1) * 4), o_col = carve(E * 4), o_eid = carve(E * 4), o_rec = carve(N * 32), o_dinv = carve(N * 4), o_amp = carve(N * 4),
                  o_att = carve(N * 4), o_gcoef = carve(N * 16), o_tile = carve((max_tiles + 1) * 4), o_tedge = carve((max_tiles + 1) * 4), o_gptr = carve((B + 1) * 4),
                  o_tgraph = carve((max_tiles + 1) * 4), o_err = carve(4), o_cut = carve((4096 + 1) * 16), o_scut = carve((1024 + 2) * 4),
-                 o_plan = carve((d.conv_type == GNNB_CONV_GCN || d.conv_type == GNNB_CONV_GIN) && d.num_layers >= 2
-                                    ? (size_t)stage_cut_levels((int)max_tiles) * (max_tiles + 1) * 4 : 0),
+                 o_plan = carve(want_plan ? (size_t)stage_cut_levels((int)max_tiles) * (max_tiles + 1) * 4 : 0),
                  o_dwork = carve(d.conv_type == GNNB_CONV_PNA ? 1024 * 16 * 4 : 0),
                  o_dperm = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 128 * 4 : 0),
                  o_dcls = carve(d.conv_type == GNNB_CONV_PNA ? ((N + 127) / 128 + GNNB_DEG_CLASSES + 1) * 4 : 0),
@@ -699,7 +701,7 @@ int gnnb_workspace_create(const gnnb_model *model, int max_graphs, int max_nodes
     ws->t.stage_cut = (int32_t *)(b + o_scut);
     ws->t.stage_cut_n = 0;
     ws->t.stage_cut_cap = 1024;
-    ws->plan_scratch = ((d.conv_type == GNNB_CONV_GCN || d.conv_type == GNNB_CONV_GIN) && d.num_layers >= 2) ? (int32_t *)(b + o_plan) : nullptr;
+    ws->plan_scratch = want_plan ? (int32_t *)(b + o_plan) : nullptr;
     ws->t.node_graph = pool_epi ? (int32_t *)(b + o_ngraph) : nullptr;
     if (d.conv_type == GNNB_CONV_PNA) {
         ws->deg_work = (int32_t *)(b + o_dwork);

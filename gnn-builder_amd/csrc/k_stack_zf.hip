@@ -1113,7 +1113,33 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                     sum.v = make_float4(v[0], v[1], v[2], v[3]);
                     mx.v = make_float4(v[4], v[5], v[6], v[7]);
                 }
+#ifndef ZF_P1_LEAN // (development A/B: 0 = the round-5 form of the pooled stores)
+#define ZF_P1_LEAN 1
+#endif
                 if (sr == 0 && lane_on) {
+#if ZF_P1_LEAN
+                    // (n is wave-uniform: ONE branch for the empty graph instead of a select per value and pool, and the reciprocal
+                    // as v_rcp + one Newton step -- 3 instructions -- instead of the 11 of an IEEE division: ~25 vector
+                    // instructions less per task, and every task's set-up is on the phase's critical path)
+                    float inv = 0.0f;
+                    if (n > 0) {
+                        const float nf = (float)n;
+                        const float r0 = __builtin_amdgcn_rcpf(nf);
+                        inv = __builtin_fmaf(__builtin_fmaf(-nf, r0, 1.0f), r0, r0);
+                    } else
+                        mx = V::splat(0.0f);
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) {
+                        if (kk >= np)
+                            break;
+                        V rr = sum; // (an empty graph: 0)
+                        if (pools[kk] == GNNB_POOL_MEAN)
+                            rr = vmul(sum, V::splat(inv));
+                        else if (pools[kk] == GNNB_POOL_MAX)
+                            rr = mx;
+                        rr.store(pooled + ((size_t)(cur.ga + gi) * np + kk) * h1p + col0);
+                    }
+#else
 #pragma unroll
                     for (int kk = 0; kk < 3; kk++) {
                         if (kk >= np)
@@ -1125,6 +1151,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
                             rr = n > 0 ? mx : V::splat(0.0f);
                         rr.store(pooled + ((size_t)(cur.ga + gi) * np + kk) * h1p + col0);
                     }
+#endif
                 }
             };
             // two loops, not one with a choice inside: a select between the LDS table and global memory is

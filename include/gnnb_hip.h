@@ -385,6 +385,8 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *   stage_cut (default 0)        the deep-GCN / GIN stack kernel's workgroups take whole stages of the batch's global greedy stage list,
  *                                planned by graph prep (k_stage_cut_lds, 15-47 us): the kernel alone 8 % faster, the three-stream
  *                                pipeline 2 % at best and 5 % slower with the planner launch: for one-at-a-time forwards
+ *                                (its tables are carved at gnnb_workspace_create: the option must be on THEN; a workspace created
+ *                                without them keeps equal tile counts)
  *   zf_head (default 0)          the 2-layer GCN stack kernel also runs the MLP head on the graphs it pooled (one launch for conv
  *                                stack + pooling + head): measured slower than the separate readout
  *   agg_form (default 0)         gather-aggregate kernel: 0 = LDS ring, 1 = barrier-free register gather (k_aggregate_rg) wherever
