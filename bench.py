@@ -268,9 +268,12 @@ def measure_fused_stack(cm, batch_dev, model_dims, iters=200, conv="gcn", layers
     f0, h0, h1, npool = model_dims
     cm.graph_prep(coo, nptr, eptr, N)
     try:
-        us = cm.gcn_stack_timed(x, iters)
+        # five loops of `iters` launches, the MEDIAN loop reported (and all five listed): the first loop after a pause runs
+        # while the clocks ramp (round 6: 40.0 us for the first loop against 37.2 for the next six on the same box)
+        runs = [cm.gcn_stack_timed(x, iters) for _ in range(5)]
     except RuntimeError:
         return None
+    us = float(np.median(runs))
     if seg is not None:  # the stack kernel runs on the graphs in front of the large segment
         B, N, E = seg
     # the dense updates (MFMA); aggregation flops not counted.  GCN: one linear per layer; GIN: two (hidden = out)
@@ -280,7 +283,7 @@ def measure_fused_stack(cm, batch_dev, model_dims, iters=200, conv="gcn", layers
         flops = 2.0 * N * (f0 * h0 + (layers - 2) * h0 * h0 + h0 * h1)
     # HBM bytes the kernel has to move: x + node records + dinv + tile/graph tables in, pooled out
     alg_bytes = 4 * N * f0 + 32 * N + 4 * N + 4 * (B + 1) + 4 * B * npool * h1
-    return dict(us=us, tflops=flops / (us * 1e-6) / 1e12, flops=flops, alg_bytes=alg_bytes)
+    return dict(us=us, tflops=flops / (us * 1e-6) / 1e12, flops=flops, alg_bytes=alg_bytes, loops_us=[round(float(r), 2) for r in runs])
 
 
 def copy_ceiling(N, width, dev, iters=200):
@@ -1040,7 +1043,7 @@ def main():
                 "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                 "traffic": pmc_traffic("gcn2", args.workload, fused["alg_bytes"]),
                 "algorithmic_flops_per_launch": fused["flops"], "algorithmic_hbm_bytes_per_launch": fused["alg_bytes"],
-                "us_per_launch": fused["us"],
+                "us_per_launch": fused["us"], "loops_us": fused.get("loops_us"),  # (median of five 200-launch loops; all five listed)
                 # the solo launch time against the one-stream prepared forward (NOT against the timed step: with
                 # several batches in flight the stack kernels of consecutive batches overlap their edges)
                 "share_of_single_stream_forward": fused["us"] / (ms_noprep_1s * 1e3),
