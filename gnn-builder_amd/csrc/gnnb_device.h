@@ -170,13 +170,18 @@ struct RangeProbe {
     }
     __device__ __forceinline__ bool any() const { return bad != 0ull; } // wave-uniform
     // one atomic per wave that saw something (rare), and the host-mapped copy graph prep's flag_batch writes too
-    __device__ __forceinline__ void report(int32_t *err, int32_t *err_host) const
+    // returns the number of vector-memory instructions the WAVE issued (wave-uniform: 0, or the atomic + the host-mapped store):
+    // the kernels that count their own vmcnt add it to their books
+    __device__ __forceinline__ int report(int32_t *err, int32_t *err_host) const
     {
-        if (err && bad != 0ull && (threadIdx.x & 63) == 0) {
+        if (!err || bad == 0ull)
+            return 0;
+        if ((threadIdx.x & 63) == 0) {
             atomicOr(err, GNNB_FLAG_RANGE);
             if (err_host)
                 *reinterpret_cast<volatile int32_t *>(err_host) = GNNB_FLAG_RANGE;
         }
+        return err_host ? 2 : 1;
     }
 };
 

@@ -661,10 +661,8 @@ __global__ __launch_bounds__(DWG) void k_linear_dma(GemmArgs g, const float *__r
 #pragma unroll
                 for (int ni = 0; ni < NT; ni++)
                     rp.see_vec<f32x16, 16>(acc[mi][ni]);
-            if (rp.any()) {
-                rp.report(err, err_host);
-                vm++;
-            }
+            if (rp.any())
+                vm += rp.report(err, err_host);
         }
 
         // ---- pooling epilogue (the model's LAST conv layer): act(acc + bias) is pooled per graph instead of stored.

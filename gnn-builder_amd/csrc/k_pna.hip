@@ -238,10 +238,8 @@ __global__ __launch_bounds__(PA_WG, 2) void k_pna_pagg(const float *__restrict__
             for (int k = 0; k < NU; k++)
                 if (rg + k * NRG < units)
                     rp.see_vec<f32x4, 4>(acc[k], (rg + k * NRG) * 16 + li < rows);
-            if (rp.any()) {
-                rp.report(err, err_host);
-                vm++;
-            }
+            if (rp.any())
+                vm += rp.report(err, err_host);
         }
         g2_barrier(); // everybody has read X
         // ---- PW: P over X (lane (li, lg): columns 16 cs + 4 lg .. + 3 of row 16 u + li)
