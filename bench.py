@@ -476,6 +476,37 @@ class Pipeline:
         self.outs = [torch.empty(b.num_graphs, self.cms[0].out_dim, device=dev) for b in batches]
         torch.cuda.synchronize()
 
+    def enable_prep_next(self, model, max_graph, max_degree):
+        """A second workspace per stream: step_prep_next alternates between the two (gnnb_forward_prepared_prep_next)."""
+        from gnnbuilder_amd import runtime
+
+        maxn, maxe, maxb = (max(getattr(b, a) for b in self.batches) for a in ("num_nodes", "num_edges", "num_graphs"))
+        self.alt = [runtime.CompiledModel.from_model(model, maxb, maxn, maxe, max_graph_nodes=max_graph) for _ in range(self.nstreams)]
+        if max_degree:
+            for c in self.alt:
+                c.set_max_degree(max_degree)
+
+    def step_prep_next(self, i, steps):
+        """Step i of a region of `steps` steps, software-pipelined per stream: the forward of batch i and the graph prep of the
+        stream's NEXT batch (i + nstreams) in one call -- that prep runs as extra workgroups of the forward's readout kernel.  Every
+        batch of the region is prepared exactly once and forwarded exactly once INSIDE the region: the first batch of each
+        stream by a graph-prep launch of its own, the last one's call preps nothing."""
+        S, nb = self.nstreams, len(self.dev_batches)
+        self.alt_used = True
+        i %= steps  # (a loop longer than the region starts the next region)
+        j, k = i % S, i % nb
+        pair = (self.cms[j], self.alt[j])
+        cur, nxt = pair[(i // S) & 1], pair[((i // S) + 1) & 1]
+        x, coo, nptr, eptr = self.dev_batches[k]
+        if i < S:
+            cur.graph_prep(coo, nptr, eptr, int(x.shape[0]), stream=self.streams[j])
+        if i + S < steps:
+            _, coo2, nptr2, eptr2 = self.dev_batches[(i + S) % nb]
+            n2 = int(self.dev_batches[(i + S) % nb][0].shape[0])
+            cur.forward_prepared_prep_next(x, nxt, coo2, nptr2, eptr2, n2, out=self.outs[k], stream=self.streams[j])
+        else:
+            cur.forward_prepared(x, out=self.outs[k], stream=self.streams[j])
+
     def step(self, i):
         k, j = i % len(self.dev_batches), i % self.nstreams
         if self.segs[k] is not None:
@@ -485,6 +516,9 @@ class Pipeline:
     def check(self):
         for c, st in zip(self.cms, self.streams):
             c.check(stream=st)  # device-side batch validation (synchronises)
+        if getattr(self, "alt_used", False):
+            for c, st in zip(self.alt, self.streams):
+                c.check(stream=st)
 
     def prepare_topology(self):
         """workspace j keeps batch j prepared (tables + classes): the prep-EXCLUDED rate runs on the same streams"""
@@ -668,6 +702,10 @@ def main():
                     help="rank-batches: every rank draws its own batches of `batch` graphs; one-batch: every global "
                          "batch of batch x N graphs is cut into contiguous node-balanced ranges "
                          "(batching.shard_bounds), one per rank")
+    ap.add_argument("--prep-next", default="0", choices=("0", "1"),
+                    help="1: 2-layer GCN workloads on molecule-sized graphs run the software-pipelined step as `value` (gnnb_forward_prepared_prep_next: "
+                         "forward of batch i + graph prep of the stream's next batch in one call, the prep as extra workgroups of the readout kernel); "
+                         "0 (default): gnnb_forward_batched per step, the pipelined form reported beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief c3 / c4 / c5 legs of the default (c2, one GPU) line")
@@ -795,6 +833,7 @@ def main():
     # PNA: promise on the largest in-degree too (a bound where the reference's degree_guess is a hint; validated on the device): molecules stay far
     # below the 15 up to which the degree-class form of the post-NN product applies (gnnb_workspace_set_max_degree)
     max_graph, max_degree = workload_promises(w, batches, segs)
+    prep_next = can_prep_next = False
     if dry:
         import torch.nn  # noqa: F401
 
@@ -811,6 +850,23 @@ def main():
     else:
         pipe = Pipeline(model, batches, segs, nstreams, dev, max_graph, max_degree)
         cm, dev_batches, outs, step = pipe.cms[0], pipe.dev_batches, pipe.outs, pipe.step
+        # software-pipelined graph prep (gnnb_forward_prepared_prep_next, ABI 104): where the next batch's prep can run inside the readout
+        # kernel -- 2-layer GCN, molecule-sized graphs (promise <= 64 nodes), no large segment.  Same work per step (one graph prep +
+        # one forward, every batch of the timed region prepared and forwarded inside it).  Measured: a gain on ONE stream
+        # (52.0 vs 55.7 us per forward), none with three batches in flight (41.8 vs 41.2 us per step) -- so `value` stays on
+        # gnnb_forward_batched and this form is reported beside it (--prep-next 1 swaps them)
+        can_prep_next = (w["conv"] == "gcn" and w["layers"] == 2 and bool(max_graph) and max_graph <= 64 and
+                         all(sg is None for sg in segs) and args.steps > nstreams)
+        prep_next = can_prep_next and args.prep_next == "1"
+        can_prep_next = can_prep_next and (prep_next or not args.no_roofline)  # (the other form is a side leg of the full line)
+        if can_prep_next:
+            pipe.enable_prep_next(model, max_graph, max_degree)
+
+            def pipelined_step(i):
+                pipe.step_prep_next(i, args.steps)
+            plain_step = pipe.step
+            if prep_next:
+                step = pipelined_step
 
     for i in range(args.warmup):
         step(i)
@@ -846,6 +902,15 @@ def main():
     elapsed = float(np.median(times))
 
     graphs_done = float(sum(batches[i % len(batches)].num_graphs for i in range(args.steps)))
+    # the same region in the other form of the step (see can_prep_next above)
+    other_form = None
+    if not dry and can_prep_next and not args.no_roofline:
+        other = plain_step if prep_next else pipelined_step
+        for i in range(args.warmup):
+            other(i)
+        other_form = float(np.median([timed_region(other) for _ in range(min(repeats, 5))]))
+        for i in range(args.warmup):
+            step(i)
     rccl_ranks = 1
     if world > 1:
         c = torch.tensor([graphs_done, 1.0], device=dev, dtype=torch.float64)
@@ -942,6 +1007,10 @@ def main():
                    "shard": args.shard, "rccl_ranks": rccl_ranks,
                    "batches_in_flight_per_gpu": nstreams, "max_graph_nodes_promise": max_graph,
                    "csr_build_in_timed_region": True,
+                   "graph_prep": ("software-pipelined per stream over two alternating workspaces (gnnb_forward_prepared_prep_next): step i = forward of "
+                                  "batch i + CSR build of the stream's next batch, the build running as extra workgroups of the readout kernel (k_head_small, GUEST); every "
+                                  "batch of the timed region is built once and forwarded once inside the region (the first per stream by a "
+                                  "k_graph_prep launch)") if prep_next else "k_graph_prep launch in front of every forward (gnnb_forward_batched)",
                    "max_degree_promise": max_degree or None,
                    "path": None if dry else cm.last_path()},
         "repeats": {"n": repeats, "statistic": "median", "steps_per_repeat": args.steps,
@@ -955,6 +1024,13 @@ def main():
                     "same streams / region / statistic as `value` (which includes the CSR build); single_stream = one workspace, "
                     "forwards back to back on one stream"},
     }
+    if other_form is not None:
+        result["prep_next_pipeline" if not prep_next else "forward_batched_per_step"] = {
+            "value": graphs_done / other_form, "unit": "graphs/s", "ms_per_step": other_form / args.steps * 1e3,
+            "note": ("the same region, software-pipelined per stream over two alternating workspaces (gnnb_forward_prepared_prep_next): step i = "
+                     "forward of batch i + CSR build of the stream's next batch as extra workgroups of the readout kernel; every batch of the "
+                     "region is built once and forwarded once inside it.  A gain with ONE batch in flight, none with three (DESIGN 3.6): not `value`")
+            if not prep_next else "the same region with gnnb_forward_batched per step (k_graph_prep launch in front of every forward)"}
     if segs[0] is not None:
         result["config"]["large_segment"] = {
             "limit_nodes": w["large_limit"],

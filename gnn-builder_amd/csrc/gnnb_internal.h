@@ -135,6 +135,9 @@ struct Options {
     OptInt agg_rg_wgs;      // ... 256-thread workgroups per CU, resident or not (0 = 32 at one row-instruction per batch)
     OptInt agg_rg_flags;    // ... bit 0: sources past the degree are not loaded (exec-masked; default) instead of aliasing the row itself;
                          //     bit 1: the run pre-touched line by line (slower); bits 2, 3: ablations (GCN, w = 128, one row-instruction)
+    OptInt prep_group;      // graphs per wave of the molecule-path graph prep (k_graph_prep<64, G>: fetches batched): 4 (default; batches of >= 2047 graphs), 1
+    OptInt guest_prep;      // 1 = gnnb_forward_prepared_prep_next runs the next batch's graph prep inside k_gcn2_zf where the batch is
+                         //     eligible (default); 0 = always as k_graph_prep behind the forward
 };
 Options &options();
 
@@ -161,6 +164,32 @@ struct MathScope { // entry points: `MathScope scope(ws->desc.math, ws->t.err, w
     MathScope &operator=(const MathScope &) = delete;
 };
 
+// Arguments of one graph prep (k_graph_prep; round 6: also of the prep the readout kernel runs for its stream's next batch, k_readout.hip)
+struct PrepParams {
+    const int2 *coo;
+    const int32_t *node_ptr, *edge_ptr;
+    int B, N, E;
+    int32_t *row_ptr, *col, *eid;
+    int4 *node_rec;
+    float *dinv, *amp, *att;
+    float delta;
+    int32_t *tile_first, *tile_edge, *tile_graph, *graph_ptr;
+    int tile_rows, num_tiles, max_graph_nodes_hint, promise_graphs, large_n, large_e, drop_self;
+    int32_t *err, *err_host;
+    int4 *agg_cut;
+    int cut_log2;
+    int32_t *node_graph;
+};
+// A graph prep on offer to the launches of a forward on this thread (gnnb_forward_prepared_prep_next): the launcher that runs it
+// inside its kernel sets `taken` (k_head_small, k_readout.hip), otherwise the caller launches k_graph_prep
+struct GuestPrep {
+    const PrepParams *params;
+    bool taken;
+};
+GuestPrep *&guest_prep_slot(); // thread-local; nullptr = nothing on offer
+PrepParams make_prep_params(const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr, const BatchTables &t, float pna_delta,
+                            int drop_self_loops);
+hipError_t launch_graph_prep(const PrepParams &p, hipStream_t s);
 // drop_self_loops: edges (v, v) are not entered into the tables (GCN: PyG's add_remaining_self_loops)
 hipError_t launch_graph_prep(const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
                              BatchTables &t, float pna_delta, int drop_self_loops, hipStream_t s);

@@ -61,13 +61,15 @@ Options &options()
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
                         env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_SAGE_FIRST_MEAN", 1), env_int("GNNB_PNA_FIRST", 1), env_int("GNNB_PNA_PAGG", 1), env_int("GNNB_STAGE_CUT", 0), env_int("GNNB_ZF_HEAD", 0),
-                        env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1)};
+                        env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1), env_int("GNNB_PREP_GROUP", 4), env_int("GNNB_GUEST_PREP", 1)};
     return o;
 }
 
 static thread_local int tl_math = -1; // >= 0: the calling thread is inside an entry point of a model with its own math mode
 static thread_local FlagWord tl_flag = {nullptr, nullptr};
 int launch_math() { return tl_math >= 0 ? tl_math : (int)options().math; }
+static thread_local GuestPrep *tl_guest = nullptr;
+GuestPrep *&guest_prep_slot() { return tl_guest; }
 FlagWord launch_flag_word() { return tl_flag; }
 MathScope::MathScope(int model_math, int32_t *err, int32_t *err_host) : prev(tl_math), prev_flag(tl_flag)
 {
@@ -282,6 +284,10 @@ int gnnb_set_option(const char *name, int value)
         o.stage_cut = value;
     else if (!strcmp(name, "zf_head") && value >= 0 && value <= 1)
         o.zf_head = value;
+    else if (!strcmp(name, "prep_group") && (value == 1 || value == 4))
+        o.prep_group = value;
+    else if (!strcmp(name, "guest_prep") && value >= 0 && value <= 1)
+        o.guest_prep = value;
     else if (!strcmp(name, "agg_form") && value >= 0 && value <= 2)
         o.agg_form = value;
     else if (!strcmp(name, "agg_rg_r") && value >= 0 && value <= 4)
@@ -798,9 +804,40 @@ int gnnb_workspace_set_max_degree(gnnb_workspace *ws, int d)
 static BatchTables small_segment(const gnnb_workspace *ws);
 
 // ---------------------------------------------------------------------------------------
+// Can this workspace's graph prep run as a guest of the forward's readout kernel (k_head_small's extra workgroups)?  The molecule
+// path (promise <= 64 nodes) of a batch that needs NOTHING launched behind its tables: no stage cuts, no degree classes, no
+// coefficient table -- the conditions below are the ones graph_prep_impl launches those under.
+static bool guest_prep_eligible(const gnnb_workspace *ws, int num_nodes)
+{
+    if (!options().guest_prep || ws->max_graph_nodes <= 0 || ws->max_graph_nodes > 64 || ws->large_g >= 0 || num_nodes <= 0)
+        return false;
+    if (options().stage_cut && ws->plan_scratch)
+        return false;
+    if (ws->desc.conv_type == GNNB_CONV_PNA && ws->max_degree > 0 && ws->max_degree <= GNNB_DEG_MAX && options().pna_classes && ws->deg_perm &&
+        ws->desc.fpx_w <= 0)
+        return false;
+    if (ws->desc.conv_type == GNNB_CONV_GCN) {
+        const bool stack_expected = options().fuse_gcn2 && ws->desc.num_layers >= 2 && ws->max_graph_nodes > 0 && ws->large_g < 0 && ws->desc.fpx_w <= 0;
+        if (!stack_expected)
+            return false;
+    }
+    // (the row-balanced aggregate ranges are part of the prep kernel itself: nothing behind it)
+    return true;
+}
+
+// defer != nullptr (and guest_prep_eligible): everything gnnb_graph_prep does EXCEPT the launch -- *defer receives the kernel's arguments
+static int graph_prep_impl(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *node_ptr_dev, const int32_t *edge_ptr_dev,
+                           int num_graphs, int num_nodes, int num_edges, float pna_delta, void *stream, PrepParams *defer);
+
 int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *node_ptr_dev,
                     const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges,
                     float pna_delta, void *stream)
+{
+    return graph_prep_impl(ws, coo_dev, node_ptr_dev, edge_ptr_dev, num_graphs, num_nodes, num_edges, pna_delta, stream, nullptr);
+}
+
+static int graph_prep_impl(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *node_ptr_dev, const int32_t *edge_ptr_dev,
+                           int num_graphs, int num_nodes, int num_edges, float pna_delta, void *stream, PrepParams *defer)
 {
     if (!ws || !node_ptr_dev || !edge_ptr_dev || (num_edges > 0 && !coo_dev))
         return fail(GNNB_ERR_INVALID, "null argument to gnnb_graph_prep");
@@ -874,10 +911,23 @@ int gnnb_graph_prep(gnnb_workspace *ws, const int32_t *coo_dev, const int32_t *n
     // GCN: an explicit self-loop edge is not entered into the tables (PyG's gcn_norm replaces the self loops of the
     // input by exactly one per node; the reference C++ would count it on top of its own self term, see gnnb_hip.h)
     const int drop_self = ws->desc.conv_type == GNNB_CONV_GCN ? 1 : 0;
-    GNNB_HIP_TRY(launch_graph_prep(coo_dev, node_ptr_dev, edge_ptr_dev, t, prep_delta, drop_self,
-                                   (hipStream_t)stream));
+    const bool deferred = defer && guest_prep_eligible(ws, num_nodes);
+    if (deferred)
+        *defer = make_prep_params(coo_dev, node_ptr_dev, edge_ptr_dev, t, prep_delta, drop_self);
+    else {
+        if (defer)
+            return fail(GNNB_ERR_INVALID, "graph prep deferred for a workspace that is not eligible");
+        GNNB_HIP_TRY(launch_graph_prep(coo_dev, node_ptr_dev, edge_ptr_dev, t, prep_delta, drop_self,
+                                       (hipStream_t)stream));
+    }
     ws->prepared = true;
     ws->prep_delta = prep_delta > 0.0f ? prep_delta : 0.0f;
+    if (deferred) { // (eligible = nothing below would be launched: the tables do not exist yet)
+        t.stage_cut_n = 0;
+        ws->gcoef_ready = false;
+        ws->deg_ready = false;
+        return GNNB_OK;
+    }
     // the conv-stack kernel's workgroup runs as whole stages of the global greedy stage list (k_plan.hip), right behind the tables
     // on the prep stream: for the batches that k_gcn2_fused takes (GIN stacks, GCN stacks deeper than two layers, the bf16x6 mode)
     t.stage_cut_n = 0;
@@ -1788,6 +1838,49 @@ int gnnb_forward_batched(const gnnb_model *model, gnnb_workspace *ws, const floa
     if (rc != GNNB_OK)
         return rc;
     return gnnb_forward_prepared(model, ws, x_dev, out_dev, stream);
+}
+
+// gnnb_forward_prepared(model, ws, ...) followed by gnnb_graph_prep(ws_next, ...) on the same stream -- with the prep of ws_next
+// run INSIDE the forward's readout kernel where that exists (k_head_small, GUEST: extra workgroups): the software-pipelined form
+// of gnnb_forward_batched for a stream of batches over two alternating workspaces.
+int gnnb_forward_prepared_prep_next(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, float *out_dev,
+                                    gnnb_workspace *ws_next, const int32_t *coo_dev, const int32_t *node_ptr_dev,
+                                    const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges, void *stream)
+{
+    if (!model || !ws || !ws_next)
+        return fail(GNNB_ERR_INVALID, "null argument to gnnb_forward_prepared_prep_next");
+    if (ws == ws_next)
+        return fail(GNNB_ERR_INVALID, "gnnb_forward_prepared_prep_next: the next batch needs a workspace of its own (the forward reads "
+                                      "the tables the prep writes)");
+    if (!ws->prepared)
+        return fail(GNNB_ERR_INVALID, "workspace has no prepared batch");
+    if (!guest_prep_eligible(ws_next, num_nodes)) {
+        const int rc = gnnb_forward_prepared(model, ws, x_dev, out_dev, stream);
+        if (rc != GNNB_OK)
+            return rc;
+        return gnnb_graph_prep(ws_next, coo_dev, node_ptr_dev, edge_ptr_dev, num_graphs, num_nodes, num_edges, model->desc.pna_delta, stream);
+    }
+    PrepParams pp;
+    int rc = graph_prep_impl(ws_next, coo_dev, node_ptr_dev, edge_ptr_dev, num_graphs, num_nodes, num_edges, model->desc.pna_delta, stream, &pp);
+    if (rc != GNNB_OK)
+        return rc; // (nothing was enqueued)
+    ws_next->prepared = false; // (until its prep is enqueued)
+    GuestPrep offer{&pp, false};
+    struct Offer { // (the slot never outlives this call)
+        GuestPrep *prev;
+        explicit Offer(GuestPrep *g) : prev(guest_prep_slot()) { guest_prep_slot() = g; }
+        ~Offer() { guest_prep_slot() = prev; }
+    };
+    {
+        Offer scope(&offer);
+        rc = gnnb_forward_prepared(model, ws, x_dev, out_dev, stream);
+    }
+    if (rc != GNNB_OK && !offer.taken)
+        return rc; // (ws_next stays unprepared)
+    if (!offer.taken) // the forward ran another readout than the one that hosts a prep: the prep as a launch of its own
+        GNNB_HIP_TRY(launch_graph_prep(pp, (hipStream_t)stream));
+    ws_next->prepared = true;
+    return rc;
 }
 
 int gnnb_forward_batched_host(const gnnb_model *model, gnnb_workspace *ws, const float *x,

@@ -1,7 +1,11 @@
 // k_readout.hip -- per-graph add / mean / max pooling + MLP head: k_global_pool, k_pool_mlp, k_head_small
 // Part of libgnnb_hip.so (hand-written gfx950 / CDNA4 kernels of the GNNBuilder hot path); wavefront = 64 lanes.
+#include <algorithm>
+#include <cstring>
+
 #include "gnnb_device.h"
 #include "gnnb_head.h"
+#include "gnnb_prep.h"
 
 namespace gnnb {
 
@@ -376,16 +380,35 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_pool_mlp(const float *__restri
 // One workgroup = 16 graphs; wave w takes the 16-column output slices w, w + 4, ...
 static constexpr int HS_THREADS = 256;
 
-template <int ACT>
-__global__ __launch_bounds__(HS_THREADS, 5) void k_head_small(const float *__restrict__ pooled, int B, HeadArgs head,
-                                                             float *__restrict__ out, int ldact)
+// GUEST (round 6, gnnb_forward_prepared_prep_next): the graph prep of the stream's NEXT batch -- COO -> CSR, node records,
+// normalisers, tile tables of ANOTHER workspace (gnnb_prep.h: one wavefront per graph, <= 64 nodes each by that workspace's
+// promise) -- as EXTRA WORKGROUPS of this launch: blocks [0, prep_blocks) prepare four graphs each, the rest run the head.  The
+// prep is a chain of dependent fetches (its graph's table entries, its edges, then a few hundred instructions and the
+// stores: ~6 us from launch to the last store) that occupies almost nothing; as a launch of its own beside the stack kernels
+// of the other streams' batches it cost the three-stream pipeline ~4.5 us of a 42-us step.  Here it starts with the first
+// blocks of a kernel that runs ~11 us anyway.  (Tried first inside k_gcn2_zf, on the waves that idle through the last stage's
+// aggregation phase: that window is 2 us, the chain -- even with its fetches hoisted into the kernel's prologue -- outlasts
+// it by 4 us, and the stack kernel is the pipeline's critical resource: no gain)
+// The parameter block is the kernel's FIRST argument and is never named: the prep blocks read it from the kernarg segment
+// (offset 0), the head blocks never fetch it.
+template <int ACT, bool GUEST>
+__global__ __launch_bounds__(HS_THREADS, 5) void k_head_small(PrepParams guest_kernarg, int prep_blocks, const float *__restrict__ pooled, int B,
+                                                             HeadArgs head, float *__restrict__ out, int ldact)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __builtin_amdgcn_s_setprio(GNNB_GUEST_PRIO); // (co-runs with the next batch's conv-stack kernel: see k_graph_prep)
-    float *sact = reinterpret_cast<float *>(smem); // [2][16][ldact]: ldact = widest hidden layer + 4 (padded rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (GUEST) {
+        static_assert(HS_THREADS / 64 == WG / 64, "the guest prep's blocks are k_graph_prep's");
+        if ((int)blockIdx.x < prep_blocks) {
+            const PrepParams gp = *kernarg_prep_params();
+            prep_graph_group<64, 4>(gp, (blockIdx.x * (HS_THREADS / 64) + wave) * 4, lane, reinterpret_cast<int32_t *>(smem) + wave * 256);
+            return;
+        }
+    }
+    float *sact = reinterpret_cast<float *>(smem); // [2][16][ldact]: ldact = widest hidden layer + 4 (padded rows)
     // one workgroup = one group of four waves = one tile of 16 graphs (gnnb_head.h)
-    head_small_run<ACT>(pooled, 0, B, head, out, ldact, sact, lane, wave, (int)blockIdx.x, 0, 1, [] { __syncthreads(); });
+    head_small_run<ACT>(pooled, 0, B, head, out, ldact, sact, lane, wave, (int)blockIdx.x - (GUEST ? prep_blocks : 0), 0, 1, [] { __syncthreads(); });
 }
 
 // hipErrorNotSupported when the head's shape does not suit the small form (caller takes k_pool_mlp)
@@ -397,14 +420,30 @@ static hipError_t launch_head_small(int num_graphs, const HeadArgs &head, int ac
     const int ldact = head_small_ldact(head);
     if (ldact <= 0)
         return hipErrorNotSupported;
-    const size_t lds = head_small_lds_bytes(ldact);
     const int grid = (num_graphs + 15) / 16;
+    // a guest graph prep on offer (gnnb_forward_prepared_prep_next)?
+    GuestPrep *const gslot = guest_prep_slot();
+    const bool guest = gslot && gslot->params && !gslot->taken && gslot->params->max_graph_nodes_hint > 0 && gslot->params->max_graph_nodes_hint <= 64;
+    PrepParams gp;
+    memset(&gp, 0, sizeof(gp));
+    int prep_blocks = 0;
+    if (guest) {
+        gp = *gslot->params;
+        prep_blocks = ((gp.B + 1 + 3) / 4 + (HS_THREADS / 64) - 1) / (HS_THREADS / 64);
+    }
+    const size_t lds = std::max(head_small_lds_bytes(ldact), guest ? (size_t)(HS_THREADS / 64) * 1024 : (size_t)0);
     auto go = [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
-        hipLaunchKernelGGL(k_head_small<ACT>, dim3(grid), dim3(HS_THREADS), lds, s, prepooled, num_graphs, head, out, ldact);
+        if (guest)
+            hipLaunchKernelGGL((k_head_small<ACT, true>), dim3(grid + prep_blocks), dim3(HS_THREADS), lds, s, gp, prep_blocks, prepooled, num_graphs, head, out, ldact);
+        else
+            hipLaunchKernelGGL((k_head_small<ACT, false>), dim3(grid), dim3(HS_THREADS), lds, s, gp, 0, prepooled, num_graphs, head, out, ldact);
     };
     GNNB_DISPATCH_ACT(act, go)
-    return hipGetLastError();
+    const hipError_t rc = hipGetLastError();
+    if (guest && rc == hipSuccess)
+        gslot->taken = true;
+    return rc;
 }
 
 hipError_t launch_pool_mlp(const float *x, const int32_t *node_ptr, int num_graphs, int d,

@@ -84,7 +84,7 @@ EXPORTED_SYMBOLS = [
     "gnnb_model_num_params", "gnnb_model_create", "gnnb_model_destroy", "gnnb_model_get_desc",
     "gnnb_workspace_create", "gnnb_workspace_destroy", "gnnb_workspace_bytes", "gnnb_workspace_set_max_graph_nodes", "gnnb_workspace_set_max_degree",
     "gnnb_workspace_last_path", "gnnb_workspace_set_large_segment",
-    "gnnb_forward_batched", "gnnb_forward_prepared", "gnnb_forward_batched_host", "gnnb_workspace_check",
+    "gnnb_forward_batched", "gnnb_forward_prepared", "gnnb_forward_prepared_prep_next", "gnnb_forward_batched_host", "gnnb_workspace_check",
     "gnnb_graph_prep", "gnnb_graph_tables_to_host", "gnnb_aggregate", "gnnb_linear", "gnnb_global_pool",
     "gnnb_event_create", "gnnb_event_record", "gnnb_event_elapsed_ms", "gnnb_event_destroy",
     "gnnb_malloc", "gnnb_free", "gnnb_memcpy_h2d", "gnnb_memcpy_d2h", "gnnb_set_option",
@@ -132,6 +132,8 @@ def load_library(require_gpu: bool = True) -> C.CDLL:
         lib.gnnb_forward_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.gnnb_forward_prepared.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.gnnb_forward_prepared_prep_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         lib.gnnb_graph_prep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_int, C.c_float, C.c_void_p]
         lib.gnnb_aggregate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -382,6 +384,29 @@ class CompiledModel:
             if out.shape[0] != self._B or out.device != x.device:
                 raise GnnbError(f"out must be [{self._B}, {self.out_dim}] on {x.device}, got {tuple(out.shape)} on {out.device}")
         _check(self.lib.gnnb_forward_prepared(self._model, self._ws, _dptr(x), _dptr(out), _stream_ptr(stream)))
+        return out
+
+    def forward_prepared_prep_next(self, x, nxt: "CompiledModel", coo, node_ptr, edge_ptr, num_nodes: int, out=None, stream=None):
+        """``forward_prepared(x)`` on this object's prepared batch, then the graph prep of the NEXT batch on the workspace of
+        ``nxt`` -- a second ``CompiledModel`` of the same design (two alternate along a stream of batches) -- in one call
+        (``gnnb_forward_prepared_prep_next``): where the forward runs the 2-layer GCN stack kernel, the prep runs inside it.
+        ``nxt.forward_prepared`` / ``nxt.forward_prepared_prep_next`` is then the next batch's forward."""
+        import torch
+        _require(x, "x", torch.float32, 2, int(self.desc.in_dim))
+        if int(x.shape[0]) != self._N:
+            raise GnnbError(f"x has {int(x.shape[0])} rows, the prepared batch has {self._N} nodes")
+        self._check_batch(None, coo, node_ptr, edge_ptr)
+        if out is None:
+            out = torch.empty((self._B, self.out_dim), dtype=torch.float32, device=x.device)
+        else:
+            _require(out, "out", torch.float32, 2, self.out_dim)
+            if out.shape[0] != self._B or out.device != x.device:
+                raise GnnbError(f"out must be [{self._B}, {self.out_dim}] on {x.device}, got {tuple(out.shape)} on {out.device}")
+        B = int(node_ptr.numel()) - 1
+        _check(self.lib.gnnb_forward_prepared_prep_next(self._model, self._ws, _dptr(x), _dptr(out), nxt._ws, _dptr(coo), _dptr(node_ptr),
+                                                        _dptr(edge_ptr), B, int(num_nodes), int(coo.shape[0]), _stream_ptr(stream)))
+        nxt._keep = (coo, node_ptr, edge_ptr)
+        nxt._N, nxt._E, nxt._B = int(num_nodes), int(coo.shape[0]), B
         return out
 
     def check(self, stream=None) -> None:

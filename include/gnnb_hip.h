@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNB_VERSION 103
+#define GNNB_VERSION 104
 
 typedef enum gnnb_status {
     GNNB_OK = 0,
@@ -212,6 +212,25 @@ int gnnb_forward_batched(const gnnb_model *model, gnnb_workspace *ws, const floa
  * (the topology of the batch is unchanged; only features differ). */
 int gnnb_forward_prepared(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev,
                           float *out_dev, void *stream);
+/* Software-pipelined form of gnnb_forward_batched for a stream of batches over TWO workspaces of one model (ABI 104):
+ * the forward of the batch prepared on `ws` (as gnnb_forward_prepared), then the graph prep of the NEXT batch on `ws_next`
+ * (as gnnb_graph_prep with the model's pna_delta), both on `stream` -- one call per batch,
+ *     gnnb_graph_prep(wsA, batch 0);  prep_next(wsA, x0, out0, wsB, batch 1);  prep_next(wsB, x1, out1, wsA, batch 2); ...
+ *     ... gnnb_forward_prepared(ws?, x_last, out_last)
+ * Results and tables are bit-identical to gnnb_forward_batched per batch.  What it buys: where ws_next carries a
+ * max_graph_nodes promise <= 64, no large segment, and nothing has to be launched behind its tables (no degree classes, stage
+ * cuts or GCN coefficient table), the next batch's prep runs as EXTRA WORKGROUPS of the forward's readout kernel (k_head_small)
+ * instead of as a launch of its own: -6.6 % per forward with one batch in flight at BASELINE config 2; with three batches in
+ * flight on three streams no gain, so bench.py's `value` keeps gnnb_forward_batched.  Anywhere else the prep is
+ * launched behind the forward, as the two calls would.  The reference has no counterpart (its compute_degree_tables /
+ * compute_neighbor_tables run serially in front of every graph's layers, gnn_builder_lib.h:1051-1124); option guest_prep = 0
+ * turns the in-kernel form off.
+ * ws_next must differ from ws (GNNB_ERR_INVALID) and, like any workspace, must not be in use by work still running on
+ * another stream.  Errors of the next batch's host-side validation (capacity, a flag left by an earlier batch on ws_next) are
+ * returned before anything is enqueued; after a forward error ws_next has no prepared batch. */
+int gnnb_forward_prepared_prep_next(const gnnb_model *model, gnnb_workspace *ws, const float *x_dev, float *out_dev,
+                                    gnnb_workspace *ws_next, const int32_t *coo_dev, const int32_t *node_ptr_dev,
+                                    const int32_t *edge_ptr_dev, int num_graphs, int num_nodes, int num_edges, void *stream);
 /* Host-buffer convenience: H2D copies, forward, D2H copy, synchronises. */
 int gnnb_forward_batched_host(const gnnb_model *model, gnnb_workspace *ws, const float *x,
                               const int32_t *coo, const int32_t *node_ptr, const int32_t *edge_ptr,
@@ -389,6 +408,12 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *                                without them keeps equal tile counts)
  *   zf_head (default 0)          the 2-layer GCN stack kernel also runs the MLP head on the graphs it pooled (one launch for conv
  *                                stack + pooling + head): measured slower than the separate readout
+ *   prep_group (default 4)       graph prep, molecule path (max_graph_nodes promise <= 64), batches of >= 2047 graphs: 4 = a wave
+ *                                prepares four consecutive graphs with its fetches batched (a quarter of the workgroups: cheaper
+ *                                beside the stack kernels of other batches in flight); 1 = one graph per wave (lower latency when
+ *                                the batch has the chip to itself).  Same tables
+ *   guest_prep (default 1)       gnnb_forward_prepared_prep_next: 1 = the next batch's prep as extra workgroups of the readout
+ *                                kernel where eligible; 0 = always a launch of its own behind the forward
  *   agg_form (default 0)         gather-aggregate kernel: 0 = LDS ring, 1 = barrier-free register gather (k_aggregate_rg) wherever
  *                                it exists, 2 = that form for PNA only; agg_rg_r / agg_rg_wgs / agg_rg_flags shape its launch
  *   fold_skip (default 1)        GraphSAGE: a middle layer's skip connection (y = conv(x) + x) as + I on the root weights -- x is an

@@ -43,7 +43,7 @@ def test_library_has_gfx950_code_object(lib_path):
 
 def test_library_loads_and_reports_version(lib_path):
     lib = runtime.load_library(require_gpu=False)
-    assert lib.gnnb_version() == 103
+    assert lib.gnnb_version() == 104
     for sym in runtime.EXPORTED_SYMBOLS:
         assert hasattr(lib, sym)
 
