@@ -78,6 +78,19 @@ for it in range(cases):
     args = to_dev(batch, dev)
     got = cm.forward(*args).cpu().numpy()
     cm.check()
+    # (round 6) every other case once more through the software-pipelined entry: this forward + the SAME batch's prep on a second
+    # workspace in one call (the prep as a guest of the readout kernel where eligible, a launch of its own elsewhere -- e.g. with
+    # zf_head, promise > 64), then the forward on that workspace: the same bits
+    if it % 2 == 0:
+        cm2 = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise)
+        again = cm.forward_prepared_prep_next(args[0], cm2, args[1], args[2], args[3], batch.num_nodes).cpu().numpy()
+        piped = cm2.forward_prepared(args[0]).cpu().numpy()
+        cm.check()
+        cm2.check()
+        if not (np.array_equal(again, got) and np.array_equal(piped, got)):
+            print(f"FAIL case {it}: gnnb_forward_prepared_prep_next differs from gnnb_forward_batched (promise {promise}, B={B})")
+            sys.exit(1)
+        cm2.close()
     took = True
     try:
         cm.gcn_stack_timed(args[0], 1)

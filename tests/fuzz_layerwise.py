@@ -77,6 +77,19 @@ try:
         got = cm.forward(*args).cpu().numpy()
         cm.check()
         again = cm.forward(*args).cpu().numpy()
+        if it % 2 == 0:
+            # (round 6) the software-pipelined entry: this forward + the SAME batch's prep on a second workspace in one call (a guest
+            # of the readout kernel where the workspace is eligible, a launch of its own elsewhere), then the forward there: the same bits
+            cm2 = runtime.CompiledModel.from_model(model, batch.num_graphs, batch.num_nodes, max(batch.num_edges, 1), max_graph_nodes=promise_n)
+            if promise:
+                cm2.set_max_degree(promise)
+            first = cm.forward_prepared_prep_next(args[0], cm2, args[1], args[2], args[3], batch.num_nodes).cpu().numpy()
+            piped = cm2.forward_prepared(args[0]).cpu().numpy()
+            cm2.check()
+            if not (np.array_equal(first, got) and np.array_equal(piped, got)):
+                print(f"FAIL case {it}: gnnb_forward_prepared_prep_next differs from gnnb_forward_batched ({conv}, max_graph_nodes={promise_n}, maxdeg promise {promise})")
+                sys.exit(1)
+            cm2.close()
         err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
         worst = max(worst, err) if math != 3 else worst
         worst_reduced = max(worst_reduced, err) if math == 3 else worst_reduced
