@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Development: what does the guest graph prep add to one k_gcn2_zf launch?  One stream, two workspaces, BASELINE config 2:
-a loop of forward_prepared (stack + head) against a loop of forward_prepared_prep_next (the same + the other workspace's
-prep inside the stack kernel) and a loop of forward (prep launch + stack + head).  us per call, median of five loops."""
+"""Development: what does the graph prep cost ONE stream of forwards, by host?  Two workspaces, BASELINE config 2: a loop of
+forward_prepared (stack + head: no prep) against a loop of forward_prepared_prep_next (the same + the other workspace's prep as
+extra workgroups of the readout kernel) and a loop of forward (prep launch + stack + head).  us per call, median of five loops
+(49.8 / 52.0 / 55.7 with one graph per prep wave, 58.9 with groups of four)."""
 import os, sys, time, json
 from pathlib import Path
 import numpy as np, torch
