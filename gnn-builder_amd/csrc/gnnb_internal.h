@@ -336,7 +336,12 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
                           int h0, const float *w1, const float *b1, int h1, int act,
                           const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1_frag_order = nullptr,
                           const HeadArgs *head = nullptr, const HeadArgs *head_dev = nullptr, float *head_out = nullptr,
-                          bool *head_fused = nullptr); // (head: host copy for the shape checks; head_dev: the same in device memory, what the kernel reads)
+                          bool *head_fused = nullptr);
+hipError_t launch_gcn2_zf_head(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
+                          int h0, const float *w1, const float *b1, int h1, int act,
+                          const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1_frag_order = nullptr,
+                          const HeadArgs *head = nullptr, const HeadArgs *head_dev = nullptr, float *head_out = nullptr,
+                          bool *head_fused = nullptr); // k_stack_zf_head.hip: the kernels WITH the MLP-head tail  (head: host copy for the shape checks; head_dev: the same in device memory, what the kernel reads)
 
 // One GCN / GIN conv layer for node rows [row_lo, N) in the small-footprint form that co-resides with the stack kernels
 // (k_conv_rows.hip: the large segment of a batch).  hipErrorNotSupported: widths beyond 128 or another conv type.

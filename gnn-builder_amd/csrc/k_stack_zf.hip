@@ -5,8 +5,19 @@
 #include "gnnb_stack.h"
 #include "gnnb_head.h"
 
+// TWO translation units are made of this file (round 6): k_stack_zf.hip itself holds the kernels WITHOUT the MLP-head tail (the
+// default forward: the head is a guest launch) and k_stack_zf_head.hip (#define ZF_TU_HEAD 1 + #include of this
+// file) the ones WITH it (option zf_head).  Without the tail's code the fp32 kernels fit 96 registers, and five waves per SIMD's
+// worth of budget leave a 128-register hole beside them -- room for TWO guest waves per SIMD (graph prep 56, readout 88) where
+// 104 registers left one (see REGISTER BUDGET below).
+#ifndef ZF_TU_HEAD
+#define ZF_TU_HEAD 0
+#endif
+
 namespace gnnb {
 
+#ifndef GNNB_ZF_KERNEL_DEFINED // (the probe build includes both translation units' sources into one)
+#define GNNB_ZF_KERNEL_DEFINED
 // =====================================================================================
 // k_gcn2_zf: the BASELINE config 1 / 2 model family (two GCN layers, fp32), round 3
 // =====================================================================================
@@ -258,8 +269,23 @@ struct ZfStage {
 // wave slot, and with ~145 KB of LDS per CU that is what lets the readout and graph-prep kernels of the other batches in
 // flight run BESIDE it: at 111 registers the three-stream pipeline of bench.py lost 12 % (59.0 vs 52.1 us per step).
 // (The launch bound only promises four waves per SIMD = 128 registers; amdgpu_num_vgpr is ignored beside it.)
-template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS, int MX = 0, bool H1FULL = false>
-__global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
+// Round 6: the forms below that fit it take 96 (a launch bound of FIVE waves per SIMD): the hole beside four of them is then 128
+// registers -- two guest waves per SIMD.
+// (round 6) HEAD = false: no MLP-head tail in the kernel's text, and for the fp32 form a budget of 96 registers (five waves per
+// SIMD by the launch bound: 99 -> 95-96 without a spill once the tail is gone).  Beside four such waves a SIMD has 128 registers
+// left: two guest waves (graph prep 56, or prep + ... the readout's 88 alone) instead of one -- the driver's 20-step region
+// 46.2 -> 45.1 us per step (six alternating runs each), `--steps 200` and the kernel alone unchanged (37.3 vs 37.2 us).
+// Which instantiations take the 96-register budget: the ones that fit it WITHOUT a spill (`make resource-usage`; the CPU test
+// test_no_stack_kernel_spills_to_scratch holds every instantiation to zero scratch) -- the fp32 forms without the head tail at
+// hidden widths 32 / 64, and at hidden 128 the ReLU form with a one-block input (every BASELINE GCN model); hidden 128 with
+// GELU / sigmoid / tanh or a two-block input needs 97-100 and keeps the 104-register budget.
+template <int ACT, int KQ0, int KQ1, int MX, bool HEAD>
+constexpr int zf_waves_per_simd()
+{
+    return (!HEAD && MX == 0 && (KQ1 < 8 || (ACT == GNNB_ACT_RELU && KQ0 == 1))) ? 5 : 4;
+}
+template <int ACT, int KQ0, int KQ1, int NW, int ZF_UNITS, int MX = 0, bool H1FULL = false, bool HEAD = true>
+__global__ __launch_bounds__(NW * 64, (zf_waves_per_simd<ACT, KQ0, KQ1, MX, HEAD>())) void k_gcn2_zf(
     const float *__restrict__ x, int f0, const int4 *__restrict__ node_rec,
     const int32_t *__restrict__ col, const float *__restrict__ dinv,
     const int32_t *__restrict__ tile_first, const int32_t *__restrict__ tile_graph, const int32_t *__restrict__ tile_edge,
@@ -1212,7 +1238,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_gcn2_zf(
     // CU reads through -- none of these lines can sit in its vector L1: the kernel has not read them), one barrier, then
     // groups of four waves take tiles of 16 graphs through gnnb_head.h -- weights and pooled rows as MFMA operands from L2,
     // the 16 x width activations in the (dead) H region.  ~2 us at the end of a workgroup's life instead of a third launch.
-    if (head_dev != nullptr) {
+    if (HEAD && head_dev != nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         g2_barrier();
         const HeadArgs &head = *head_dev; // (read HERE, through the scalar cache: nothing of it lives through the stage loop)
@@ -1247,8 +1273,11 @@ static bool zf_wide_shape(int f0, int promise)
     (void)promise;
     return f0 <= 16 && sh != 0;
 }
-int zf_stage_rows(int f0, int promise) { return zf_wide_shape(f0, promise) ? 176 : 96; }
 static constexpr int ZF_TCAP = 62; // tiles per workgroup: the run's table lives in one register per lane (+ its end)
+#endif // GNNB_ZF_KERNEL_DEFINED
+
+#if !ZF_TU_HEAD
+int zf_stage_rows(int f0, int promise) { return zf_wide_shape(f0, promise) ? 176 : 96; }
 long gcn2_zf_tile_capacity(int f0, int promise)
 {
     return (long)ZF_TCAP * (zf_wide_shape(f0, promise) ? 1 : 2) * device_cu_count();
@@ -1284,7 +1313,14 @@ extern "C" int gnnb_zf_dbg_spans(unsigned long long *host, int *launches)
 }
 #endif
 
-hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
+#endif // !ZF_TU_HEAD
+
+#if ZF_TU_HEAD
+#define ZF_LAUNCH_NAME launch_gcn2_zf_head // (the kernels with the MLP-head tail: called by launch_gcn2_zf when the head is to run inside)
+#else
+#define ZF_LAUNCH_NAME launch_gcn2_zf
+#endif
+hipError_t ZF_LAUNCH_NAME(const BatchTables &t, const float *x, int f0, const float *w0, const float *b0,
                           int h0, const float *w1, const float *b1, int h1, int act,
                           const int32_t *pools, int num_pools, float *pooled, hipStream_t s, const float *w1f,
                           const HeadArgs *head_in, const HeadArgs *head_dev_in, float *head_out, bool *head_fused)
@@ -1341,11 +1377,18 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
             head_ldact = ld;
         }
     }
+#if ZF_TU_HEAD
+    if (head_dev == nullptr)
+        return hipErrorNotSupported; // (this translation unit holds the kernels with the head tail only)
+#else
+    if (head_dev != nullptr)
+        return launch_gcn2_zf_head(t, x, f0, w0, b0, h0, w1, b1, h1, act, pools, num_pools, pooled, s, w1f, head_in, head_dev_in, head_out, head_fused);
+#endif
     hipError_t rc = hipErrorNotSupported;
     auto go3 = [&](auto atag, auto q0tag, auto q1tag, auto nwtag, auto utag, auto mxtag, auto fulltag) {
         constexpr int ACT = decltype(atag)::value, KQ0 = decltype(q0tag)::value, KQ1 = decltype(q1tag)::value;
         constexpr int NW = decltype(nwtag)::value, NU = decltype(utag)::value, MX = decltype(mxtag)::value;
-        auto kern = k_gcn2_zf<ACT, KQ0, KQ1, NW, NU, MX, decltype(fulltag)::value != 0>;
+        auto kern = k_gcn2_zf<ACT, KQ0, KQ1, NW, NU, MX, decltype(fulltag)::value != 0, ZF_TU_HEAD != 0>;
         if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds) != hipSuccess) {
             rc = hipErrorNotSupported;
             return;
@@ -1435,5 +1478,7 @@ hipError_t launch_gcn2_zf(const BatchTables &t, const float *x, int f0, const fl
 #ifdef GNNB_ZF_ABLATE
 #undef lds
 #endif
+#undef ZF_LAUNCH_NAME
 
 } // namespace gnnb
+#undef ZF_TU_HEAD
