@@ -188,36 +188,40 @@ __device__ __forceinline__ void head_small_run(const float *__restrict__ pooled,
 #pragma unroll
                 for (int u = 0; u < 4; u++)
                     accs[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                auto loadf = [&](int kb, float4 (&a)[4], float4 (&w)[4]) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int kk = kb + 16 * u; // (+ 4 lg inside the row pointers)
-                        const bool ok = kk + 4 * lg < k; // k % 4 == 0: a float4 is whole or absent
-                        const int kc = ok ? kk : 0;
-                        w[u] = *reinterpret_cast<const float4 *>(wrow + kc);
-                        a[u] = l == 0 ? *reinterpret_cast<const float4 *>(arow_g + kc)
-                                      : *reinterpret_cast<const float4 *>(arow_l + kc);
-                        if (!ok)
-                            a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                };
-                // (no operand double-buffering: the register budget is what lets the stand-alone kernel share a SIMD with the
+                // The four k slices of a 64-wide block are fetched and multiplied as TWO PAIRS (round 6): half the operand registers of
+                // the four-at-once form, the same four accumulators and the same sums in the same order (bit-identical results).
+                // What it buys is the stand-alone kernel's register count, 82 -> 67: beside four 96-register waves of k_gcn2_zf a SIMD
+                // has 128 registers left, and a 72-register readout wave + a 56-register graph-prep wave now fit TOGETHER.
+                // (no operand double-buffering either: the register budget is what lets the stand-alone kernel share a SIMD with the
                 // conv-stack kernel of another batch, and inside k_gcn2_zf it must stay below that kernel's own budget)
                 for (int kb = 0; kb < k; kb += 64) {
-                    float4 a[4], w[4];
-                    loadf(kb, a, w);
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, w[u].x, accs[u], 0, 0, 0);
+                    for (int hp = 0; hp < 2; hp++) {
+                        float4 a[2], w[2];
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, w[u].y, accs[u], 0, 0, 0);
+                        for (int u2 = 0; u2 < 2; u2++) {
+                            const int kk = kb + 16 * (2 * hp + u2); // (+ 4 lg inside the row pointers)
+                            const bool ok = kk + 4 * lg < k;        // k % 4 == 0: a float4 is whole or absent
+                            const int kc = ok ? kk : 0;
+                            w[u2] = *reinterpret_cast<const float4 *>(wrow + kc);
+                            a[u2] = l == 0 ? *reinterpret_cast<const float4 *>(arow_g + kc)  // layer 0: A straight from the pooled matrix
+                                           : *reinterpret_cast<const float4 *>(arow_l + kc); // later layers: from LDS
+                            if (!ok)
+                                a[u2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, w[u].z, accs[u], 0, 0, 0);
+                        for (int u2 = 0; u2 < 2; u2++)
+                            accs[2 * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].x, w[u2].x, accs[2 * hp + u2], 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, w[u].w, accs[u], 0, 0, 0);
+                        for (int u2 = 0; u2 < 2; u2++)
+                            accs[2 * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].y, w[u2].y, accs[2 * hp + u2], 0, 0, 0);
+#pragma unroll
+                        for (int u2 = 0; u2 < 2; u2++)
+                            accs[2 * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].z, w[u2].z, accs[2 * hp + u2], 0, 0, 0);
+#pragma unroll
+                        for (int u2 = 0; u2 < 2; u2++)
+                            accs[2 * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].w, w[u2].w, accs[2 * hp + u2], 0, 0, 0);
+                    }
                 }
                 // C/D: col = lane&15 (output column nn), row = (lane>>4)*4 + r (graph inside the tile)
                 if (nn < n) {

@@ -391,8 +391,14 @@ static constexpr int HS_THREADS = 256;
 // it by 4 us, and the stack kernel is the pipeline's critical resource: no gain)
 // The parameter block is the kernel's FIRST argument and is never named: the prep blocks read it from the kernarg segment
 // (offset 0), the head blocks never fetch it.
+// REGISTER BUDGET (round 6): 72 (a launch bound of seven waves per SIMD; 67 used).  Beside k_gcn2_zf's four 96-register waves a
+// SIMD has 128 registers left: this kernel's wave and a graph-prep wave (56) of the stream's next batch then run side by side
+// instead of one after the other -- BASELINE config 2, three batches in flight: 40.4-41.6 -> 37.6-37.7 us per step.
+#ifndef GNNB_HS_WAVES
+#define GNNB_HS_WAVES 7
+#endif
 template <int ACT, bool GUEST>
-__global__ __launch_bounds__(HS_THREADS, 5) void k_head_small(PrepParams guest_kernarg, int prep_blocks, const float *__restrict__ pooled, int B,
+__global__ __launch_bounds__(HS_THREADS, GUEST ? 5 : GNNB_HS_WAVES) /* (the guest form carries the prep's code: 85 registers) */ void k_head_small(PrepParams guest_kernarg, int prep_blocks, const float *__restrict__ pooled, int B,
                                                              HeadArgs head, float *__restrict__ out, int ldact)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
