@@ -2,7 +2,9 @@
 
 The conv-stack kernel k_gcn2_zf runs four waves per SIMD; at <= 104 VGPRs they leave one 96-register wave slot per SIMD, and
 that slot is where graph prep and the readout of the other batches in flight run (at 109 registers the
-three-stream step went from 52 to 58 us without any test noticing)."""
+three-stream step went from 52 to 58 us without any test noticing).  Round 6: the forms of the BASELINE model family without
+the MLP-head tail hold 96, the hole beside four of them is 128 registers, and the step's two guests fit it TOGETHER -- a readout
+wave (<= 72) and a grouped graph-prep wave (<= 56): 40.4-41.6 -> 37.7 us per step at BASELINE config 2."""
 import re
 import shutil
 import subprocess
@@ -58,6 +60,21 @@ def test_kernels_that_share_a_cu_keep_their_register_budgets(tmp_path):
     assert guests
     for k, (v, a, _, _) in guests.items():
         assert v + a <= 96, f"{k}: {v} + {a} registers do not fit the slot the conv-stack kernel leaves"
+    # round 6: the 128-register hole beside four 96-register waves, shared by the readout and the grouped graph prep.
+    # (allocation granule: 8 registers)
+    def granule(n):
+        return (n + 7) // 8 * 8
+    # the forward's own kernels (HEAD = false: the last template argument) of the BASELINE family, fp32 (MX 0), wide shape (16 waves)
+    main = {k: v for k, v in regs.items() if re.search(r"k_gcn2_zfILi0ELi1ELi\d+ELi16ELi11ELi0ELb[01]ELb0EE", k)}
+    assert len(main) >= 6, sorted(regs)[:5]
+    for k, (v, a, _, _) in main.items():
+        assert granule(v + a) <= 96, f"{k}: {v} + {a} registers: four such waves leave less than 128 on a SIMD"
+    head = {k: v for k, v in regs.items() if re.search(r"k_head_smallILi\d+ELb0E", k)}  # (the plain readout, not the prep-hosting form)
+    prep = {k: v for k, v in regs.items() if re.search(r"k_graph_prepILi64ELi4E", k)}
+    assert head and prep
+    worst_head = max(granule(v + a) for v, a, _, _ in head.values())
+    worst_prep = max(granule(v + a) for v, a, _, _ in prep.values())
+    assert worst_head + worst_prep <= 128, f"readout {worst_head} + grouped graph prep {worst_prep} registers do not fit the hole together"
 
 
 @pytest.mark.skipif(not LIB.exists() or shutil.which(str(LLVM / "llvm-readelf")) is None, reason="library or LLVM tools missing")
