@@ -963,7 +963,7 @@ def main():
     # the prep-EXCLUDED rate (both side by side): topology tables re-used, only features change.  Same pipeline as
     # `value` -- the same streams, one prepared batch per workspace, the same K-step region and statistic -- so the two are
     # comparable; the one-stream figure (a single workspace, forwards back to back) is kept beside it
-    ms_noprep = ms_noprep_1s = None
+    ms_noprep = ms_noprep_1s = ms_noprep_1s_lat = None
     if not dry:
         pipe.prepare_topology()
         for i in range(max(args.warmup, pipe.nstreams)):
@@ -979,6 +979,20 @@ def main():
             cm.forward_prepared(x0, out=outs[0])
         torch.cuda.synchronize()
         ms_noprep_1s = (time.perf_counter() - t1) / nprep * 1e3
+        # ... and with the library's settings for ONE batch in flight (head_pairs = 0: the readout's four-operand form; prep_group = 1 is
+        # not involved here): the defaults trade ~2 us of this figure for the pipeline's step
+        runtime.set_option("head_pairs", 0)
+        try:
+            for _ in range(5):
+                cm.forward_prepared(x0, out=outs[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nprep):
+                cm.forward_prepared(x0, out=outs[0])
+            torch.cuda.synchronize()
+            ms_noprep_1s_lat = (time.perf_counter() - t1) / nprep * 1e3
+        finally:
+            runtime.set_option("head_pairs", 1)
 
     if world > 1:
         dist.barrier()
@@ -1020,9 +1034,10 @@ def main():
         "prepared_topology": None if ms_noprep is None else {
             "ms_per_step": ms_noprep, "value": graphs_done / (ms_noprep * 1e-3 * args.steps), "unit": "graphs/s",
             "batches_in_flight_per_gpu": nstreams, "ms_per_step_single_stream": ms_noprep_1s,
+            "ms_per_step_single_stream_head_pairs_0": ms_noprep_1s_lat,
             "note": "CSR build EXCLUDED: every workspace keeps one batch's tables prepared, only the features are read anew; "
                     "same streams / region / statistic as `value` (which includes the CSR build); single_stream = one workspace, "
-                    "forwards back to back on one stream"},
+                    "forwards back to back on one stream (head_pairs_0: with the option set for one batch in flight, gnnb_hip.h)"},
     }
     if other_form is not None:
         result["prep_next_pipeline" if not prep_next else "forward_batched_per_step"] = {

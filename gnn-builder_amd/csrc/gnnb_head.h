@@ -160,7 +160,9 @@ __device__ __forceinline__ void head_tail_run(const float *__restrict__ pooled, 
 // weights straight from L2 (shared by every workgroup); four accumulator chains over interleaved 16-wide k blocks.
 // `bar()` is the barrier that every wave of the WORKGROUP reaches once per layer and iteration -- groups without a tile
 // still call it (iters is workgroup-uniform).  sact: this group's LDS tile [2][16][ldact].
-template <int ACT, typename Barrier>
+// UW: k slices of a 64-wide block fetched and multiplied together -- 2 (default: the 72-register form, below) or 4 (82 registers, more
+// loads in flight: ~2 us faster when the kernel has the chip to itself; option head_pairs = 0).  Same accumulators, same sums.
+template <int ACT, int UW = 2, typename Barrier>
 __device__ __forceinline__ void head_small_run(const float *__restrict__ pooled, int g_begin, int g_end, const HeadArgs &head,
                                                float *__restrict__ out, int ldact, float *sact, int lane, int gw, int tile0,
                                                int tile_stride, int iters, Barrier bar)
@@ -194,14 +196,15 @@ __device__ __forceinline__ void head_small_run(const float *__restrict__ pooled,
                 // has 128 registers left, and a 72-register readout wave + a 56-register graph-prep wave now fit TOGETHER.
                 // (no operand double-buffering either: the register budget is what lets the stand-alone kernel share a SIMD with the
                 // conv-stack kernel of another batch, and inside k_gcn2_zf it must stay below that kernel's own budget)
+                static_assert(UW == 2 || UW == 4, "operand group width");
                 for (int kb = 0; kb < k; kb += 64) {
 #pragma unroll
-                    for (int hp = 0; hp < 2; hp++) {
-                        float4 a[2], w[2];
+                    for (int hp = 0; hp < 4 / UW; hp++) {
+                        float4 a[UW], w[UW];
 #pragma unroll
-                        for (int u2 = 0; u2 < 2; u2++) {
-                            const int kk = kb + 16 * (2 * hp + u2); // (+ 4 lg inside the row pointers)
-                            const bool ok = kk + 4 * lg < k;        // k % 4 == 0: a float4 is whole or absent
+                        for (int u2 = 0; u2 < UW; u2++) {
+                            const int kk = kb + 16 * (UW * hp + u2); // (+ 4 lg inside the row pointers)
+                            const bool ok = kk + 4 * lg < k;         // k % 4 == 0: a float4 is whole or absent
                             const int kc = ok ? kk : 0;
                             w[u2] = *reinterpret_cast<const float4 *>(wrow + kc);
                             a[u2] = l == 0 ? *reinterpret_cast<const float4 *>(arow_g + kc)  // layer 0: A straight from the pooled matrix
@@ -210,17 +213,17 @@ __device__ __forceinline__ void head_small_run(const float *__restrict__ pooled,
                                 a[u2] = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
 #pragma unroll
-                        for (int u2 = 0; u2 < 2; u2++)
-                            accs[2 * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].x, w[u2].x, accs[2 * hp + u2], 0, 0, 0);
+                        for (int u2 = 0; u2 < UW; u2++)
+                            accs[UW * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].x, w[u2].x, accs[UW * hp + u2], 0, 0, 0);
 #pragma unroll
-                        for (int u2 = 0; u2 < 2; u2++)
-                            accs[2 * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].y, w[u2].y, accs[2 * hp + u2], 0, 0, 0);
+                        for (int u2 = 0; u2 < UW; u2++)
+                            accs[UW * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].y, w[u2].y, accs[UW * hp + u2], 0, 0, 0);
 #pragma unroll
-                        for (int u2 = 0; u2 < 2; u2++)
-                            accs[2 * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].z, w[u2].z, accs[2 * hp + u2], 0, 0, 0);
+                        for (int u2 = 0; u2 < UW; u2++)
+                            accs[UW * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].z, w[u2].z, accs[UW * hp + u2], 0, 0, 0);
 #pragma unroll
-                        for (int u2 = 0; u2 < 2; u2++)
-                            accs[2 * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].w, w[u2].w, accs[2 * hp + u2], 0, 0, 0);
+                        for (int u2 = 0; u2 < UW; u2++)
+                            accs[UW * hp + u2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u2].w, w[u2].w, accs[UW * hp + u2], 0, 0, 0);
                     }
                 }
                 // C/D: col = lane&15 (output column nn), row = (lane>>4)*4 + r (graph inside the tile)

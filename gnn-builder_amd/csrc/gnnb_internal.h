@@ -136,6 +136,8 @@ struct Options {
     OptInt agg_rg_flags;    // ... bit 0: sources past the degree are not loaded (exec-masked; default) instead of aliasing the row itself;
                          //     bit 1: the run pre-touched line by line (slower); bits 2, 3: ablations (GCN, w = 128, one row-instruction)
     OptInt prep_group;      // graphs per wave of the molecule-path graph prep (k_graph_prep<64, G>: fetches batched): 4 (default; batches of >= 2047 graphs), 1
+    OptInt head_pairs;      // readout on a pooled matrix (k_head_small): 1 = operands in pairs, 72 registers: shares a SIMD with a graph-prep wave
+                         //     beside the stack kernel (default); 0 = four slices in flight, 82 registers: faster with one batch in flight
     OptInt guest_prep;      // 1 = gnnb_forward_prepared_prep_next runs the next batch's graph prep inside k_gcn2_zf where the batch is
                          //     eligible (default); 0 = always as k_graph_prep behind the forward
 };

@@ -61,7 +61,7 @@ Options &options()
                         env_int("GNNB_FUSE_GCN2", 1),         env_int("GNNB_FUSE_HEAD", 1), env_int("GNNB_FUSE_POOL", 1),
                         env_int("GNNB_HEAD_SMALL", 1),        env_int("GNNB_HEAD_SPLIT", 0),
                         env_int("GNNB_MATH", 0),              env_int("GNNB_GEMM_TAIL_SPLIT", 2), env_int("GNNB_PNA_FOLD_LIN", 1), env_int("GNNB_PNA_CLASSES", 1), env_int("GNNB_FOLD_SKIP", 1), env_int("GNNB_SAGE_FIRST_MEAN", 1), env_int("GNNB_PNA_FIRST", 1), env_int("GNNB_PNA_PAGG", 1), env_int("GNNB_STAGE_CUT", 0), env_int("GNNB_ZF_HEAD", 0),
-                        env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1), env_int("GNNB_PREP_GROUP", 4), env_int("GNNB_GUEST_PREP", 1)};
+                        env_int("GNNB_AGG_FORM", 0), env_int("GNNB_AGG_RG_R", 0), env_int("GNNB_AGG_RG_WGS", 0), env_int("GNNB_AGG_RG_FLAGS", 1), env_int("GNNB_PREP_GROUP", 4), env_int("GNNB_HEAD_PAIRS", 1), env_int("GNNB_GUEST_PREP", 1)};
     return o;
 }
 
@@ -286,6 +286,8 @@ int gnnb_set_option(const char *name, int value)
         o.zf_head = value;
     else if (!strcmp(name, "prep_group") && (value == 1 || value == 4))
         o.prep_group = value;
+    else if (!strcmp(name, "head_pairs") && value >= 0 && value <= 1)
+        o.head_pairs = value;
     else if (!strcmp(name, "guest_prep") && value >= 0 && value <= 1)
         o.guest_prep = value;
     else if (!strcmp(name, "agg_form") && value >= 0 && value <= 2)

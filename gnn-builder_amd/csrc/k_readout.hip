@@ -397,8 +397,10 @@ static constexpr int HS_THREADS = 256;
 #ifndef GNNB_HS_WAVES
 #define GNNB_HS_WAVES 7
 #endif
-template <int ACT, bool GUEST>
-__global__ __launch_bounds__(HS_THREADS, GUEST ? 5 : GNNB_HS_WAVES) /* (the guest form carries the prep's code: 85 registers) */ void k_head_small(PrepParams guest_kernarg, int prep_blocks, const float *__restrict__ pooled, int B,
+// PAIRS = false (option head_pairs = 0): four operand slices in flight, 82 registers -- the faster form when NOTHING shares the chip (one
+// stream of forwards: 49.8 vs 51.9 us per forward at BASELINE config 2), the slower one in the pipeline.
+template <int ACT, bool GUEST, bool PAIRS = true>
+__global__ __launch_bounds__(HS_THREADS, (GUEST || !PAIRS) ? 5 : GNNB_HS_WAVES) /* (the guest form carries the prep's code) */ void k_head_small(PrepParams guest_kernarg, int prep_blocks, const float *__restrict__ pooled, int B,
                                                              HeadArgs head, float *__restrict__ out, int ldact)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -414,7 +416,8 @@ __global__ __launch_bounds__(HS_THREADS, GUEST ? 5 : GNNB_HS_WAVES) /* (the gues
     }
     float *sact = reinterpret_cast<float *>(smem); // [2][16][ldact]: ldact = widest hidden layer + 4 (padded rows)
     // one workgroup = one group of four waves = one tile of 16 graphs (gnnb_head.h)
-    head_small_run<ACT>(pooled, 0, B, head, out, ldact, sact, lane, wave, (int)blockIdx.x - (GUEST ? prep_blocks : 0), 0, 1, [] { __syncthreads(); });
+    head_small_run<ACT, PAIRS ? 2 : 4>(pooled, 0, B, head, out, ldact, sact, lane, wave, (int)blockIdx.x - (GUEST ? prep_blocks : 0), 0, 1,
+                                       [] { __syncthreads(); });
 }
 
 // hipErrorNotSupported when the head's shape does not suit the small form (caller takes k_pool_mlp)
@@ -442,8 +445,10 @@ static hipError_t launch_head_small(int num_graphs, const HeadArgs &head, int ac
         constexpr int ACT = decltype(tag)::value;
         if (guest)
             hipLaunchKernelGGL((k_head_small<ACT, true>), dim3(grid + prep_blocks), dim3(HS_THREADS), lds, s, gp, prep_blocks, prepooled, num_graphs, head, out, ldact);
-        else
+        else if (options().head_pairs)
             hipLaunchKernelGGL((k_head_small<ACT, false>), dim3(grid), dim3(HS_THREADS), lds, s, gp, 0, prepooled, num_graphs, head, out, ldact);
+        else
+            hipLaunchKernelGGL((k_head_small<ACT, false, false>), dim3(grid), dim3(HS_THREADS), lds, s, gp, 0, prepooled, num_graphs, head, out, ldact);
     };
     GNNB_DISPATCH_ACT(act, go)
     const hipError_t rc = hipGetLastError();

@@ -412,6 +412,11 @@ int gnnb_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
  *                                prepares four consecutive graphs with its fetches batched (a quarter of the workgroups: cheaper
  *                                beside the stack kernels of other batches in flight); 1 = one graph per wave (lower latency when
  *                                the batch has the chip to itself).  Same tables
+ *   head_pairs (default 1)       the readout on a pooled matrix (k_head_small): 1 = its MFMA operands in pairs, 72 registers -- a readout
+ *                                wave and a graph-prep wave of another batch then share the registers the 2-layer GCN stack kernel
+ *                                leaves on a SIMD (batches in flight on several streams); 0 = four operand slices in flight, 82
+ *                                registers: ~2 us faster when one batch has the chip to itself.  Same bits.  Together with
+ *                                prep_group = 1: the settings for ONE stream of forwards
  *   guest_prep (default 1)       gnnb_forward_prepared_prep_next: 1 = the next batch's prep as extra workgroups of the readout
  *                                kernel where eligible; 0 = always a launch of its own behind the forward
  *   agg_form (default 0)         gather-aggregate kernel: 0 = LDS ring, 1 = barrier-free register gather (k_aggregate_rg) wherever

@@ -261,3 +261,23 @@ def test_three_streams_of_alternating_workspaces(dev):
             cm.check()
     for i in range(len(batches)):
         assert np.array_equal(outs[i].cpu().numpy(), want[i]), f"batch {i}"
+
+
+def test_both_forms_of_the_readout_and_of_the_prep_give_the_same_bits(dev):
+    """Options head_pairs (k_head_small's operands in pairs / four at once) and prep_group (graphs per prep wave) change register
+    counts and schedules, never results: the settings for one stream of forwards against the pipeline defaults."""
+    model = _model(seed=31)
+    batches = _qm9_batches((2500, 300), seed=80)
+    promise = max(int(np.diff(b.node_ptr).max()) for b in batches)
+    want, want_tabs = _run_plain(model, batches, dev, promise, want_tables=True)
+    try:
+        runtime.set_option("head_pairs", 0)
+        runtime.set_option("prep_group", 1)
+        got, got_tabs = _run_plain(model, batches, dev, promise, want_tables=True)
+    finally:
+        runtime.set_option("head_pairs", 1)
+        runtime.set_option("prep_group", 4)
+    for i in range(len(batches)):
+        assert np.array_equal(got[i], want[i])
+        for a, b in zip(got_tabs[i], want_tabs[i]):
+            assert np.array_equal(a, b)

@@ -69,7 +69,7 @@ def test_kernels_that_share_a_cu_keep_their_register_budgets(tmp_path):
     assert len(main) >= 6, sorted(regs)[:5]
     for k, (v, a, _, _) in main.items():
         assert granule(v + a) <= 96, f"{k}: {v} + {a} registers: four such waves leave less than 128 on a SIMD"
-    head = {k: v for k, v in regs.items() if re.search(r"k_head_smallILi\d+ELb0E", k)}  # (the plain readout, not the prep-hosting form)
+    head = {k: v for k, v in regs.items() if re.search(r"k_head_smallILi\d+ELb0ELb1E", k)}  # (the plain readout in its default, paired-operand form)
     prep = {k: v for k, v in regs.items() if re.search(r"k_graph_prepILi64ELi4E", k)}
     assert head and prep
     worst_head = max(granule(v + a) for v, a, _, _ in head.values())
